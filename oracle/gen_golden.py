@@ -1,0 +1,320 @@
+#!/usr/bin/env python3
+"""
+Golden-vector generator for the Matsuno dycore step.   TEST INFRASTRUCTURE ONLY.
+
+Runs ONLY in the build container (needs /root/reference, which never travels to
+the GPU box).  It imports the reference's own Python modules
+(dyn_matsuno.step_matsuno and everything below it) and executes their scalar
+formulae as plain IEEE-754 Python, then writes small .npz fixtures under
+tests/golden/.  Nothing of the reference's source text is copied: the fixtures
+hold inputs and outputs only.
+
+Why stand-ins are needed: the reference decorates its
+pure-Python scalar functions with numba.njit, and numba is not installed in
+this image.  The stand-ins written below (to a temp dir, at run time) are
+  * `numba`      : njit/jit = identity decorator, prange = range (the decorated
+                   functions are unchanged reference code, executed by CPython);
+                   ndarray arguments are viewed through a subclass whose scalar
+                   __getitem__ yields NaN for an out-of-range index (numba does
+                   no bounds check; the reference issues a few such loads whose
+                   values are never used), and a function that returns a
+                   never-assigned local yields 0 (dyn_functions.py:310/377,
+                   levels never consumed).
+  * `netCDF4`    : Dataset reader over scipy.io.netcdf_file (topography input).
+  * `scipy.interpolate.interp2d` : bilinear interpolation (removed from SciPy).
+  * `bin.rad_longwave_cython`    : empty (radiation is off).
+  * `namelist`   : the reference's namelist.py is executed, then the run-mode
+                   values are overridden (CPU mode, no restart, physics off,
+                   grid extents); the dlat->UVFLX_dif_coef table rule of
+                   namelist.py:286-316 is re-applied for the overridden dlat.
+Consequently the golden vectors are "the reference's formulae evaluated in
+IEEE fp64 by CPython/libm"; true numba bit patterns are unobtainable offline
+(numba sums sequentially where numpy sums pairwise, LLVM pow vs libm pow).
+Tolerances in tests/ are stated accordingly.
+
+Usage:
+    python oracle/gen_golden.py            # regenerate every fixture
+    python oracle/gen_golden.py --case g10x4_dry   # one case (subprocess body)
+"""
+import argparse
+import os
+import subprocess
+import sys
+import tempfile
+import textwrap
+
+import numpy as np
+
+REF = '/root/reference'
+HERE = os.path.dirname(os.path.abspath(__file__))
+GOLDEN = os.path.join(os.path.dirname(HERE), 'tests', 'golden')
+
+# name -> (dlat=dlon [deg], nz, n_steps, snapshot steps, stage capture, turb variant)
+CASES = {
+    'g10x4_dry':  dict(d=10, nz=4, steps=10, snaps=(1, 2, 10), stages=True,  turb=False),
+    'g10x4_turb': dict(d=10, nz=4, steps=1,  snaps=(1,),       stages=True,  turb=True),
+    'g4x8_dry':   dict(d=4,  nz=8, steps=10, snaps=(1, 10),    stages=False, turb=False),
+}
+
+NUMBA_SHIM = r'''
+import numpy as _np
+class _OOB(_np.ndarray):
+    """ndarray view: scalar out-of-range read -> NaN (numba has no bounds check)."""
+    def __getitem__(self, idx):
+        try:
+            return _np.ndarray.__getitem__(self, idx)
+        except IndexError:
+            return _np.float64('nan')
+def _wrap(f):
+    def g(*args):
+        args = tuple(a.view(_OOB) if type(a) is _np.ndarray else a for a in args)
+        try:
+            return f(*args)
+        except UnboundLocalError:
+            return 0.0
+    g.__name__ = getattr(f, '__name__', 'g')
+    g.__wrapped__ = f
+    return g
+def njit(*args, **kwargs):
+    if args and callable(args[0]):
+        return _wrap(args[0])
+    return lambda f: _wrap(f)
+jit = njit
+prange = range
+def vectorize(*args, **kwargs):
+    return lambda f: _np.vectorize(f)
+float32 = 'float32'
+float64 = 'float64'
+class _Cuda:
+    def __getattr__(self, name):
+        raise RuntimeError('numba.cuda stand-in: GPU path not available')
+cuda = _Cuda()
+class config:
+    NUMBA_DEFAULT_NUM_THREADS = 1
+'''
+
+NETCDF4_SHIM = r'''
+from scipy.io import netcdf_file as _ncf
+import numpy as _np
+class _Var:
+    def __init__(self, v):
+        self._v = v
+    def __getitem__(self, idx):
+        return _np.array(self._v.data[idx], dtype=_np.float64)
+class Dataset:
+    def __init__(self, filename, mode='r', format=None):
+        self._f = _ncf(filename, 'r', mmap=False)
+    def __getitem__(self, name):
+        return _Var(self._f.variables[name])
+'''
+
+NAMELIST_SHIM = r'''
+import runpy as _runpy
+_g = _runpy.run_path(%(ref)r + '/namelist.py')
+globals().update({k: v for k, v in _g.items() if not k.startswith('__')})
+# ---- run-mode overrides (SURVEY.md 8a "dry-dycore definition") ----
+i_comp_mode = 1
+i_load_from_restart = 0
+i_save_to_restart = 0
+i_load_from_IC = 0
+i_radiation = 0
+i_microphysics = 0
+i_turbulence = 0
+i_surface_scheme = 0
+working_precision = %(wp)r
+nz = %(nz)d
+lat0_deg = -90
+lat1_deg = 90
+dlat_deg = %(d)r
+dlon_deg = %(d)r
+i_sim_n_days = 1
+i_out_nth_hour = 1
+# ---- namelist.py:286-316 table rule, re-applied for the overridden dlat ----
+UVFLX_dif_coef = 0
+POTT_dif_coef = 1E-5
+COLP_dif_coef = 0
+moist_dif_coef = POTT_dif_coef
+_tab = {10: 1.5, 8: 1.5, 6: 1.8, 5: 2, 4: 2.5, 3: 3.3, 2: 5, 1.5: 7.5}
+if dlat_deg in _tab:
+    UVFLX_dif_coef = _tab[dlat_deg]
+elif dlat_deg <= 1:
+    UVFLX_dif_coef = 10
+UVFLX_dif_coef *= 2.0
+'''
+
+
+def _install_shims(tmp, d, nz, wp):
+    os.makedirs(os.path.join(tmp, 'numba'))
+    with open(os.path.join(tmp, 'numba', '__init__.py'), 'w') as f:
+        f.write(NUMBA_SHIM)
+    with open(os.path.join(tmp, 'netCDF4.py'), 'w') as f:
+        f.write(NETCDF4_SHIM)
+    os.makedirs(os.path.join(tmp, 'bin'))
+    open(os.path.join(tmp, 'bin', '__init__.py'), 'w').close()
+    with open(os.path.join(tmp, 'bin', 'rad_longwave_cython.py'), 'w') as f:
+        for fn in ('calc_planck_intensity_c', 'calc_surface_emission_c',
+                   'rad_calc_LW_RTE_matrix_c'):
+            f.write('def %s(*a, **k):\n    raise NotImplementedError\n' % fn)
+    with open(os.path.join(tmp, 'namelist.py'), 'w') as f:
+        f.write(NAMELIST_SHIM % dict(ref=REF, d=d, nz=nz, wp=wp))
+
+    # scipy.interpolate.interp2d (removed in SciPy >= 1.14): bilinear, nearest outside.
+    import scipy.interpolate as si
+    from scipy.interpolate import RegularGridInterpolator
+
+    class interp2d:
+        def __init__(self, x, y, z, kind='linear'):
+            x = np.asarray(x, dtype=np.float64).ravel()
+            y = np.asarray(y, dtype=np.float64).ravel()
+            z = np.asarray(z, dtype=np.float64)
+            ix, iy = np.argsort(x), np.argsort(y)
+            self.x, self.y = x[ix], y[iy]
+            self.rgi = RegularGridInterpolator((self.y, self.x), z[np.ix_(iy, ix)],
+                                               method='linear')
+
+        def __call__(self, xn, yn):
+            xn = np.sort(np.atleast_1d(np.asarray(xn, dtype=np.float64)))
+            yn = np.sort(np.atleast_1d(np.asarray(yn, dtype=np.float64)))
+            xc = np.clip(xn, self.x[0], self.x[-1])
+            yc = np.clip(yn, self.y[0], self.y[-1])
+            yy, xx = np.meshgrid(yc, xc, indexing='ij')
+            return self.rgi(np.stack([yy.ravel(), xx.ravel()], -1)).reshape(len(yn), len(xn))
+    si.interp2d = interp2d
+
+
+GRID_CONSTS = ['corf', 'corf_is', 'A', 'sigma_vb', 'dsigma', 'dxjs', 'dyis',
+               'lat_rad', 'lat_is_rad', 'dlat_rad', 'dlon_rad',
+               'POTT_dif_coef', 'UVFLX_dif_coef', 'moist_dif_coef']
+PROGNOSTIC = ['COLP', 'UWIND', 'VWIND', 'POTT', 'QV', 'QC']
+
+
+def run_case(name):
+    cfg = CASES[name]
+    sys.dont_write_bytecode = True
+    tmp = tempfile.mkdtemp(prefix='golden_shims_')
+    _install_shims(tmp, cfg['d'], cfg['nz'], 'float64')
+    sys.path.insert(0, REF)
+    sys.path.insert(0, tmp)
+    os.chdir(REF)            # the reference opens data/... relative to cwd
+
+    from io_read_namelist import CPU
+    from main_grid import Grid
+    from main_fields import ModelFields
+    import dyn_tendencies
+    import dyn_matsuno
+    from dyn_org_discretizations import DiagnosticsFactory
+    from namelist import pair_top
+
+    GR = Grid()
+    F = ModelFields(GR, False)
+    Diagnostics = DiagnosticsFactory(target=CPU)
+    T = dyn_tendencies.Tendencies
+    P = dyn_matsuno.Prognostics
+    D = dyn_matsuno.Diagnostics
+
+    hot = []
+    for lst in (T.fields_continuity, T.fields_momentum, T.fields_temperature,
+                T.fields_moisture, D.fields_primary_diag, D.fields_secondary_diag,
+                P.fields_prognostic):
+        for n in lst:
+            if n not in hot:
+                hot.append(n)
+
+    rng = np.random.default_rng(11)
+    # physics-produced inputs: 0 in the dry definition, random in the turb variant
+    for n in ['KMOM', 'KHEAT', 'SSHFLX', 'SLHFLX', 'SMOMXFLX', 'SMOMYFLX', 'dPOTTdt_RAD']:
+        F.host[n][:] = 0.
+    if cfg['turb']:
+        F.host['KMOM'][:] = rng.uniform(0.5, 20., F.host['KMOM'].shape)
+        F.host['KHEAT'][:] = rng.uniform(0.5, 20., F.host['KHEAT'].shape)
+        F.host['SSHFLX'][:] = rng.uniform(-50., 150., F.host['SSHFLX'].shape)
+        F.host['SLHFLX'][:] = rng.uniform(-20., 200., F.host['SLHFLX'].shape)
+        F.host['SMOMXFLX'][:] = rng.uniform(-0.2, 0.2, F.host['SMOMXFLX'].shape)
+        F.host['SMOMYFLX'][:] = rng.uniform(-0.2, 0.2, F.host['SMOMYFLX'].shape)
+
+    out = {}
+    out['meta/nx'] = np.int64(GR.nx)
+    out['meta/ny'] = np.int64(GR.ny)
+    out['meta/nz'] = np.int64(GR.nz)
+    out['meta/nb'] = np.int64(GR.nb)
+    out['meta/dt'] = np.int64(GR.dt)
+    out['meta/pair_top'] = np.float64(pair_top)
+    out['meta/dlat_deg'] = np.float64(cfg['d'])
+    for n in GRID_CONSTS:
+        out['grid/' + n] = np.array(GR.GRF[CPU][n])
+    out['ic/HSURF'] = F.host['HSURF'].copy()
+    for n in PROGNOSTIC + ['KMOM', 'KHEAT', 'SSHFLX', 'SLHFLX', 'SMOMXFLX', 'SMOMYFLX',
+                           'dPOTTdt_RAD', 'WWIND', 'POTTVB']:
+        out['ic/' + n] = F.host[n].copy()
+
+    # solver.py:70-73
+    Diagnostics.primary_diag(GR.GRF[CPU], **F.get(Diagnostics.fields_primary_diag, target=CPU))
+
+    # ---------------- stage capture (first step only) ----------------
+    state = {'last': {}, 'seq': []}
+
+    def capture(tag, full=False):
+        for n in hot:
+            a = F.host[n]
+            prev = state['last'].get(n)
+            if full or prev is None or not np.array_equal(a, prev, equal_nan=True):
+                out['%s/%s' % (tag, n)] = a.copy()
+                state['last'][n] = a.copy()
+        state['seq'].append(tag)
+
+    def hook(obj, meth, label):
+        orig = getattr(obj, meth)
+
+        def wrapped(*a, **k):
+            r = orig(*a, **k)
+            if state.get('on'):
+                state['n'] = state.get('n', 0) + 1
+                capture('st%02d_%s' % (state['n'], label))
+            return r
+        setattr(obj, meth, wrapped)
+
+    if cfg['stages']:
+        hook(T, 'continuity', 'continuity')
+        hook(T, 'momentum', 'momentum')
+        hook(T, 'temperature', 'temperature')
+        hook(T, 'moisture', 'moisture')
+        hook(P, 'euler_forward', 'euler_forward')
+        hook(D, 'primary_diag', 'primary_diag')
+
+    for ts in range(1, cfg['steps'] + 1):
+        Diagnostics.secondary_diag(**F.get(Diagnostics.fields_secondary_diag, target=CPU))
+        if ts == 1 and cfg['stages']:
+            capture('st00_pre', full=True)
+            state['on'] = True
+        dyn_matsuno.step_matsuno(GR, F)
+        state['on'] = False
+        if ts in cfg['snaps']:
+            for n in PROGNOSTIC:
+                out['step%03d/%s' % (ts, n)] = F.host[n].copy()
+        umax = np.nanmax(np.abs(F.host['UWIND'][1:-1, 1:-1, :]))
+        print('[%s] step %d  max|U| = %.6f  mean COLP = %.3f' % (
+            name, ts, umax, np.nanmean(F.host['COLP'][1:-1, 1:-1, 0])), flush=True)
+        if not np.isfinite(umax):
+            raise RuntimeError('reference run produced non-finite UWIND')
+    if cfg['stages']:
+        out['meta/stage_seq'] = np.array(state['seq'])
+
+    os.makedirs(GOLDEN, exist_ok=True)
+    path = os.path.join(GOLDEN, name + '.npz')
+    np.savez_compressed(path, **out)
+    print('wrote', path, os.path.getsize(path), 'bytes')
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--case', default=None)
+    args = ap.parse_args()
+    if args.case:
+        run_case(args.case)
+        return
+    for name in CASES:
+        subprocess.run([sys.executable, os.path.abspath(__file__), '--case', name], check=True)
+
+
+if __name__ == '__main__':
+    main()

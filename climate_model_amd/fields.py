@@ -1,0 +1,152 @@
+"""Model-field registry and host/device field container for the dycore hot path.
+
+Mirrors the part of the reference's `main_fields.py` the Matsuno step touches:
+the field table (main_fields.py:234-475: staggering and vertical extent of each
+array), NaN-initialised host arrays in the reference's C-order [i, j, k] layout
+(main_fields.py:477-485), and the get/set/copy_* accessors
+(main_fields.py:184-215).  The device side holds `DeviceField` handles naming
+buffers that live inside the HIP dycore handle (i-fastest [k][j][i] layout, see
+DESIGN.md); the layout adaptor runs on upload/download.
+"""
+from collections import OrderedDict
+
+import numpy as np
+
+CPU = 'CPU'
+HIP = 'HIP'
+
+# name -> (stgx, stgy, vertical extent: 'nz' | 'nzs' | 1)
+FIELD_TABLE = OrderedDict([
+    # pressure
+    ('COLP',          (0, 0, 1)),
+    ('COLP_OLD',      (0, 0, 1)),
+    ('COLP_NEW',      (0, 0, 1)),
+    ('dCOLPdt',       (0, 0, 1)),
+    ('HSURF',         (0, 0, 1)),
+    # fluxes
+    ('UFLX',          (1, 0, 'nz')),
+    ('dUFLXdt',       (1, 0, 'nz')),
+    ('VFLX',          (0, 1, 'nz')),
+    ('dVFLXdt',       (0, 1, 'nz')),
+    ('FLXDIV',        (0, 0, 'nz')),
+    ('BFLX',          (0, 0, 'nz')),
+    ('CFLX',          (1, 1, 'nz')),
+    ('DFLX',          (0, 1, 'nz')),
+    ('EFLX',          (0, 1, 'nz')),
+    ('RFLX',          (0, 0, 'nz')),
+    ('QFLX',          (1, 1, 'nz')),
+    ('SFLX',          (1, 0, 'nz')),
+    ('TFLX',          (1, 0, 'nz')),
+    # velocities
+    ('UWIND',         (1, 0, 'nz')),
+    ('UWIND_OLD',     (1, 0, 'nz')),
+    ('VWIND',         (0, 1, 'nz')),
+    ('VWIND_OLD',     (0, 1, 'nz')),
+    ('WWIND',         (0, 0, 'nzs')),
+    ('WWIND_UWIND',   (1, 0, 'nzs')),
+    ('WWIND_VWIND',   (0, 1, 'nzs')),
+    ('KMOM_dUWINDdz', (1, 0, 'nzs')),
+    ('KMOM_dVWINDdz', (0, 1, 'nzs')),
+    # temperature
+    ('POTT',          (0, 0, 'nz')),
+    ('POTT_OLD',      (0, 0, 'nz')),
+    ('dPOTTdt',       (0, 0, 'nz')),
+    ('POTTVB',        (0, 0, 'nzs')),
+    # primary diagnostics
+    ('PVTF',          (0, 0, 'nz')),
+    ('PVTFVB',        (0, 0, 'nzs')),
+    ('PHI',           (0, 0, 'nz')),
+    ('PHIVB',         (0, 0, 'nzs')),
+    # secondary diagnostics / physics inputs the dycore consumes
+    ('RHO',           (0, 0, 'nz')),
+    ('RHOVB',         (0, 0, 'nzs')),
+    ('KMOM',          (0, 0, 'nzs')),
+    ('KHEAT',         (0, 0, 'nzs')),
+    ('SSHFLX',        (0, 0, 1)),
+    ('SMOMXFLX',      (0, 0, 1)),
+    ('SMOMYFLX',      (0, 0, 1)),
+    ('dPOTTdt_RAD',   (0, 0, 'nz')),
+    ('dUFLXdt_TURB',  (1, 0, 'nz')),
+    ('dVFLXdt_TURB',  (0, 1, 'nz')),
+    ('dPOTTdt_TURB',  (0, 0, 'nz')),
+])
+
+# fields the reference also passes through the factory signatures but that the
+# dry/turbulence-coupled dycore does not own (moisture = SURVEY.md 8f "next" row)
+PASS_THROUGH_FIELDS = ('QV', 'QV_OLD', 'QC', 'QC_OLD', 'dQVdt', 'dQCdt')
+
+
+def field_shape(name, nx, ny, nz, nb=1):
+    """Host shape (reference layout) of a field: main_fields.py:477-485."""
+    stgx, stgy, nk = FIELD_TABLE[name]
+    nk = {'nz': nz, 'nzs': nz + 1}.get(nk, nk)
+    return (nx + 2 * nb + stgx, ny + 2 * nb + stgy, nk)
+
+
+def allocate_fields(nx, ny, nz, dtype=np.float64):
+    """NaN-filled host arrays for every hot-path field (main_fields.py:477-485)."""
+    return OrderedDict((name, np.full(field_shape(name, nx, ny, nz), np.nan, dtype=dtype))
+                       for name in FIELD_TABLE)
+
+
+class DeviceField:
+    """Names one field buffer that lives inside a HIP dycore handle."""
+    __slots__ = ('name', 'core')
+
+    def __init__(self, name, core):
+        self.name = name
+        self.core = core
+
+    def __repr__(self):
+        return 'DeviceField(%s)' % self.name
+
+
+class ModelFields:
+    """Host dict + device mirror; same accessors as main_fields.py:184-215."""
+
+    ALL_FIELDS = 'all_fields'
+    PROGNOSTIC_FIELDS = 'prognostic_fields'
+    PRINT_DIAG_FIELDS = 'print_diag_fields'
+
+    def __init__(self, GR, core=None, dtype=np.float64):
+        self.host = allocate_fields(GR.nx, GR.ny, GR.nz, dtype=dtype)
+        self.device = {}
+        self.core = core
+        self.field_groups = {
+            self.ALL_FIELDS: list(self.host.keys()),
+            self.PROGNOSTIC_FIELDS: ['COLP', 'UWIND', 'VWIND', 'POTT'],
+            self.PRINT_DIAG_FIELDS: ['COLP', 'UWIND', 'POTT'],
+        }
+        # non-NaN values the kernels rely on (io_initial_conditions.py:45-46)
+        self.host['POTTVB'][:] = 0.
+        self.host['WWIND'][:] = 0.
+        # physics-produced inputs: zero in the dry dycore
+        for n in ('KMOM', 'KHEAT', 'SSHFLX', 'SMOMXFLX', 'SMOMYFLX', 'dPOTTdt_RAD'):
+            self.host[n][:] = 0.
+        if core is not None:
+            self.attach(core)
+
+    def attach(self, core):
+        self.core = core
+        self.device = {name: DeviceField(name, core) for name in self.host}
+        for name in PASS_THROUGH_FIELDS:
+            self.device[name] = None
+
+    def get(self, field_names, target=CPU):
+        src = self.host if target == CPU else self.device
+        return {name: src.get(name) for name in field_names}
+
+    def set(self, field_dict, target=CPU):
+        dst = self.host if target == CPU else self.device
+        for name, field in field_dict.items():
+            dst[name] = field
+
+    def copy_host_to_device(self, GR=None, field_group=ALL_FIELDS):
+        names = self.field_groups.get(field_group, field_group)
+        for name in names:
+            self.core.upload(name, self.host[name])
+
+    def copy_device_to_host(self, GR=None, field_group=ALL_FIELDS):
+        names = self.field_groups.get(field_group, field_group)
+        for name in names:
+            self.core.download(name, self.host[name])

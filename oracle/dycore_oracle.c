@@ -1,0 +1,715 @@
+/*
+ * dycore_oracle.c -- CPU restatement of the reference's Matsuno dycore step.
+ * TEST INFRASTRUCTURE ONLY (see dycore_oracle.h).  Plain C + OpenMP, fp64.
+ *
+ * Structured like the reference's CPU kernels on purpose (it doubles as the
+ * "restated CPU baseline" timed by bench.py): [i][j][k] k-contiguous arrays,
+ * one function per reference kernel, `omp parallel for` over i where the
+ * reference uses njit(parallel=True)+prange(i), serial where it does not
+ * (dyn_timestep.py:297).
+ *
+ * Deliberate differences from the reference (none changes a value that
+ * survives the following exchange_BC):
+ *   - loads the reference issues out of bounds / from never-written halos and
+ *     then discards are not issued; the cells they would have
+ *     produced (dUFLXdt column nx+1, dVFLXdt rows 1 and ny+1, UWIND/VWIND/POTT
+ *     halo cells in make_timestep) are left untouched here;
+ *   - dCOLPdt is summed sequentially in k (numba order), not numpy-pairwise.
+ */
+#include "dycore_oracle.h"
+
+#include <math.h>
+#include <stddef.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+/* io_constants.py:15-20 */
+#define CON_G 9.81
+#define CON_RE 6371000.0
+#define CON_RD 287.058
+#define CON_CP 1005.0
+#define CON_KAPPA (CON_RD / CON_CP)
+
+#define AT(F, i, j, k, stgy, nk) \
+    (F)[((size_t)(i) * (size_t)(ny + 2 + (stgy)) + (size_t)(j)) * (size_t)(nk) + (size_t)(k)]
+/* 2-D (.., .., 1) fields */
+#define A2(F, i, j) AT(F, i, j, 0, 0, 1)
+#define A2S(F, i, j) AT(F, i, j, 0, 1, 1)
+
+#ifdef _OPENMP
+#define PAR_FOR _Pragma("omp parallel for schedule(static) num_threads(nthr)")
+static int nthreads_of(const oracle_cfg *c)
+{
+    return c->nthreads > 0 ? c->nthreads : omp_get_max_threads();
+}
+#else
+#define PAR_FOR
+static int nthreads_of(const oracle_cfg *c) { (void)c; return 1; }
+#endif
+
+/* ------------------------------------------------------------------------- */
+/* misc_boundaries.py:22-42 */
+void oracle_exchange_bc(const oracle_cfg *c, double *F, int stgx, int stgy, int nk)
+{
+    const int nx = c->nx, ny = c->ny;
+    const int nxs = nx + 1, nys = ny + 1;
+    const int fny = ny + 2 + stgy;
+    const size_t col = (size_t)fny * nk;
+    if (stgx) {
+        memcpy(F, F + (size_t)(nxs - 1) * col, col * sizeof(double));
+        memcpy(F + (size_t)nxs * col, F + 1 * col, col * sizeof(double));
+        memcpy(F + (size_t)(nxs + 1) * col, F + 2 * col, col * sizeof(double));
+    } else {
+        memcpy(F, F + (size_t)nx * col, col * sizeof(double));
+        memcpy(F + (size_t)(nx + 1) * col, F + 1 * col, col * sizeof(double));
+    }
+    const int fnx = nx + 2 + stgx;
+    for (int i = 0; i < fnx; i++) {
+        double *Fi = F + (size_t)i * col;
+        if (stgy) {
+            const int rows[4] = {0, 1, nys, nys + 1};
+            for (int r = 0; r < 4; r++)
+                for (int k = 0; k < nk; k++) Fi[(size_t)rows[r] * nk + k] = 0.0;
+        } else {
+            for (int k = 0; k < nk; k++) {
+                Fi[k] = Fi[(size_t)1 * nk + k];
+                Fi[(size_t)(ny + 1) * nk + k] = Fi[(size_t)ny * nk + k];
+            }
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------- */
+/* dyn_continuity.py:40-47 (formulae), :170-232 (loops) */
+void oracle_continuity(const oracle_cfg *c, const oracle_grid *g, oracle_fields *f, double dt)
+{
+    const int nx = c->nx, ny = c->ny, nz = c->nz, nzs = nz + 1;
+    const int nthr = nthreads_of(c);
+    (void)nthr;
+    PAR_FOR
+    for (int i = 1; i < nx + 1; i++) {
+        for (int j = 1; j < ny + 1; j++) {
+            const double colp = A2(f->COLP, i, j);
+            const double c_im1 = A2(f->COLP, i - 1, j), c_ip1 = A2(f->COLP, i + 1, j);
+            const double c_jm1 = A2(f->COLP, i, j - 1), c_jp1 = A2(f->COLP, i, j + 1);
+            const double dy_i = AT(g->dyis, i, j, 0, 0, 1), dy_ip1 = AT(g->dyis, i + 1, j, 0, 0, 1);
+            const double dx_j = A2S(g->dxjs, i, j), dx_jp1 = A2S(g->dxjs, i, j + 1);
+            const double area = A2(g->A, i, j);
+            double sum = 0.0;
+            for (int k = 0; k < nz; k++) {
+                const double uflx_i = (c_im1 + colp) / 2.0 * AT(f->UWIND, i, j, k, 0, nz) * dy_i;
+                const double uflx_ip1 = (colp + c_ip1) / 2.0 * AT(f->UWIND, i + 1, j, k, 0, nz) * dy_ip1;
+                const double vflx_j = (c_jm1 + colp) / 2.0 * AT(f->VWIND, i, j, k, 1, nz) * dx_j;
+                const double vflx_jp1 = (colp + c_jp1) / 2.0 * AT(f->VWIND, i, j + 1, k, 1, nz) * dx_jp1;
+                AT(f->UFLX, i, j, k, 0, nz) = uflx_i;
+                AT(f->VFLX, i, j, k, 1, nz) = vflx_j;
+                const double div = (uflx_ip1 - uflx_i + vflx_jp1 - vflx_j) * g->dsigma[k] / area;
+                AT(f->FLXDIV, i, j, k, 0, nz) = div;
+                sum += div;
+            }
+            const double dcolpdt = -sum;                               /* :212 */
+            const double colp_new = A2(f->COLP_OLD, i, j) + dt * dcolpdt; /* :218 */
+            A2(f->dCOLPdt, i, j) = dcolpdt;
+            A2(f->COLP_NEW, i, j) = colp_new;
+            double run = AT(f->FLXDIV, i, j, 0, 0, nz);                /* :222-229 */
+            for (int k = 1; k < nz; k++) {
+                AT(f->WWIND, i, j, k, 0, nzs) =
+                    -run / colp_new - g->sigma_vb[k] * dcolpdt / colp_new;
+                run += AT(f->FLXDIV, i, j, k, 0, nz);
+            }
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------- */
+/* dyn_UVFLX_prepare.py:249-439 */
+void oracle_uvflx_prepare(const oracle_cfg *c, const oracle_grid *g, oracle_fields *f)
+{
+    const int nx = c->nx, ny = c->ny, nz = c->nz, nzs = nz + 1;
+    const int nthr = nthreads_of(c);
+    (void)nthr;
+    /* ---- WWIND_UWIND (:262-280), rigid wall at j = 1 and j = ny ---- */
+    PAR_FOR
+    for (int i = 1; i < nx + 2; i++)
+        for (int j = 1; j < ny + 1; j++) {
+            AT(f->WWIND_UWIND, i, j, 0, 0, nzs) = 0.0;
+            AT(f->WWIND_UWIND, i, j, nz, 0, nzs) = 0.0;
+            const int lo = (j == 1), hi = (j == ny);
+            for (int k = 1; k < nz; k++) {
+                /* products are formed as COLP_NEW*A*WWIND, doubled terms as 2*COLP_NEW*A*WWIND */
+                const double p_pp1_dm1 = A2(f->COLP_NEW, i - 1, j + 1) * A2(g->A, i - 1, j + 1) * AT(f->WWIND, i - 1, j + 1, k, 0, nzs);
+                const double p_pp1 = A2(f->COLP_NEW, i, j + 1) * A2(g->A, i, j + 1) * AT(f->WWIND, i, j + 1, k, 0, nzs);
+                const double p_pm1_dm1 = A2(f->COLP_NEW, i - 1, j - 1) * A2(g->A, i - 1, j - 1) * AT(f->WWIND, i - 1, j - 1, k, 0, nzs);
+                const double p_pm1 = A2(f->COLP_NEW, i, j - 1) * A2(g->A, i, j - 1) * AT(f->WWIND, i, j - 1, k, 0, nzs);
+                double s;
+                if (lo || hi) {
+                    const double p_dm1 = A2(f->COLP_NEW, i - 1, j) * A2(g->A, i - 1, j) * AT(f->WWIND, i - 1, j, k, 0, nzs);
+                    const double p_0 = A2(f->COLP_NEW, i, j) * A2(g->A, i, j) * AT(f->WWIND, i, j, k, 0, nzs);
+                    s = lo ? 0.25 * (p_pp1_dm1 + p_pp1 + p_dm1 + p_0)
+                           : 0.25 * (p_dm1 + p_0 + p_pm1_dm1 + p_pm1);
+                } else {
+                    const double d_dm1 = 2.0 * A2(f->COLP_NEW, i - 1, j) * A2(g->A, i - 1, j) * AT(f->WWIND, i - 1, j, k, 0, nzs);
+                    const double d_0 = 2.0 * A2(f->COLP_NEW, i, j) * A2(g->A, i, j) * AT(f->WWIND, i, j, k, 0, nzs);
+                    s = 0.125 * (p_pp1_dm1 + p_pp1 + d_dm1 + d_0 + p_pm1_dm1 + p_pm1);
+                }
+                const double u_ks = (g->dsigma[k] * AT(f->UWIND, i, j, k - 1, 0, nz) +
+                                     g->dsigma[k - 1] * AT(f->UWIND, i, j, k, 0, nz)) /
+                                    (g->dsigma[k] + g->dsigma[k - 1]);
+                AT(f->WWIND_UWIND, i, j, k, 0, nzs) = s * u_ks;
+            }
+        }
+    /* ---- WWIND_VWIND (:282-300), no wall variant ---- */
+    PAR_FOR
+    for (int i = 1; i < nx + 1; i++)
+        for (int j = 1; j < ny + 2; j++) {
+            AT(f->WWIND_VWIND, i, j, 0, 1, nzs) = 0.0;
+            AT(f->WWIND_VWIND, i, j, nz, 1, nzs) = 0.0;
+            for (int k = 1; k < nz; k++) {
+                const double p_pp1_dm1 = A2(f->COLP_NEW, i + 1, j - 1) * A2(g->A, i + 1, j - 1) * AT(f->WWIND, i + 1, j - 1, k, 0, nzs);
+                const double p_pp1 = A2(f->COLP_NEW, i + 1, j) * A2(g->A, i + 1, j) * AT(f->WWIND, i + 1, j, k, 0, nzs);
+                const double d_dm1 = 2.0 * A2(f->COLP_NEW, i, j - 1) * A2(g->A, i, j - 1) * AT(f->WWIND, i, j - 1, k, 0, nzs);
+                const double d_0 = 2.0 * A2(f->COLP_NEW, i, j) * A2(g->A, i, j) * AT(f->WWIND, i, j, k, 0, nzs);
+                const double p_pm1_dm1 = A2(f->COLP_NEW, i - 1, j - 1) * A2(g->A, i - 1, j - 1) * AT(f->WWIND, i - 1, j - 1, k, 0, nzs);
+                const double p_pm1 = A2(f->COLP_NEW, i - 1, j) * A2(g->A, i - 1, j) * AT(f->WWIND, i - 1, j, k, 0, nzs);
+                const double s = 0.125 * (p_pp1_dm1 + p_pp1 + d_dm1 + d_0 + p_pm1_dm1 + p_pm1);
+                const double v_ks = (g->dsigma[k] * AT(f->VWIND, i, j, k - 1, 1, nz) +
+                                     g->dsigma[k - 1] * AT(f->VWIND, i, j, k, 1, nz)) /
+                                    (g->dsigma[k] + g->dsigma[k - 1]);
+                AT(f->WWIND_VWIND, i, j, k, 1, nzs) = s * v_ks;
+            }
+        }
+    /* ---- KMOM_dUWINDdz / KMOM_dVWINDdz (:303-352; dyn_functions.py:276-377) ---- */
+    if (c->i_turb) {
+#define RK(ii, jj) (AT(f->RHOVB, ii, jj, k, 0, nzs) * A2(f->COLP, ii, jj) * A2(g->A, ii, jj) * AT(f->KMOM, ii, jj, k, 0, nzs))
+#define RK2(ii, jj) (2.0 * AT(f->RHOVB, ii, jj, k, 0, nzs) * A2(f->COLP, ii, jj) * A2(g->A, ii, jj) * AT(f->KMOM, ii, jj, k, 0, nzs))
+#define PH(ii, jj, kk) AT(f->PHI, ii, jj, kk, 0, nz)
+        PAR_FOR
+        for (int i = 1; i < nx + 2; i++)
+            for (int j = 1; j < ny + 1; j++) {
+                /* k = 0 and k = nz: the reference returns an unassigned local
+                 * (dyn_functions.py:310 vs :377); never consumed -> 0 */
+                AT(f->KMOM_dUWINDdz, i, j, 0, 0, nzs) = 0.0;
+                AT(f->KMOM_dUWINDdz, i, j, nz, 0, nzs) = 0.0;
+                const int lo = (j == 1), hi = (j == ny);
+                for (int k = 1; k < nz; k++) {
+                    double cak, alt_km1, alt;
+                    if (lo) {
+                        cak = 0.25 * (RK(i - 1, j + 1) + RK(i, j + 1) + RK(i - 1, j) + RK(i, j));
+                        alt_km1 = 0.25 * (PH(i - 1, j + 1, k - 1) + PH(i, j + 1, k - 1) + PH(i - 1, j, k - 1) + PH(i, j, k - 1)) / CON_G;
+                        alt = 0.25 * (PH(i - 1, j + 1, k) + PH(i, j + 1, k) + PH(i - 1, j, k) + PH(i, j, k)) / CON_G;
+                    } else if (hi) {
+                        cak = 0.25 * (RK(i - 1, j) + RK(i, j) + RK(i - 1, j - 1) + RK(i, j - 1));
+                        alt_km1 = 0.25 * (PH(i - 1, j, k - 1) + PH(i, j, k - 1) + PH(i - 1, j - 1, k - 1) + PH(i, j - 1, k - 1)) / CON_G;
+                        alt = 0.25 * (PH(i - 1, j, k) + PH(i, j, k) + PH(i - 1, j - 1, k) + PH(i, j - 1, k)) / CON_G;
+                    } else {
+                        cak = 0.125 * (RK(i - 1, j + 1) + RK(i, j + 1) + RK2(i - 1, j) + RK2(i, j) + RK(i - 1, j - 1) + RK(i, j - 1));
+                        alt_km1 = 0.125 * (PH(i - 1, j + 1, k - 1) + PH(i, j + 1, k - 1) + 2.0 * PH(i - 1, j, k - 1) + 2.0 * PH(i, j, k - 1) + PH(i - 1, j - 1, k - 1) + PH(i, j - 1, k - 1)) / CON_G;
+                        alt = 0.125 * (PH(i - 1, j + 1, k) + PH(i, j + 1, k) + 2.0 * PH(i - 1, j, k) + 2.0 * PH(i, j, k) + PH(i - 1, j - 1, k) + PH(i, j - 1, k)) / CON_G;
+                    }
+                    const double dudz = (AT(f->UWIND, i, j, k - 1, 0, nz) - AT(f->UWIND, i, j, k, 0, nz)) / (alt_km1 - alt);
+                    AT(f->KMOM_dUWINDdz, i, j, k, 0, nzs) = cak * dudz;
+                }
+            }
+        PAR_FOR
+        for (int i = 1; i < nx + 1; i++)
+            for (int j = 1; j < ny + 2; j++) {
+                AT(f->KMOM_dVWINDdz, i, j, 0, 1, nzs) = 0.0;
+                AT(f->KMOM_dVWINDdz, i, j, nz, 1, nzs) = 0.0;
+                for (int k = 1; k < nz; k++) {
+                    const double cak = 0.125 * (RK(i + 1, j - 1) + RK(i + 1, j) + RK2(i, j - 1) + RK2(i, j) + RK(i - 1, j - 1) + RK(i - 1, j));
+                    const double alt_km1 = 0.125 * (PH(i + 1, j - 1, k - 1) + PH(i + 1, j, k - 1) + 2.0 * PH(i, j - 1, k - 1) + 2.0 * PH(i, j, k - 1) + PH(i - 1, j - 1, k - 1) + PH(i - 1, j, k - 1)) / CON_G;
+                    const double alt = 0.125 * (PH(i + 1, j - 1, k) + PH(i + 1, j, k) + 2.0 * PH(i, j - 1, k) + 2.0 * PH(i, j, k) + PH(i - 1, j - 1, k) + PH(i - 1, j, k)) / CON_G;
+                    const double dvdz = (AT(f->VWIND, i, j, k - 1, 1, nz) - AT(f->VWIND, i, j, k, 1, nz)) / (alt_km1 - alt);
+                    AT(f->KMOM_dVWINDdz, i, j, k, 1, nzs) = cak * dvdz;
+                }
+            }
+#undef RK
+#undef RK2
+#undef PH
+    }
+    /* ---- the eight Arakawa-C momentum fluxes (:357-436; dyn_functions.py:429-536) ---- */
+#define UF(ii, jj) AT(f->UFLX, ii, jj, k, 0, nz)
+#define VF(ii, jj) AT(f->VFLX, ii, jj, k, 1, nz)
+    PAR_FOR
+    for (int i = 1; i < nx + 2; i++)
+        for (int j = 1; j < ny + 2; j++)
+            for (int k = 0; k < nz; k++) {
+                /* (is,js): CFLX, QFLX */
+                AT(f->CFLX, i, j, k, 1, nz) = 1.0 / 12.0 *
+                    (VF(i - 1, j - 1) + VF(i, j - 1) + 2.0 * (VF(i - 1, j) + VF(i, j)) + VF(i - 1, j + 1) + VF(i, j + 1));
+                AT(f->QFLX, i, j, k, 1, nz) = 1.0 / 12.0 *
+                    (UF(i - 1, j - 1) + UF(i - 1, j) + 2.0 * (UF(i, j - 1) + UF(i, j)) + UF(i + 1, j - 1) + UF(i + 1, j));
+                if (i < nx + 1) { /* (i,js): DFLX, EFLX */
+                    AT(f->DFLX, i, j, k, 1, nz) = 1.0 / 24.0 *
+                        (VF(i, j - 1) + 2.0 * VF(i, j) + VF(i, j + 1) + UF(i, j - 1) + UF(i, j) + UF(i + 1, j - 1) + UF(i + 1, j));
+                    AT(f->EFLX, i, j, k, 1, nz) = 1.0 / 24.0 *
+                        (VF(i, j - 1) + 2.0 * VF(i, j) + VF(i, j + 1) - UF(i, j - 1) - UF(i, j) - UF(i + 1, j - 1) - UF(i + 1, j));
+                }
+                if (j < ny + 1) { /* (is,j): SFLX, TFLX */
+                    AT(f->SFLX, i, j, k, 0, nz) = 1.0 / 24.0 *
+                        (VF(i - 1, j) + VF(i - 1, j + 1) + VF(i, j) + VF(i, j + 1) + UF(i - 1, j) + 2.0 * UF(i, j) + UF(i + 1, j));
+                    AT(f->TFLX, i, j, k, 0, nz) = 1.0 / 24.0 *
+                        (VF(i - 1, j) + VF(i - 1, j + 1) + VF(i, j) + VF(i, j + 1) - UF(i - 1, j) - 2.0 * UF(i, j) - UF(i + 1, j));
+                }
+                if (i < nx + 1 && j < ny + 1) { /* (i,j): BFLX, RFLX */
+                    AT(f->BFLX, i, j, k, 0, nz) = 1.0 / 12.0 *
+                        (UF(i, j - 1) + UF(i + 1, j - 1) + 2.0 * (UF(i, j) + UF(i + 1, j)) + UF(i, j + 1) + UF(i + 1, j + 1));
+                    AT(f->RFLX, i, j, k, 0, nz) = 1.0 / 12.0 *
+                        (VF(i - 1, j) + VF(i - 1, j + 1) + 2.0 * (VF(i, j) + VF(i, j + 1)) + VF(i + 1, j) + VF(i + 1, j + 1));
+                }
+            }
+#undef UF
+#undef VF
+}
+
+/* ------------------------------------------------------------------------- */
+/* dyn_functions.py:383-424 (note: divides by g itself) */
+static inline double var_ds(double v0, double v_dm1, double v_pm1, double v_pp1,
+                            double v_pm1_dm1, double v_pp1_dm1, int wall_lo, int wall_hi)
+{
+    if (wall_lo) return 0.25 * (v_pp1_dm1 + v_pp1 + v_dm1 + v0) / CON_G;
+    if (wall_hi) return 0.25 * (v_dm1 + v0 + v_pm1_dm1 + v_pm1) / CON_G;
+    return 0.125 * (v_pp1_dm1 + v_pp1 + 2.0 * v_dm1 + 2.0 * v0 + v_pm1_dm1 + v_pm1) / CON_G;
+}
+
+/* dyn_functions.py:177-207 */
+static inline double pre_grad(double phi, double phi_dm1, double colp, double colp_dm1,
+                              double pott, double pott_dm1, double pvtf, double pvtf_dm1,
+                              double pvtfvb, double pvtfvb_dm1, double pvtfvb_dm1_kp1,
+                              double pvtfvb_kp1, double dsig, double svb, double svb_kp1,
+                              double dgrid)
+{
+    return -dgrid * ((phi - phi_dm1) * (colp + colp_dm1) / 2.0 +
+                     (colp - colp_dm1) * CON_CP / 2.0 *
+                         (+pott_dm1 / dsig * (svb_kp1 * (pvtfvb_dm1_kp1 - pvtf_dm1) + svb * (pvtf_dm1 - pvtfvb_dm1)) +
+                          pott / dsig * (svb_kp1 * (pvtfvb_kp1 - pvtf) + svb * (pvtf - pvtfvb))));
+}
+
+/* dyn_UFLX.py:339-434, add_up_tendencies_py :69-199 */
+void oracle_uflx_tendency(const oracle_cfg *c, const oracle_grid *g, oracle_fields *f)
+{
+    const int nx = c->nx, ny = c->ny, nz = c->nz, nzs = nz + 1;
+    const int nthr = nthreads_of(c);
+    (void)nthr;
+#define U(ii, jj) AT(f->UWIND, ii, jj, k, 0, nz)
+#define V(ii, jj) AT(f->VWIND, ii, jj, k, 1, nz)
+    PAR_FOR
+    for (int i = 1; i < nx + 1; i++) {
+        const int im1 = (i == 1) ? nx : i - 1;          /* :366-374 */
+        for (int j = 1; j < ny + 1; j++) {
+            const double colp = A2(f->COLP, i, j), colp_im1 = A2(f->COLP, i - 1, j);
+            const double corf = AT(g->corf_is, i, j, 0, 0, 1), lat = AT(g->lat_is_rad, i, j, 0, 0, 1);
+            const double dlon = A2S(g->dlon_rad, i, j), dlat = AT(g->dlat_rad, i, j, 0, 0, 1);
+            const double dyis = AT(g->dyis, i, j, 0, 0, 1);
+            const int lo = (j == 1), hi = (j == ny);
+            double smom_is = 0.0;
+            if (c->i_turb)
+                smom_is = var_ds(A2(f->SMOMXFLX, i, j), A2(f->SMOMXFLX, i - 1, j), A2(f->SMOMXFLX, i, j - 1),
+                                 A2(f->SMOMXFLX, i, j + 1), A2(f->SMOMXFLX, i - 1, j - 1), A2(f->SMOMXFLX, i - 1, j + 1), lo, hi);
+            for (int k = 0; k < nz; k++) {
+                double bflx = AT(f->BFLX, i, j, k, 0, nz), bflx_im1 = AT(f->BFLX, im1, j, k, 0, nz);
+                double cflx = AT(f->CFLX, i, j, k, 1, nz), cflx_jp1 = AT(f->CFLX, i, j + 1, k, 1, nz);
+                double dflx_im1 = AT(f->DFLX, im1, j, k, 1, nz), dflx_jp1 = AT(f->DFLX, i, j + 1, k, 1, nz);
+                double eflx = AT(f->EFLX, i, j, k, 1, nz), eflx_im1_jp1 = AT(f->EFLX, im1, j + 1, k, 1, nz);
+                if (lo) { dflx_im1 = 0.0; cflx = 0.0; eflx = 0.0; }               /* :377-380 */
+                if (hi) { dflx_jp1 = 0.0; cflx_jp1 = 0.0; eflx_im1_jp1 = 0.0; }   /* :381-384 */
+                const double u = U(i, j);
+                double t = 0.0;
+                /* horizontal advection, dyn_functions.py:541-572, sign +1 */
+                t = t + (+bflx_im1 * (U(i - 1, j) + u) / 2.0 - bflx * (u + U(i + 1, j)) / 2.0
+                         + cflx * (U(i, j - 1) + u) / 2.0 - cflx_jp1 * (u + U(i, j + 1)) / 2.0
+                         + dflx_im1 * (U(i - 1, j - 1) + u) / 2.0 - dflx_jp1 * (u + U(i + 1, j + 1)) / 2.0
+                         + 1.0 * (+eflx * (U(i + 1, j - 1) + u) / 2.0 - eflx_im1_jp1 * (u + U(i - 1, j + 1)) / 2.0));
+                /* vertical advection */
+                t = t + (AT(f->WWIND_UWIND, i, j, k, 0, nzs) - AT(f->WWIND_UWIND, i, j, k + 1, 0, nzs)) / g->dsigma[k];
+                /* vertical turbulent transport (:137-170); interp_VAR_ds already divides by g,
+                 * ALTVB is divided by g a second time, RHO and SMOMXFLX once (reference quirk) */
+                if (c->i_turb) {
+#define PV(ii, jj, kk) AT(f->PHIVB, ii, jj, kk, 0, nzs)
+#define RH(ii, jj) AT(f->RHO, ii, jj, k, 0, nz)
+                    const double altvb = var_ds(PV(i, j, k), PV(i - 1, j, k), PV(i, j - 1, k), PV(i, j + 1, k), PV(i - 1, j - 1, k), PV(i - 1, j + 1, k), lo, hi) / CON_G;
+                    const double altvb_kp1 = var_ds(PV(i, j, k + 1), PV(i - 1, j, k + 1), PV(i, j - 1, k + 1), PV(i, j + 1, k + 1), PV(i - 1, j - 1, k + 1), PV(i - 1, j + 1, k + 1), lo, hi) / CON_G;
+                    const double rho_is = var_ds(RH(i, j), RH(i - 1, j), RH(i, j - 1), RH(i, j + 1), RH(i - 1, j - 1), RH(i - 1, j + 1), lo, hi);
+                    const double kd = AT(f->KMOM_dUWINDdz, i, j, k, 0, nzs), kd_kp1 = AT(f->KMOM_dUWINDdz, i, j, k + 1, 0, nzs);
+                    double turb;
+                    if (k == 0) turb = (0.0 - kd_kp1) / ((altvb - altvb_kp1) * rho_is);
+                    else if (k == nz - 1) turb = (kd + smom_is) / ((altvb - altvb_kp1) * rho_is);
+                    else turb = (kd - kd_kp1) / ((altvb - altvb_kp1) * rho_is);
+                    t = t + turb;
+                    AT(f->dUFLXdt_TURB, i, j, k, 0, nz) = turb;
+#undef PV
+#undef RH
+                }
+                /* Coriolis + spherical metric, dyn_UFLX.py:39-66 */
+                t = t + CON_RE * dlon * dlat / 2.0 *
+                            (colp_im1 * (V(i - 1, j) + V(i - 1, j + 1)) / 2.0 *
+                                 (corf * CON_RE * cos(lat) + (U(i - 1, j) + u) / 2.0 * sin(lat)) +
+                             colp * (V(i, j) + V(i, j + 1)) / 2.0 *
+                                 (corf * CON_RE * cos(lat) + (u + U(i + 1, j)) / 2.0 * sin(lat)));
+                /* pressure gradient */
+                t = t + pre_grad(AT(f->PHI, i, j, k, 0, nz), AT(f->PHI, i - 1, j, k, 0, nz), colp, colp_im1,
+                                 AT(f->POTT, i, j, k, 0, nz), AT(f->POTT, i - 1, j, k, 0, nz),
+                                 AT(f->PVTF, i, j, k, 0, nz), AT(f->PVTF, i - 1, j, k, 0, nz),
+                                 AT(f->PVTFVB, i, j, k, 0, nzs), AT(f->PVTFVB, i - 1, j, k, 0, nzs),
+                                 AT(f->PVTFVB, i - 1, j, k + 1, 0, nzs), AT(f->PVTFVB, i, j, k + 1, 0, nzs),
+                                 g->dsigma[k], g->sigma_vb[k], g->sigma_vb[k + 1], dyis);
+                /* horizontal diffusion, dyn_functions.py:158-170 */
+                if (g->UVFLX_dif_coef[k] > 0.0)
+                    t = t + g->UVFLX_dif_coef[k] *
+                                (AT(f->UFLX, i - 1, j, k, 0, nz) + AT(f->UFLX, i + 1, j, k, 0, nz) +
+                                 AT(f->UFLX, i, j - 1, k, 0, nz) + AT(f->UFLX, i, j + 1, k, 0, nz) -
+                                 4.0 * AT(f->UFLX, i, j, k, 0, nz));
+                AT(f->dUFLXdt, i, j, k, 0, nz) = t;
+            }
+        }
+    }
+#undef U
+#undef V
+}
+
+/* dyn_VFLX.py:322-408, add_up_tendencies_py :67-198.  Rows js = 1 and ny+1 (the
+ * poles) are skipped: the reference computes them from NaN halos and
+ * exchange_BC zeroes VWIND there (misc_boundaries.py:36-38). */
+void oracle_vflx_tendency(const oracle_cfg *c, const oracle_grid *g, oracle_fields *f)
+{
+    const int nx = c->nx, ny = c->ny, nz = c->nz, nzs = nz + 1;
+    const int nthr = nthreads_of(c);
+    (void)nthr;
+#define U(ii, jj) AT(f->UWIND, ii, jj, k, 0, nz)
+#define V(ii, jj) AT(f->VWIND, ii, jj, k, 1, nz)
+    PAR_FOR
+    for (int i = 1; i < nx + 1; i++) {
+        const int ip1 = (i == nx) ? 1 : i + 1;          /* :349-356 */
+        for (int j = 2; j < ny + 1; j++) {
+            const double colp = A2(f->COLP, i, j), colp_jm1 = A2(f->COLP, i, j - 1);
+            const double corf = A2(g->corf, i, j), corf_jm1 = A2(g->corf, i, j - 1);
+            const double lat = A2(g->lat_rad, i, j), lat_jm1 = A2(g->lat_rad, i, j - 1);
+            const double dlon = A2S(g->dlon_rad, i, j), dlat = AT(g->dlat_rad, i, j, 0, 0, 1);
+            const double dxjs = A2S(g->dxjs, i, j);
+            double smom_js = 0.0;
+            if (c->i_turb)
+                smom_js = var_ds(A2(f->SMOMYFLX, i, j), A2(f->SMOMYFLX, i, j - 1), A2(f->SMOMYFLX, i - 1, j),
+                                 A2(f->SMOMYFLX, i + 1, j), A2(f->SMOMYFLX, i - 1, j - 1), A2(f->SMOMYFLX, i + 1, j - 1), 0, 0);
+            for (int k = 0; k < nz; k++) {
+                const double rflx = AT(f->RFLX, i, j, k, 0, nz), rflx_jm1 = AT(f->RFLX, i, j - 1, k, 0, nz);
+                const double qflx = AT(f->QFLX, i, j, k, 1, nz), qflx_ip1 = AT(f->QFLX, ip1, j, k, 1, nz);
+                const double sflx_jm1 = AT(f->SFLX, i, j - 1, k, 0, nz), sflx_ip1 = AT(f->SFLX, ip1, j, k, 0, nz);
+                const double tflx = AT(f->TFLX, i, j, k, 0, nz), tflx_ip1_jm1 = AT(f->TFLX, ip1, j - 1, k, 0, nz);
+                const double v = V(i, j);
+                double t = 0.0;
+                /* horizontal advection, sign -1 on the T term */
+                t = t + (+rflx_jm1 * (V(i, j - 1) + v) / 2.0 - rflx * (v + V(i, j + 1)) / 2.0
+                         + qflx * (V(i - 1, j) + v) / 2.0 - qflx_ip1 * (v + V(i + 1, j)) / 2.0
+                         + sflx_jm1 * (V(i - 1, j - 1) + v) / 2.0 - sflx_ip1 * (v + V(i + 1, j + 1)) / 2.0
+                         + -1.0 * (+tflx * (V(i - 1, j + 1) + v) / 2.0 - tflx_ip1_jm1 * (v + V(i + 1, j - 1)) / 2.0));
+                t = t + (AT(f->WWIND_VWIND, i, j, k, 1, nzs) - AT(f->WWIND_VWIND, i, j, k + 1, 1, nzs)) / g->dsigma[k];
+                if (c->i_turb) {
+#define PV(ii, jj, kk) AT(f->PHIVB, ii, jj, kk, 0, nzs)
+#define RH(ii, jj) AT(f->RHO, ii, jj, k, 0, nz)
+                    const double altvb = var_ds(PV(i, j, k), PV(i, j - 1, k), PV(i - 1, j, k), PV(i + 1, j, k), PV(i - 1, j - 1, k), PV(i + 1, j - 1, k), 0, 0) / CON_G;
+                    const double altvb_kp1 = var_ds(PV(i, j, k + 1), PV(i, j - 1, k + 1), PV(i - 1, j, k + 1), PV(i + 1, j, k + 1), PV(i - 1, j - 1, k + 1), PV(i + 1, j - 1, k + 1), 0, 0) / CON_G;
+                    const double rho_js = var_ds(RH(i, j), RH(i, j - 1), RH(i - 1, j), RH(i + 1, j), RH(i - 1, j - 1), RH(i + 1, j - 1), 0, 0);
+                    const double kd = AT(f->KMOM_dVWINDdz, i, j, k, 1, nzs), kd_kp1 = AT(f->KMOM_dVWINDdz, i, j, k + 1, 1, nzs);
+                    double turb;
+                    if (k == 0) turb = (0.0 - kd_kp1) / ((altvb - altvb_kp1) * rho_js);
+                    else if (k == nz - 1) turb = (kd + smom_js) / ((altvb - altvb_kp1) * rho_js);
+                    else turb = (kd - kd_kp1) / ((altvb - altvb_kp1) * rho_js);
+                    t = t + turb;
+                    AT(f->dVFLXdt_TURB, i, j, k, 1, nz) = turb;
+#undef PV
+#undef RH
+                }
+                /* Coriolis + metric, dyn_VFLX.py:39-64 */
+                t = t + -CON_RE * dlon * dlat / 2.0 *
+                            (colp_jm1 * (U(i, j - 1) + U(i + 1, j - 1)) / 2.0 *
+                                 (corf_jm1 * CON_RE * cos(lat_jm1) + (U(i, j - 1) + U(i + 1, j - 1)) / 2.0 * sin(lat_jm1)) +
+                             colp * (U(i, j) + U(i + 1, j)) / 2.0 *
+                                 (corf * CON_RE * cos(lat) + (U(i, j) + U(i + 1, j)) / 2.0 * sin(lat)));
+                t = t + pre_grad(AT(f->PHI, i, j, k, 0, nz), AT(f->PHI, i, j - 1, k, 0, nz), colp, colp_jm1,
+                                 AT(f->POTT, i, j, k, 0, nz), AT(f->POTT, i, j - 1, k, 0, nz),
+                                 AT(f->PVTF, i, j, k, 0, nz), AT(f->PVTF, i, j - 1, k, 0, nz),
+                                 AT(f->PVTFVB, i, j, k, 0, nzs), AT(f->PVTFVB, i, j - 1, k, 0, nzs),
+                                 AT(f->PVTFVB, i, j - 1, k + 1, 0, nzs), AT(f->PVTFVB, i, j, k + 1, 0, nzs),
+                                 g->dsigma[k], g->sigma_vb[k], g->sigma_vb[k + 1], dxjs);
+                if (g->UVFLX_dif_coef[k] > 0.0)
+                    t = t + g->UVFLX_dif_coef[k] *
+                                (AT(f->VFLX, i - 1, j, k, 1, nz) + AT(f->VFLX, i + 1, j, k, 1, nz) +
+                                 AT(f->VFLX, i, j - 1, k, 1, nz) + AT(f->VFLX, i, j + 1, k, 1, nz) -
+                                 4.0 * AT(f->VFLX, i, j, k, 1, nz));
+                AT(f->dVFLXdt, i, j, k, 1, nz) = t;
+            }
+        }
+    }
+#undef U
+#undef V
+}
+
+/* ------------------------------------------------------------------------- */
+/* dyn_POTT.py:180-216, add_up_tendencies_py :55-110 */
+void oracle_pott_tendency(const oracle_cfg *c, const oracle_grid *g, oracle_fields *f)
+{
+    const int nx = c->nx, ny = c->ny, nz = c->nz, nzs = nz + 1;
+    const int nthr = nthreads_of(c);
+    (void)nthr;
+#define P(ii, jj, kk) AT(f->POTT, ii, jj, kk, 0, nz)
+    PAR_FOR
+    for (int i = 1; i < nx + 1; i++)
+        for (int j = 1; j < ny + 1; j++) {
+            const double colp = A2(f->COLP, i, j), colp_new = A2(f->COLP_NEW, i, j);
+            const double c_im1 = A2(f->COLP, i - 1, j), c_ip1 = A2(f->COLP, i + 1, j);
+            const double c_jm1 = A2(f->COLP, i, j - 1), c_jp1 = A2(f->COLP, i, j + 1);
+            const double area = A2(g->A, i, j);
+            for (int k = 0; k < nz; k++) {
+                const double p = P(i, j, k);
+                double t = 0.0;
+                /* hor_adv_py, dyn_functions.py:105-114 */
+                t = t + (+AT(f->UFLX, i, j, k, 0, nz) * (P(i - 1, j, k) + p) / 2.0
+                         - AT(f->UFLX, i + 1, j, k, 0, nz) * (p + P(i + 1, j, k)) / 2.0
+                         + AT(f->VFLX, i, j, k, 1, nz) * (P(i, j - 1, k) + p) / 2.0
+                         - AT(f->VFLX, i, j + 1, k, 1, nz) * (p + P(i, j + 1, k)) / 2.0) / area;
+                /* vert_adv_py, dyn_functions.py:118-138 */
+                {
+                    const double w_kp1 = AT(f->WWIND, i, j, k + 1, 0, nzs), pvb_kp1 = AT(f->POTTVB, i, j, k + 1, 0, nzs);
+                    if (k == 0)
+                        t = t + colp_new * (-w_kp1 * pvb_kp1) / g->dsigma[k];
+                    else
+                        t = t + colp_new * (+AT(f->WWIND, i, j, k, 0, nzs) * AT(f->POTTVB, i, j, k, 0, nzs) - w_kp1 * pvb_kp1) / g->dsigma[k];
+                }
+                /* turb_flux_tendency_py, dyn_functions.py:26-67 */
+                if (c->i_turb) {
+                    const double alt = AT(f->PHI, i, j, k, 0, nz) / CON_G;
+                    const double altvb = AT(f->PHIVB, i, j, k, 0, nzs) / CON_G, altvb_kp1 = AT(f->PHIVB, i, j, k + 1, 0, nzs) / CON_G;
+                    const double rho = AT(f->RHO, i, j, k, 0, nz);
+                    const double surf = A2(f->SSHFLX, i, j) / CON_CP;
+                    double turb;
+                    if (k == 0) {
+                        const double alt_kp1 = AT(f->PHI, i, j, k + 1, 0, nz) / CON_G;
+                        turb = colp * ((+0.0 - ((p - P(i, j, k + 1)) / (alt - alt_kp1) * AT(f->RHOVB, i, j, k + 1, 0, nzs) * AT(f->KHEAT, i, j, k + 1, 0, nzs))) /
+                                       ((altvb - altvb_kp1) * rho));
+                    } else if (k == nz - 1) {
+                        const double alt_km1 = AT(f->PHI, i, j, k - 1, 0, nz) / CON_G;
+                        turb = colp * ((+((P(i, j, k - 1) - p) / (alt_km1 - alt) * AT(f->RHOVB, i, j, k, 0, nzs) * AT(f->KHEAT, i, j, k, 0, nzs)) + surf) /
+                                       ((altvb - altvb_kp1) * rho));
+                    } else {
+                        const double alt_kp1 = AT(f->PHI, i, j, k + 1, 0, nz) / CON_G;
+                        const double alt_km1 = AT(f->PHI, i, j, k - 1, 0, nz) / CON_G;
+                        turb = colp * ((+((P(i, j, k - 1) - p) / (alt_km1 - alt) * AT(f->RHOVB, i, j, k, 0, nzs) * AT(f->KHEAT, i, j, k, 0, nzs))
+                                        - ((p - P(i, j, k + 1)) / (alt - alt_kp1) * AT(f->RHOVB, i, j, k + 1, 0, nzs) * AT(f->KHEAT, i, j, k + 1, 0, nzs))) /
+                                       ((altvb - altvb_kp1) * rho));
+                    }
+                    t = t + turb;
+                    AT(f->dPOTTdt_TURB, i, j, k, 0, nz) = turb / colp * 3600.0;   /* dyn_POTT.py:93-94 */
+                }
+                /* num_dif_pw_py, dyn_functions.py:142-155 */
+                if (g->POTT_dif_coef[k] > 0.0)
+                    t = t + g->POTT_dif_coef[k] * (+c_im1 * P(i - 1, j, k) + c_ip1 * P(i + 1, j, k) + c_jm1 * P(i, j - 1, k) + c_jp1 * P(i, j + 1, k) - 4.0 * colp * p);
+                if (c->i_radiation)
+                    t = t + AT(f->dPOTTdt_RAD, i, j, k, 0, nz) * colp;
+                AT(f->dPOTTdt, i, j, k, 0, nz) = t;
+            }
+        }
+#undef P
+}
+
+/* ------------------------------------------------------------------------- */
+/* dyn_timestep.py:212-297 (serial in the reference: plain njit) */
+void oracle_make_timestep(const oracle_cfg *c, const oracle_grid *g, oracle_fields *f, double dt)
+{
+    const int nx = c->nx, ny = c->ny, nz = c->nz;
+#define CN(ii, jj) (A2(f->COLP, ii, jj))
+#define CO(ii, jj) (A2(f->COLP_OLD, ii, jj))
+#define AR(ii, jj) (A2(g->A, ii, jj))
+    for (int i = 1; i < nx + 2; i++)
+        for (int j = 1; j < ny + 2; j++) {
+            if (i < nx + 1 && j < ny + 1) {   /* UWIND: is in [1,nx], j in [1,ny]; column nx+1 is the
+                                                 periodic duplicate refreshed by exchange_BC */
+                double ca, ca_old;
+                if (j == 1) {
+                    ca = 1.0 / 4.0 * (CN(i - 1, j + 1) * AR(i - 1, j + 1) + CN(i, j + 1) * AR(i, j + 1) + CN(i - 1, j) * AR(i - 1, j) + CN(i, j) * AR(i, j));
+                    ca_old = 1.0 / 4.0 * (CO(i - 1, j + 1) * AR(i - 1, j + 1) + CO(i, j + 1) * AR(i, j + 1) + CO(i - 1, j) * AR(i - 1, j) + CO(i, j) * AR(i, j));
+                } else if (j == ny) {
+                    ca = 1.0 / 4.0 * (CN(i - 1, j - 1) * AR(i - 1, j - 1) + CN(i, j - 1) * AR(i, j - 1) + CN(i - 1, j) * AR(i - 1, j) + CN(i, j) * AR(i, j));
+                    ca_old = 1.0 / 4.0 * (CO(i - 1, j - 1) * AR(i - 1, j - 1) + CO(i, j - 1) * AR(i, j - 1) + CO(i - 1, j) * AR(i - 1, j) + CO(i, j) * AR(i, j));
+                } else {
+                    ca = 1.0 / 8.0 * (CN(i - 1, j + 1) * AR(i - 1, j + 1) + CN(i, j + 1) * AR(i, j + 1) + 2.0 * CN(i - 1, j) * AR(i - 1, j) + 2.0 * CN(i, j) * AR(i, j) + CN(i - 1, j - 1) * AR(i - 1, j - 1) + CN(i, j - 1) * AR(i, j - 1));
+                    ca_old = 1.0 / 8.0 * (CO(i - 1, j + 1) * AR(i - 1, j + 1) + CO(i, j + 1) * AR(i, j + 1) + 2.0 * CO(i - 1, j) * AR(i - 1, j) + 2.0 * CO(i, j) * AR(i, j) + CO(i - 1, j - 1) * AR(i - 1, j - 1) + CO(i, j - 1) * AR(i, j - 1));
+                }
+                for (int k = 0; k < nz; k++)
+                    AT(f->UWIND, i, j, k, 0, nz) = AT(f->UWIND_OLD, i, j, k, 0, nz) * ca_old / ca + dt * AT(f->dUFLXdt, i, j, k, 0, nz) / ca;
+            }
+            if (i < nx + 1 && j > 1 && j < ny + 1) {   /* VWIND: js in [2,ny] (poles are zeroed by exchange_BC) */
+                const double ca = 1.0 / 8.0 * (CN(i + 1, j - 1) * AR(i + 1, j - 1) + CN(i + 1, j) * AR(i + 1, j) + 2.0 * CN(i, j - 1) * AR(i, j - 1) + 2.0 * CN(i, j) * AR(i, j) + CN(i - 1, j - 1) * AR(i - 1, j - 1) + CN(i - 1, j) * AR(i - 1, j));
+                const double ca_old = 1.0 / 8.0 * (CO(i + 1, j - 1) * AR(i + 1, j - 1) + CO(i + 1, j) * AR(i + 1, j) + 2.0 * CO(i, j - 1) * AR(i, j - 1) + 2.0 * CO(i, j) * AR(i, j) + CO(i - 1, j - 1) * AR(i - 1, j - 1) + CO(i - 1, j) * AR(i - 1, j));
+                for (int k = 0; k < nz; k++)
+                    AT(f->VWIND, i, j, k, 1, nz) = AT(f->VWIND_OLD, i, j, k, 1, nz) * ca_old / ca + dt * AT(f->dVFLXdt, i, j, k, 1, nz) / ca;
+            }
+            if (i < nx + 1 && j < ny + 1) {
+                const double cn = CN(i, j), co = CO(i, j);
+                for (int k = 0; k < nz; k++)
+                    AT(f->POTT, i, j, k, 0, nz) = AT(f->POTT_OLD, i, j, k, 0, nz) * co / cn + dt * AT(f->dPOTTdt, i, j, k, 0, nz) / cn;
+            }
+        }
+#undef CN
+#undef CO
+#undef AR
+}
+
+/* ------------------------------------------------------------------------- */
+/* dyn_diagnostics.py:139-156 */
+void oracle_diag_pvtf(const oracle_cfg *c, const oracle_grid *g, oracle_fields *f)
+{
+    const int nx = c->nx, ny = c->ny, nz = c->nz, nzs = nz + 1;
+    const int nthr = nthreads_of(c);
+    (void)nthr;
+    PAR_FOR
+    for (int i = 0; i < nx + 2; i++)
+        for (int j = 0; j < ny + 2; j++) {
+            const double colp = A2(f->COLP, i, j);
+            for (int k = 0; k < nz; k++) {
+                const double p_km12 = c->pair_top + g->sigma_vb[k] * colp;
+                const double p_kp12 = c->pair_top + g->sigma_vb[k + 1] * colp;
+                AT(f->PVTF, i, j, k, 0, nz) = 1.0 / (1.0 + CON_KAPPA) *
+                    (pow(p_kp12 / 100000.0, CON_KAPPA) * p_kp12 - pow(p_km12 / 100000.0, CON_KAPPA) * p_km12) / (p_kp12 - p_km12);
+                AT(f->PVTFVB, i, j, k, 0, nzs) = pow(p_km12 / 100000.0, CON_KAPPA);
+                if (k == nz - 1) AT(f->PVTFVB, i, j, k + 1, 0, nzs) = pow(p_kp12 / 100000.0, CON_KAPPA);
+            }
+        }
+}
+
+/* dyn_diagnostics.py:160-174 */
+void oracle_diag_phi(const oracle_cfg *c, oracle_fields *f)
+{
+    const int nx = c->nx, ny = c->ny, nz = c->nz, nzs = nz + 1;
+    const int nthr = nthreads_of(c);
+    (void)nthr;
+    PAR_FOR
+    for (int i = 0; i < nx + 2; i++)
+        for (int j = 0; j < ny + 2; j++) {
+            AT(f->PHIVB, i, j, nz, 0, nzs) = A2(f->HSURF, i, j) * CON_G;
+            for (int k = nz - 1; k >= 0; k--) {
+                const double pott = AT(f->POTT, i, j, k, 0, nz), pvtf = AT(f->PVTF, i, j, k, 0, nz);
+                const double phi = AT(f->PHIVB, i, j, k + 1, 0, nzs) - CON_CP * (pott * (pvtf - AT(f->PVTFVB, i, j, k + 1, 0, nzs)));
+                AT(f->PHI, i, j, k, 0, nz) = phi;
+                AT(f->PHIVB, i, j, k, 0, nzs) = phi - CON_CP * (pott * (AT(f->PVTFVB, i, j, k, 0, nzs) - pvtf));
+            }
+        }
+}
+
+/* dyn_diagnostics.py:179-195 */
+void oracle_diag_pottvb(const oracle_cfg *c, oracle_fields *f)
+{
+    const int nx = c->nx, ny = c->ny, nz = c->nz, nzs = nz + 1;
+    const int nthr = nthreads_of(c);
+    (void)nthr;
+    PAR_FOR
+    for (int i = 0; i < nx + 2; i++)
+        for (int j = 0; j < ny + 2; j++)
+            for (int k = 1; k < nzs - 1; k++) {
+                const double v = (+(AT(f->PVTFVB, i, j, k, 0, nzs) - AT(f->PVTF, i, j, k - 1, 0, nz)) * AT(f->POTT, i, j, k - 1, 0, nz)
+                                  + (AT(f->PVTF, i, j, k, 0, nz) - AT(f->PVTFVB, i, j, k, 0, nzs)) * AT(f->POTT, i, j, k, 0, nz)) /
+                                 (AT(f->PVTF, i, j, k, 0, nz) - AT(f->PVTF, i, j, k - 1, 0, nz));
+                AT(f->POTTVB, i, j, k, 0, nzs) = v;
+                if (k == 1)          /* extrapolate to the model top */
+                    AT(f->POTTVB, i, j, k - 1, 0, nzs) = AT(f->POTT, i, j, k - 1, 0, nz) - (v - AT(f->POTT, i, j, k - 1, 0, nz));
+                else if (k == nzs - 2) /* ... and to the surface (elif in the reference) */
+                    AT(f->POTTVB, i, j, k + 1, 0, nzs) = AT(f->POTT, i, j, k, 0, nz) - (v - AT(f->POTT, i, j, k, 0, nz));
+            }
+}
+
+/* dyn_diagnostics.py:199-222, the RHO / RHOVB part */
+void oracle_diag_rho(const oracle_cfg *c, oracle_fields *f)
+{
+    const int nx = c->nx, ny = c->ny, nz = c->nz, nzs = nz + 1;
+    const int nthr = nthreads_of(c);
+    (void)nthr;
+    PAR_FOR
+    for (int i = 0; i < nx + 2; i++)
+        for (int j = 0; j < ny + 2; j++) {
+            for (int k = 0; k < nzs; k++) {
+                const double pairvb = 100000.0 * pow(AT(f->PVTFVB, i, j, k, 0, nzs), 1.0 / CON_KAPPA);
+                const double tairvb = AT(f->POTTVB, i, j, k, 0, nzs) * AT(f->PVTFVB, i, j, k, 0, nzs);
+                AT(f->RHOVB, i, j, k, 0, nzs) = pairvb / (CON_RD * tairvb);
+            }
+            for (int k = 0; k < nz; k++) {
+                const double tair = AT(f->POTT, i, j, k, 0, nz) * AT(f->PVTF, i, j, k, 0, nz);
+                const double pair = 100000.0 * pow(AT(f->PVTF, i, j, k, 0, nz), 1.0 / CON_KAPPA);
+                AT(f->RHO, i, j, k, 0, nz) = pair / (CON_RD * tair);
+            }
+        }
+}
+
+/* ------------------------------------------------------------------------- */
+/* dyn_org_discretizations.py:89-117 */
+void oracle_stage_continuity(const oracle_cfg *c, const oracle_grid *g, oracle_fields *f, double dt)
+{
+    const int nzs = c->nz + 1;
+    oracle_continuity(c, g, f, dt);
+    oracle_exchange_bc(c, f->UFLX, 1, 0, c->nz);
+    oracle_exchange_bc(c, f->VFLX, 0, 1, c->nz);
+    oracle_exchange_bc(c, f->WWIND, 0, 0, nzs);
+    oracle_exchange_bc(c, f->COLP_NEW, 0, 0, 1);
+}
+
+/* dyn_org_discretizations.py:121-249 */
+void oracle_stage_momentum(const oracle_cfg *c, const oracle_grid *g, oracle_fields *f)
+{
+    const int nzs = c->nz + 1;
+    if (c->i_turb) oracle_exchange_bc(c, f->KMOM, 0, 0, nzs);
+    oracle_uvflx_prepare(c, g, f);
+    if (c->i_turb) {
+        oracle_exchange_bc(c, f->KMOM_dUWINDdz, 1, 0, nzs);
+        oracle_exchange_bc(c, f->KMOM_dVWINDdz, 0, 1, nzs);
+        oracle_exchange_bc(c, f->SMOMXFLX, 0, 0, 1);
+        oracle_exchange_bc(c, f->SMOMYFLX, 0, 0, 1);
+    }
+    oracle_uflx_tendency(c, g, f);
+    oracle_vflx_tendency(c, g, f);
+}
+
+/* dyn_org_discretizations.py:253-273 */
+void oracle_stage_temperature(const oracle_cfg *c, const oracle_grid *g, oracle_fields *f)
+{
+    oracle_pott_tendency(c, g, f);
+}
+
+/* dyn_org_discretizations.py:359-393 */
+void oracle_stage_euler_forward(const oracle_cfg *c, const oracle_grid *g, oracle_fields *f, double dt)
+{
+    oracle_make_timestep(c, g, f, dt);
+    oracle_exchange_bc(c, f->POTT, 0, 0, c->nz);
+    oracle_exchange_bc(c, f->VWIND, 0, 1, c->nz);
+    oracle_exchange_bc(c, f->UWIND, 1, 0, c->nz);
+}
+
+/* dyn_org_discretizations.py:310-326 */
+void oracle_stage_primary_diag(const oracle_cfg *c, const oracle_grid *g, oracle_fields *f)
+{
+    oracle_diag_pvtf(c, g, f);
+    oracle_diag_phi(c, f);
+    oracle_diag_pottvb(c, f);
+}
+
+/* dyn_matsuno.py:28-131 */
+void oracle_step_matsuno(const oracle_cfg *c, const oracle_grid *g, oracle_fields *f,
+                         double dt, int nsteps, int with_rho)
+{
+    const int nx = c->nx, ny = c->ny, nz = c->nz;
+    const size_t n2 = (size_t)(nx + 2) * (ny + 2);
+    for (int s = 0; s < nsteps; s++) {
+        if (with_rho) oracle_diag_rho(c, f);                        /* solver.py:99-101 */
+        memcpy(f->COLP_OLD, f->COLP, n2 * sizeof(double));          /* :34-41 */
+        memcpy(f->UWIND_OLD, f->UWIND, (size_t)(nx + 3) * (ny + 2) * nz * sizeof(double));
+        memcpy(f->VWIND_OLD, f->VWIND, (size_t)(nx + 2) * (ny + 3) * nz * sizeof(double));
+        memcpy(f->POTT_OLD, f->POTT, n2 * nz * sizeof(double));
+        for (int sub = 0; sub < 2; sub++) {
+            oracle_stage_continuity(c, g, f, dt);                   /* dyn_tendencies.py:25-70 */
+            oracle_stage_momentum(c, g, f);
+            oracle_stage_temperature(c, g, f);
+            memcpy(f->COLP, f->COLP_NEW, n2 * sizeof(double));      /* :64-67 */
+            oracle_stage_euler_forward(c, g, f, dt);                /* :75-77 */
+            oracle_stage_primary_diag(c, g, f);                     /* :86-88 */
+        }
+    }
+}

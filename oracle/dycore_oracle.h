@@ -1,0 +1,95 @@
+/*
+ * dycore_oracle.h -- CPU restatement of the reference's dry/turbulence-coupled
+ * hydrostatic dynamical-core Matsuno step.   TEST INFRASTRUCTURE ONLY.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load
+ * this library; the product path (climate_model_amd + libdycore_hip.so) never
+ * calls into it and has no CPU fallback.
+ *
+ * Parity status: PINNED by the .npz files under tests/golden/, which oracle/gen_golden.py
+ * produced in the build container by executing the reference's own Python
+ * functions (see that script's header for the import stand-ins it needs because
+ * numba is absent).  The reference repository itself holds no known-answer
+ * tests for this path.
+ *
+ * Layout mirrors the reference: C-order [i][j][k], k contiguous
+ * (main_fields.py:477-485), halo nb = 1.
+ *   unstaggered (nx+2, ny+2, nk)   x-staggered (nx+3, ny+2, nk)
+ *   y-staggered (nx+2, ny+3, nk)   xy-staggered (nx+3, ny+3, nk)
+ *   nk = nz, nz+1 or 1.  Vertical 1-D fields are plain arrays of nz / nz+1.
+ */
+#ifndef DYCORE_ORACLE_H
+#define DYCORE_ORACLE_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct {
+    int nx, ny, nz;
+    int i_turb;        /* i_UVFLX_vert_turb / i_POTT_vert_turb (namelist.py:66,77) */
+    int i_radiation;   /* i_POTT_radiation after io_read_namelist.py:66-67         */
+    int nthreads;      /* OpenMP threads, 0 = runtime default                      */
+    double pair_top;   /* namelist.py pair_top                                     */
+} oracle_cfg;
+
+/* grid constants: main_grid.py:299-314 (GRF dict) */
+typedef struct {
+    const double *A, *dxjs, *dyis, *corf, *corf_is, *lat_rad, *lat_is_rad,
+                 *dlon_rad, *dlat_rad;                 /* 2-D (.., .., 1) */
+    const double *sigma_vb, *dsigma, *UVFLX_dif_coef, *POTT_dif_coef; /* 1-D */
+} oracle_grid;
+
+/* model fields touched by the hot path: main_fields.py:234-475 */
+typedef struct {
+    double *COLP, *COLP_OLD, *COLP_NEW, *dCOLPdt, *HSURF;
+    double *UWIND, *UWIND_OLD, *VWIND, *VWIND_OLD, *WWIND;
+    double *POTT, *POTT_OLD, *POTTVB;
+    double *UFLX, *VFLX, *FLXDIV;
+    double *BFLX, *CFLX, *DFLX, *EFLX, *RFLX, *QFLX, *SFLX, *TFLX;
+    double *WWIND_UWIND, *WWIND_VWIND, *KMOM_dUWINDdz, *KMOM_dVWINDdz;
+    double *dUFLXdt, *dVFLXdt, *dPOTTdt;
+    double *dUFLXdt_TURB, *dVFLXdt_TURB, *dPOTTdt_TURB;
+    double *PVTF, *PVTFVB, *PHI, *PHIVB;
+    double *RHO, *RHOVB, *KMOM, *KHEAT;
+    double *SSHFLX, *SMOMXFLX, *SMOMYFLX, *dPOTTdt_RAD;
+} oracle_fields;
+
+/* misc_boundaries.py:22-42 ; stgx/stgy = 1 if staggered in that direction */
+void oracle_exchange_bc(const oracle_cfg *c, double *F, int stgx, int stgy, int nk);
+
+/* dyn_continuity.py:170-232 (kernel only, no exchange) */
+void oracle_continuity(const oracle_cfg *c, const oracle_grid *g, oracle_fields *f, double dt);
+/* dyn_UVFLX_prepare.py:249-439 */
+void oracle_uvflx_prepare(const oracle_cfg *c, const oracle_grid *g, oracle_fields *f);
+/* dyn_UFLX.py:339-434 */
+void oracle_uflx_tendency(const oracle_cfg *c, const oracle_grid *g, oracle_fields *f);
+/* dyn_VFLX.py:322-408 */
+void oracle_vflx_tendency(const oracle_cfg *c, const oracle_grid *g, oracle_fields *f);
+/* dyn_POTT.py:180-216 */
+void oracle_pott_tendency(const oracle_cfg *c, const oracle_grid *g, oracle_fields *f);
+/* dyn_timestep.py:212-297 (UWIND, VWIND, POTT only) */
+void oracle_make_timestep(const oracle_cfg *c, const oracle_grid *g, oracle_fields *f, double dt);
+/* dyn_diagnostics.py:139-195 */
+void oracle_diag_pvtf(const oracle_cfg *c, const oracle_grid *g, oracle_fields *f);
+void oracle_diag_phi(const oracle_cfg *c, oracle_fields *f);
+void oracle_diag_pottvb(const oracle_cfg *c, oracle_fields *f);
+/* dyn_diagnostics.py:199-222, RHO and RHOVB only (the two the dycore consumes) */
+void oracle_diag_rho(const oracle_cfg *c, oracle_fields *f);
+
+/* factory-level stages: dyn_org_discretizations.py:89-117, 121-249, 253-273, 359-393, 310-326 */
+void oracle_stage_continuity(const oracle_cfg *c, const oracle_grid *g, oracle_fields *f, double dt);
+void oracle_stage_momentum(const oracle_cfg *c, const oracle_grid *g, oracle_fields *f);
+void oracle_stage_temperature(const oracle_cfg *c, const oracle_grid *g, oracle_fields *f);
+void oracle_stage_euler_forward(const oracle_cfg *c, const oracle_grid *g, oracle_fields *f, double dt);
+void oracle_stage_primary_diag(const oracle_cfg *c, const oracle_grid *g, oracle_fields *f);
+
+/* dyn_matsuno.py:28-131, nsteps times; with_rho != 0 re-diagnoses RHO/RHOVB
+ * before every step as solver.py:99-101 does */
+void oracle_step_matsuno(const oracle_cfg *c, const oracle_grid *g, oracle_fields *f,
+                         double dt, int nsteps, int with_rho);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

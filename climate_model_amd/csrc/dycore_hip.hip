@@ -1,0 +1,570 @@
+// dycore_hip.hip -- host side of libdycore_hip.so: handle, field registry, layout adaptor,
+// stage launches, the fused Matsuno step and measurement.  C ABI in include/dycore.h.
+// Target: MI355X / gfx950 only.
+#include "../../include/dycore.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "dycore_common.h"
+#include "kernels_stage.h"
+
+using namespace dyc;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                        \
+    do {                                                                                     \
+        hipError_t e_ = (expr);                                                              \
+        if (e_ != hipSuccess)                                                                \
+            return fail(DYCORE_EHIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_),  \
+                        __FILE__, __LINE__);                                                 \
+    } while (0)
+
+struct FieldDesc {
+    const char *name;
+    int stgx, stgy;
+    int nk;                         // 0 -> nz, -1 -> nz+1, 1 -> 1
+    double *Ptrs::*member;
+};
+
+// main_fields.py:234-475
+#define F_(n, sx, sy, nk) {#n, sx, sy, nk, &Ptrs::n}
+const FieldDesc kFields[] = {
+    F_(COLP, 0, 0, 1), F_(COLP_OLD, 0, 0, 1), F_(COLP_NEW, 0, 0, 1), F_(dCOLPdt, 0, 0, 1), F_(HSURF, 0, 0, 1),
+    F_(UWIND, 1, 0, 0), F_(UWIND_OLD, 1, 0, 0), F_(VWIND, 0, 1, 0), F_(VWIND_OLD, 0, 1, 0), F_(WWIND, 0, 0, -1),
+    F_(POTT, 0, 0, 0), F_(POTT_OLD, 0, 0, 0), F_(POTTVB, 0, 0, -1),
+    F_(UFLX, 1, 0, 0), F_(VFLX, 0, 1, 0), F_(FLXDIV, 0, 0, 0),
+    F_(BFLX, 0, 0, 0), F_(CFLX, 1, 1, 0), F_(DFLX, 0, 1, 0), F_(EFLX, 0, 1, 0),
+    F_(RFLX, 0, 0, 0), F_(QFLX, 1, 1, 0), F_(SFLX, 1, 0, 0), F_(TFLX, 1, 0, 0),
+    F_(WWIND_UWIND, 1, 0, -1), F_(WWIND_VWIND, 0, 1, -1), F_(KMOM_dUWINDdz, 1, 0, -1), F_(KMOM_dVWINDdz, 0, 1, -1),
+    F_(dUFLXdt, 1, 0, 0), F_(dVFLXdt, 0, 1, 0), F_(dPOTTdt, 0, 0, 0),
+    F_(dUFLXdt_TURB, 1, 0, 0), F_(dVFLXdt_TURB, 0, 1, 0), F_(dPOTTdt_TURB, 0, 0, 0),
+    F_(PVTF, 0, 0, 0), F_(PVTFVB, 0, 0, -1), F_(PHI, 0, 0, 0), F_(PHIVB, 0, 0, -1),
+    F_(RHO, 0, 0, 0), F_(RHOVB, 0, 0, -1), F_(KMOM, 0, 0, -1), F_(KHEAT, 0, 0, -1),
+    F_(SSHFLX, 0, 0, 1), F_(SMOMXFLX, 0, 0, 1), F_(SMOMYFLX, 0, 0, 1), F_(dPOTTdt_RAD, 0, 0, 0),
+};
+#undef F_
+constexpr int kNFields = sizeof(kFields) / sizeof(kFields[0]);
+
+struct GridDesc {
+    const char *name;
+    int stgx, stgy;                 // 2-D: staggering; 1-D: stgx = -1
+    int nk;                         // 1-D: 0 -> nz, -1 -> nz+1
+    const double *Ptrs::*member;
+};
+#define G_(n, sx, sy, nk) {#n, sx, sy, nk, &Ptrs::n}
+const GridDesc kGrid[] = {
+    G_(A, 0, 0, 1), G_(dxjs, 0, 1, 1), G_(dyis, 1, 0, 1), G_(corf, 0, 0, 1), G_(corf_is, 1, 0, 1),
+    G_(lat_rad, 0, 0, 1), G_(lat_is_rad, 1, 0, 1), G_(dlon_rad, 0, 1, 1), G_(dlat_rad, 1, 0, 1),
+    G_(sigma_vb, -1, 0, -1), G_(dsigma, -1, 0, 0), G_(UVFLX_dif_coef, -1, 0, 0), G_(POTT_dif_coef, -1, 0, 0),
+};
+#undef G_
+constexpr int kNGrid = sizeof(kGrid) / sizeof(kGrid[0]);
+
+// kernels tracked by the profiler
+enum KernelId {
+    K_CONTINUITY = 0, K_PREPARE, K_UFLX, K_VFLX, K_POTT, K_EULER, K_DIAG, K_RHO, K_EXCHANGE, K_COPY,
+    K_COUNT
+};
+const char *kKernelNames[K_COUNT] = {
+    "k_continuity", "k_prepare", "k_uflx_tendency", "k_vflx_tendency", "k_pott_tendency",
+    "k_euler_forward", "k_primary_diag", "k_diag_rho", "k_exchange_bc", "copy_field",
+};
+
+struct ProfRec { int kid; hipEvent_t a, b; };
+
+}  // namespace
+
+struct dycore {
+    DycoreConfig cfg;
+    Geo g;
+    Ptrs p;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    std::unordered_map<std::string, int> field_idx, grid_idx;
+    std::vector<double *> allocs;
+    double *stage = nullptr;        // staging buffer for the layout adaptor
+    size_t stage_elems = 0;
+    int grid_set = 0;
+    // profiler
+    bool prof = false;
+    std::vector<ProfRec> recs;
+    std::vector<hipEvent_t> ev_pool;
+    int64_t launches[K_COUNT] = {0};
+    double total_ms[K_COUNT] = {0};
+
+    int nk_of(int code) const { return code == 0 ? g.nz : (code == -1 ? g.nz + 1 : 1); }
+    size_t field_elems(int code) const { return (size_t)g.plane * nk_of(code); }
+};
+
+namespace {
+
+int get_event(dycore *h, hipEvent_t *e)
+{
+    if (!h->ev_pool.empty()) { *e = h->ev_pool.back(); h->ev_pool.pop_back(); return 0; }
+    HIP_TRY(hipEventCreate(e));
+    return 0;
+}
+
+int prof_flush(dycore *h)
+{
+    if (h->recs.empty()) return 0;
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    for (auto &r : h->recs) {
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, r.a, r.b));
+        h->total_ms[r.kid] += ms;
+        h->launches[r.kid] += 1;
+        h->ev_pool.push_back(r.a);
+        h->ev_pool.push_back(r.b);
+    }
+    h->recs.clear();
+    return 0;
+}
+
+struct Scope {          // brackets one launch with events when profiling is on
+    dycore *h; int kid; ProfRec r; bool on;
+    Scope(dycore *h_, int kid_) : h(h_), kid(kid_), on(false)
+    {
+        if (!h->prof) return;
+        if (get_event(h, &r.a) || get_event(h, &r.b)) return;
+        r.kid = kid;
+        on = hipEventRecord(r.a, h->stream) == hipSuccess;
+    }
+    ~Scope()
+    {
+        if (!on) return;
+        (void)hipEventRecord(r.b, h->stream);
+        h->recs.push_back(r);
+        if (h->recs.size() >= 4096) prof_flush(h);
+    }
+};
+
+dim3 grid_for(const Geo &g, int ni, int nj) { return dim3((ni + TI - 1) / TI, (nj + TJ - 1) / TJ, 1); }
+
+int check_ready(dycore *h)
+{
+    if (!h) return fail(DYCORE_EINVAL, "null handle");
+    if (h->grid_set != (1 << kNGrid) - 1)
+        return fail(DYCORE_ESTATE, "grid constants missing: call dycore_set_grid for all %d arrays first", kNGrid);
+    return 0;
+}
+
+int launch_check(const char *what)
+{
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(DYCORE_EHIP, "launch of %s failed: %s", what, hipGetErrorString(e));
+    return 0;
+}
+
+// ---- stage launches -------------------------------------------------------------------
+int do_continuity(dycore *h, const Ptrs &p, double dt)
+{
+    Scope s(h, K_CONTINUITY);
+    hipLaunchKernelGGL(k_continuity, grid_for(h->g, h->g.nx, h->g.ny), dim3(TI, TJ), 0, h->stream, h->g, p, dt);
+    return launch_check("k_continuity");
+}
+int do_prepare(dycore *h, const Ptrs &p)
+{
+    Scope s(h, K_PREPARE);
+    dim3 gr = grid_for(h->g, h->g.nx + 1, h->g.ny + 1);
+    if (h->g.i_turb) hipLaunchKernelGGL(k_prepare<true>, gr, dim3(TI, TJ), 0, h->stream, h->g, p);
+    else hipLaunchKernelGGL(k_prepare<false>, gr, dim3(TI, TJ), 0, h->stream, h->g, p);
+    return launch_check("k_prepare");
+}
+int do_uflx(dycore *h, const Ptrs &p)
+{
+    Scope s(h, K_UFLX);
+    dim3 gr = grid_for(h->g, h->g.nx, h->g.ny);
+    if (h->g.i_turb) hipLaunchKernelGGL(k_uflx_tendency<true>, gr, dim3(TI, TJ), 0, h->stream, h->g, p);
+    else hipLaunchKernelGGL(k_uflx_tendency<false>, gr, dim3(TI, TJ), 0, h->stream, h->g, p);
+    return launch_check("k_uflx_tendency");
+}
+int do_vflx(dycore *h, const Ptrs &p)
+{
+    Scope s(h, K_VFLX);
+    const int jlo = h->g.pole_s ? 2 : 1;
+    const int jhi = h->g.ny;                      // js = ny+1 is a pole or the neighbour's row
+    if (jhi < jlo) return 0;
+    dim3 gr = grid_for(h->g, h->g.nx, jhi - jlo + 1);
+    if (h->g.i_turb) hipLaunchKernelGGL(k_vflx_tendency<true>, gr, dim3(TI, TJ), 0, h->stream, h->g, p, jlo, jhi);
+    else hipLaunchKernelGGL(k_vflx_tendency<false>, gr, dim3(TI, TJ), 0, h->stream, h->g, p, jlo, jhi);
+    return launch_check("k_vflx_tendency");
+}
+int do_pott(dycore *h, const Ptrs &p)
+{
+    Scope s(h, K_POTT);
+    dim3 gr = grid_for(h->g, h->g.nx, h->g.ny);
+    if (h->g.i_turb) hipLaunchKernelGGL(k_pott_tendency<true>, gr, dim3(TI, TJ), 0, h->stream, h->g, p);
+    else hipLaunchKernelGGL(k_pott_tendency<false>, gr, dim3(TI, TJ), 0, h->stream, h->g, p);
+    return launch_check("k_pott_tendency");
+}
+int do_euler(dycore *h, const Ptrs &p, double dt)
+{
+    Scope s(h, K_EULER);
+    hipLaunchKernelGGL(k_euler_forward, grid_for(h->g, h->g.nx, h->g.ny + 1), dim3(TI, TJ), 0, h->stream, h->g, p, dt);
+    return launch_check("k_euler_forward");
+}
+int do_diag(dycore *h, const Ptrs &p)
+{
+    Scope s(h, K_DIAG);
+    hipLaunchKernelGGL(k_primary_diag, grid_for(h->g, h->g.nx + 2, h->g.ny + 2), dim3(TI, TJ), 0, h->stream, h->g, p);
+    return launch_check("k_primary_diag");
+}
+int do_rho(dycore *h, const Ptrs &p)
+{
+    Scope s(h, K_RHO);
+    hipLaunchKernelGGL(k_diag_rho, grid_for(h->g, h->g.nx + 2, h->g.ny + 2), dim3(TI, TJ), 0, h->stream, h->g, p);
+    return launch_check("k_diag_rho");
+}
+int do_exchange(dycore *h, double *F, int stgx, int stgy, int nk)
+{
+    Scope s(h, K_EXCHANGE);
+    const int fnx = h->g.nx + 2 + stgx, fny = h->g.ny + 2 + stgy;
+    hipLaunchKernelGGL(k_exchange_bc, dim3((fnx + 255) / 256, fny, nk), dim3(256), 0, h->stream, h->g, F, stgx, stgy, nk);
+    return launch_check("k_exchange_bc");
+}
+int do_copy(dycore *h, double *dst, const double *src, size_t elems)
+{
+    Scope s(h, K_COPY);
+    HIP_TRY(hipMemcpyAsync(dst, src, elems * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+    return 0;
+}
+
+int do_momentum(dycore *h, const Ptrs &p)
+{
+    int rc;
+    if (h->g.i_turb) {   // dyn_org_discretizations.py:195-196, 212-216
+        if ((rc = do_exchange(h, p.KMOM, 0, 0, h->g.nz + 1))) return rc;
+    }
+    if ((rc = do_prepare(h, p))) return rc;
+    if (h->g.i_turb) {   // KMOM_d*dz halos are written by k_prepare itself
+        if ((rc = do_exchange(h, p.SMOMXFLX, 0, 0, 1))) return rc;
+        if ((rc = do_exchange(h, p.SMOMYFLX, 0, 0, 1))) return rc;
+    }
+    if ((rc = do_uflx(h, p))) return rc;
+    return do_vflx(h, p);
+}
+
+// dyn_matsuno.py:28-131 with the *_OLD copies replaced by pointer rotation: after the swap
+// X_OLD holds the state at step start; the predictor evaluates tendencies on X_OLD and
+// writes the estimate into X, the corrector evaluates on X and overwrites X in place
+// (k_euler_forward reads X_OLD and the tendency at the written cell only).
+int do_step(dycore *h, double dt, int with_rho)
+{
+    int rc;
+    Ptrs &p = h->p;
+    if (with_rho && (rc = do_rho(h, p))) return rc;
+    std::swap(p.UWIND, p.UWIND_OLD);
+    std::swap(p.VWIND, p.VWIND_OLD);
+    std::swap(p.POTT, p.POTT_OLD);
+    std::swap(p.COLP, p.COLP_OLD);
+    for (int sub = 0; sub < 2; sub++) {
+        Ptrs q = p;
+        if (sub == 0) {            // predictor: the current state IS the *_OLD buffers
+            q.UWIND = p.UWIND_OLD; q.VWIND = p.VWIND_OLD; q.POTT = p.POTT_OLD; q.COLP = p.COLP_OLD;
+        }
+        if ((rc = do_continuity(h, q, dt))) return rc;
+        if ((rc = do_momentum(h, q))) return rc;
+        if ((rc = do_pott(h, q))) return rc;
+        // COLP <- COLP_NEW (dyn_matsuno.py:64-67), then the Euler step writes p.UWIND/VWIND/POTT
+        if ((rc = do_copy(h, p.COLP, p.COLP_NEW, (size_t)h->g.plane))) return rc;
+        if ((rc = do_euler(h, p, dt))) return rc;
+        if ((rc = do_diag(h, p))) return rc;
+    }
+    return 0;
+}
+
+}  // namespace
+
+// =========================================================================================
+extern "C" {
+
+const char *dycore_last_error(void) { return g_err.c_str(); }
+int dycore_abi_version(void) { return DYCORE_ABI_VERSION; }
+
+int dycore_create(const DycoreConfig *cfg, dycore_t **out)
+{
+    if (!cfg || !out) return fail(DYCORE_EINVAL, "null argument");
+    if (cfg->abi_version != DYCORE_ABI_VERSION)
+        return fail(DYCORE_EINVAL, "ABI version mismatch: caller %d, library %d", cfg->abi_version, DYCORE_ABI_VERSION);
+    if (cfg->nx < 3 || cfg->ny < 2 || cfg->nz < 2)
+        return fail(DYCORE_EINVAL, "extents too small: nx=%d ny=%d nz=%d (need nx>=3, ny>=2, nz>=2)", cfg->nx, cfg->ny, cfg->nz);
+    if (cfg->ny_global < cfg->ny || cfg->j_offset < 0 || cfg->j_offset + cfg->ny > cfg->ny_global)
+        return fail(DYCORE_EINVAL, "band [%d,%d] outside the global grid of %d rows", cfg->j_offset + 1, cfg->j_offset + cfg->ny, cfg->ny_global);
+    int ndev = 0;
+    HIP_TRY(hipGetDeviceCount(&ndev));
+    if (cfg->device < 0 || cfg->device >= ndev) return fail(DYCORE_EINVAL, "device %d not present (%d visible)", cfg->device, ndev);
+    HIP_TRY(hipSetDevice(cfg->device));
+
+    dycore *h = new dycore();
+    h->cfg = *cfg;
+    Geo &g = h->g;
+    g.nx = cfg->nx; g.ny = cfg->ny; g.nz = cfg->nz;
+    g.P = ((cfg->nx + 3 + 63) / 64) * 64;
+    g.NJ = cfg->ny + 3;
+    g.plane = (long long)g.P * g.NJ;
+    g.ny_global = cfg->ny_global; g.joff = cfg->j_offset;
+    g.pole_s = (cfg->j_offset == 0);
+    g.pole_n = (cfg->j_offset + cfg->ny == cfg->ny_global);
+    g.i_turb = cfg->i_turb != 0; g.i_rad = cfg->i_radiation != 0;
+    g.pair_top = cfg->pair_top;
+    memset(&h->p, 0, sizeof h->p);
+    if (cfg->stream) h->stream = (hipStream_t)cfg->stream;
+    else {
+        hipError_t e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
+        if (e != hipSuccess) { delete h; return fail(DYCORE_EHIP, "hipStreamCreate: %s", hipGetErrorString(e)); }
+        h->own_stream = true;
+    }
+    const double nan = std::numeric_limits<double>::quiet_NaN();
+    auto alloc = [&](size_t elems, double **out_p) -> int {
+        double *d = nullptr;
+        hipError_t e = hipMalloc((void **)&d, elems * sizeof(double));
+        if (e != hipSuccess) return fail(DYCORE_ENOMEM, "hipMalloc of %zu bytes failed: %s", elems * sizeof(double), hipGetErrorString(e));
+        h->allocs.push_back(d);
+        hipLaunchKernelGGL(k_fill, dim3(1024), dim3(256), 0, h->stream, d, elems, nan);   // main_fields.py:484
+        *out_p = d;
+        return 0;
+    };
+    int rc = 0;
+    for (int f = 0; f < kNFields && !rc; f++) {
+        double *d = nullptr;
+        rc = alloc(h->field_elems(kFields[f].nk), &d);
+        h->p.*(kFields[f].member) = d;
+        h->field_idx[kFields[f].name] = f;
+    }
+    for (int f = 0; f < kNGrid && !rc; f++) {
+        double *d = nullptr;
+        const size_t elems = kGrid[f].stgx < 0 ? (size_t)(g.nz + 1) : (size_t)g.plane;
+        rc = alloc(elems, &d);
+        h->p.*(kGrid[f].member) = d;
+        h->grid_idx[kGrid[f].name] = f;
+    }
+    if (!rc) {
+        h->stage_elems = (size_t)(g.nx + 3) * (g.ny + 3) * (g.nz + 1);
+        double *d = nullptr;
+        rc = alloc(h->stage_elems, &d);
+        h->stage = d;
+    }
+    if (!rc && hipStreamSynchronize(h->stream) != hipSuccess) rc = fail(DYCORE_EHIP, "initial fill failed");
+    if (rc) { dycore_destroy(h); return rc; }
+    *out = h;
+    return 0;
+}
+
+int dycore_destroy(dycore_t *h)
+{
+    if (!h) return 0;
+    (void)hipStreamSynchronize(h->stream);
+    for (auto &r : h->recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+    for (auto e : h->ev_pool) (void)hipEventDestroy(e);
+    for (double *d : h->allocs) (void)hipFree(d);
+    if (h->own_stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+    return 0;
+}
+
+int dycore_sync(dycore_t *h)
+{
+    if (!h) return fail(DYCORE_EINVAL, "null handle");
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+int dycore_set_grid(dycore_t *h, const char *name, const double *host, int32_t n0, int32_t n1, int32_t n2)
+{
+    if (!h || !name || !host) return fail(DYCORE_EINVAL, "null argument");
+    auto it = h->grid_idx.find(name);
+    if (it == h->grid_idx.end()) return fail(DYCORE_EINVAL, "unknown grid array '%s'", name);
+    const GridDesc &d = kGrid[it->second];
+    const Geo &g = h->g;
+    double *dev = const_cast<double *>(h->p.*(d.member));
+    if (d.stgx < 0) {
+        const int n = d.nk == 0 ? g.nz : g.nz + 1;
+        if ((long long)n0 * n1 * n2 != n) return fail(DYCORE_EINVAL, "grid array '%s': expected %d elements, got %dx%dx%d", name, n, n0, n1, n2);
+        HIP_TRY(hipMemcpyAsync(dev, host, n * sizeof(double), hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(hipStreamSynchronize(h->stream));
+    } else {
+        const int e0 = g.nx + 2 + d.stgx, e1 = g.ny + 2 + d.stgy;
+        if (n0 != e0 || n1 != e1 || n2 != 1)
+            return fail(DYCORE_EINVAL, "grid array '%s': expected shape (%d,%d,1), got (%d,%d,%d)", name, e0, e1, n0, n1, n2);
+        const size_t n = (size_t)n0 * n1;
+        HIP_TRY(hipMemcpyAsync(h->stage, host, n * sizeof(double), hipMemcpyHostToDevice, h->stream));
+        hipLaunchKernelGGL(k_to_device, dim3((n0 + 31) / 32, 1, n1), dim3(32, 8), 0, h->stream, g, h->stage, dev, n0, n1, 1);
+        int rc = launch_check("k_to_device");
+        if (rc) return rc;
+        HIP_TRY(hipStreamSynchronize(h->stream));
+    }
+    h->grid_set |= 1 << it->second;
+    return 0;
+}
+
+static int find_field(dycore_t *h, const char *name, const FieldDesc **d)
+{
+    if (!h || !name) return fail(DYCORE_EINVAL, "null argument");
+    auto it = h->field_idx.find(name);
+    if (it == h->field_idx.end()) return fail(DYCORE_EINVAL, "unknown field '%s'", name);
+    *d = &kFields[it->second];
+    return 0;
+}
+
+int dycore_field_shape(dycore_t *h, const char *name, int32_t shape[3])
+{
+    const FieldDesc *d;
+    int rc = find_field(h, name, &d);
+    if (rc) return rc;
+    shape[0] = h->g.nx + 2 + d->stgx;
+    shape[1] = h->g.ny + 2 + d->stgy;
+    shape[2] = h->nk_of(d->nk);
+    return 0;
+}
+
+int dycore_upload(dycore_t *h, const char *name, const double *host)
+{
+    const FieldDesc *d;
+    int rc = find_field(h, name, &d);
+    if (rc) return rc;
+    if (!host) return fail(DYCORE_EINVAL, "null host pointer");
+    const Geo &g = h->g;
+    const int n0 = g.nx + 2 + d->stgx, n1 = g.ny + 2 + d->stgy, n2 = h->nk_of(d->nk);
+    const size_t n = (size_t)n0 * n1 * n2;
+    HIP_TRY(hipMemcpyAsync(h->stage, host, n * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    hipLaunchKernelGGL(k_to_device, dim3((n0 + 31) / 32, (n2 + 31) / 32, n1), dim3(32, 8), 0, h->stream,
+                       g, h->stage, h->p.*(d->member), n0, n1, n2);
+    if ((rc = launch_check("k_to_device"))) return rc;
+    HIP_TRY(hipStreamSynchronize(h->stream));   // the staging buffer is reused by the next call
+    return 0;
+}
+
+int dycore_download(dycore_t *h, const char *name, double *host)
+{
+    const FieldDesc *d;
+    int rc = find_field(h, name, &d);
+    if (rc) return rc;
+    if (!host) return fail(DYCORE_EINVAL, "null host pointer");
+    const Geo &g = h->g;
+    const int n0 = g.nx + 2 + d->stgx, n1 = g.ny + 2 + d->stgy, n2 = h->nk_of(d->nk);
+    const size_t n = (size_t)n0 * n1 * n2;
+    hipLaunchKernelGGL(k_to_host, dim3((n0 + 31) / 32, (n2 + 31) / 32, n1), dim3(32, 8), 0, h->stream,
+                       g, h->p.*(d->member), h->stage, n0, n1, n2);
+    if ((rc = launch_check("k_to_host"))) return rc;
+    HIP_TRY(hipMemcpyAsync(host, h->stage, n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+int dycore_field_ptr(dycore_t *h, const char *name, void **dev, int64_t *pitch, int64_t *rows, int64_t *levels)
+{
+    const FieldDesc *d;
+    int rc = find_field(h, name, &d);
+    if (rc) return rc;
+    if (dev) *dev = h->p.*(d->member);
+    if (pitch) *pitch = h->g.P;
+    if (rows) *rows = h->g.NJ;
+    if (levels) *levels = h->nk_of(d->nk);
+    return 0;
+}
+
+int dycore_copy_field(dycore_t *h, const char *dst, const char *src)
+{
+    const FieldDesc *a, *b;
+    int rc;
+    if ((rc = find_field(h, dst, &a)) || (rc = find_field(h, src, &b))) return rc;
+    if (a->stgx != b->stgx || a->stgy != b->stgy || a->nk != b->nk)
+        return fail(DYCORE_EINVAL, "copy_field: '%s' and '%s' differ in shape", dst, src);
+    return do_copy(h, h->p.*(a->member), h->p.*(b->member), h->field_elems(a->nk));
+}
+
+int dycore_exchange_bc(dycore_t *h, const char *name)
+{
+    const FieldDesc *d;
+    int rc = find_field(h, name, &d);
+    if (rc) return rc;
+    return do_exchange(h, h->p.*(d->member), d->stgx, d->stgy, h->nk_of(d->nk));
+}
+
+int dycore_continuity(dycore_t *h, double dt) { int rc = check_ready(h); return rc ? rc : do_continuity(h, h->p, dt); }
+int dycore_momentum(dycore_t *h) { int rc = check_ready(h); return rc ? rc : do_momentum(h, h->p); }
+int dycore_momentum_prepare(dycore_t *h) { int rc = check_ready(h); return rc ? rc : do_prepare(h, h->p); }
+int dycore_uflx_tendency(dycore_t *h) { int rc = check_ready(h); return rc ? rc : do_uflx(h, h->p); }
+int dycore_vflx_tendency(dycore_t *h) { int rc = check_ready(h); return rc ? rc : do_vflx(h, h->p); }
+int dycore_pott_tendency(dycore_t *h) { int rc = check_ready(h); return rc ? rc : do_pott(h, h->p); }
+int dycore_euler_forward(dycore_t *h, double dt) { int rc = check_ready(h); return rc ? rc : do_euler(h, h->p, dt); }
+int dycore_primary_diag(dycore_t *h) { int rc = check_ready(h); return rc ? rc : do_diag(h, h->p); }
+int dycore_secondary_diag_rho(dycore_t *h) { int rc = check_ready(h); return rc ? rc : do_rho(h, h->p); }
+
+int dycore_step_matsuno(dycore_t *h, double dt, int32_t nsteps, int32_t with_rho)
+{
+    int rc = check_ready(h);
+    if (rc) return rc;
+    if (nsteps < 0) return fail(DYCORE_EINVAL, "nsteps < 0");
+    for (int s = 0; s < nsteps; s++)
+        if ((rc = do_step(h, dt, with_rho))) return rc;
+    return 0;
+}
+
+int dycore_time_steps(dycore_t *h, double dt, int32_t nsteps, int32_t with_rho, double *ms)
+{
+    int rc = check_ready(h);
+    if (rc) return rc;
+    if (!ms) return fail(DYCORE_EINVAL, "null ms");
+    hipEvent_t a, b;
+    HIP_TRY(hipEventCreate(&a));
+    HIP_TRY(hipEventCreate(&b));
+    HIP_TRY(hipEventRecord(a, h->stream));
+    for (int s = 0; s < nsteps && !rc; s++) rc = do_step(h, dt, with_rho);
+    HIP_TRY(hipEventRecord(b, h->stream));
+    HIP_TRY(hipEventSynchronize(b));
+    float f = 0.f;
+    HIP_TRY(hipEventElapsedTime(&f, a, b));
+    (void)hipEventDestroy(a);
+    (void)hipEventDestroy(b);
+    *ms = f;
+    return rc;
+}
+
+int dycore_profile(dycore_t *h, int32_t enable)
+{
+    if (!h) return fail(DYCORE_EINVAL, "null handle");
+    int rc = prof_flush(h);
+    h->prof = enable != 0;
+    if (enable) { memset(h->launches, 0, sizeof h->launches); memset(h->total_ms, 0, sizeof h->total_ms); }
+    return rc;
+}
+
+int dycore_n_kernels(void) { return K_COUNT; }
+
+int dycore_kernel_stats(dycore_t *h, int32_t idx, const char **name, int64_t *launches, double *total_ms)
+{
+    if (!h || idx < 0 || idx >= K_COUNT) return fail(DYCORE_EINVAL, "bad kernel index");
+    int rc = prof_flush(h);
+    if (rc) return rc;
+    if (name) *name = kKernelNames[idx];
+    if (launches) *launches = h->launches[idx];
+    if (total_ms) *total_ms = h->total_ms[idx];
+    return 0;
+}
+
+}  // extern "C"

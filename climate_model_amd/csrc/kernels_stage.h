@@ -1,0 +1,610 @@
+// kernels_stage.h -- one HIP kernel per reference kernel of the Matsuno step.
+//
+// Thread mapping (all kernels): lane <-> longitude i (64 consecutive i per wavefront, so
+// every global access is a coalesced 512-B row segment), threadIdx.y <-> latitude row j,
+// the k loop runs inside the thread with the k+-1 neighbours carried in registers.
+// These "stage" kernels read their horizontal neighbours straight from global memory
+// (L1/L2 absorb the 3x3 reuse); they back the per-stage C ABI and the parity tests.
+// The fused fast path used by dycore_step_matsuno lives in kernels_fused.h.
+#pragma once
+#include "dycore_common.h"
+
+namespace dyc {
+
+constexpr int TI = 64;   // lanes along i  (one wavefront)
+constexpr int TJ = 4;    // rows per workgroup
+
+#define DYC_IJ(i0, j0)                                   \
+    const int i = blockIdx.x * TI + threadIdx.x + (i0);  \
+    const int j = blockIdx.y * TJ + threadIdx.y + (j0);
+
+// ------------------------------------------------------------------------------------
+// continuity: dyn_continuity.py:170-232 (+ exchange_BC of UFLX, VFLX, WWIND, COLP_NEW,
+// dyn_org_discretizations.py:107-117).  Owned cells i in [1,nx], j in [1,ny].
+__global__ __launch_bounds__(TI *TJ) void k_continuity(Geo g, Ptrs p, double dt)
+{
+    DYC_IJ(1, 1)
+    if (i > g.nx || j > g.ny) return;
+    const size_t c = at2(g, i, j);
+    const double colp = p.COLP[c];
+    const double c_im1 = p.COLP[c - 1], c_ip1 = p.COLP[c + 1];
+    const double c_jm1 = p.COLP[c - g.P], c_jp1 = p.COLP[c + g.P];
+    const double dy_i = p.dyis[c], dy_ip1 = p.dyis[c + 1];
+    const double dx_j = p.dxjs[c], dx_jp1 = p.dxjs[c + g.P];
+    const double area = p.A[c];
+    const bool top_row = (j == g.ny && g.pole_n);
+    double sum = 0.0;
+    for (int k = 0; k < g.nz; k++) {
+        const size_t q = c + (size_t)k * g.plane;
+        const double uflx_i = (c_im1 + colp) / 2.0 * p.UWIND[q] * dy_i;
+        const double uflx_ip1 = (colp + c_ip1) / 2.0 * p.UWIND[q + 1] * dy_ip1;
+        const double vflx_j = (c_jm1 + colp) / 2.0 * p.VWIND[q] * dx_j;
+        const double vflx_jp1 = (colp + c_jp1) / 2.0 * p.VWIND[q + g.P] * dx_jp1;
+        put_c(p.UFLX, g, i, j, k, uflx_i, 1);
+        put_s(p.VFLX, g, i, j, k, vflx_j);
+        if (top_row) put_s(p.VFLX, g, i, j + 1, k, 0.0);
+        const double div = (uflx_ip1 - uflx_i + vflx_jp1 - vflx_j) * p.dsigma[k] / area;
+        p.FLXDIV[q] = div;
+        sum += div;
+    }
+    const double dcolpdt = -sum;
+    const double colp_new = p.COLP_OLD[c] + dt * dcolpdt;
+    p.dCOLPdt[c] = dcolpdt;
+    put_c(p.COLP_NEW, g, i, j, 0, colp_new, 0);
+    // sigma-dot vanishes at the model top and at the surface (io_initial_conditions.py:45-46)
+    put_c(p.WWIND, g, i, j, 0, 0.0, 0);
+    put_c(p.WWIND, g, i, j, g.nz, 0.0, 0);
+    double run = p.FLXDIV[c];
+    for (int k = 1; k < g.nz; k++) {
+        const double w = -run / colp_new - p.sigma_vb[k] * dcolpdt / colp_new;
+        put_c(p.WWIND, g, i, j, k, w, 0);
+        run += p.FLXDIV[c + (size_t)k * g.plane];
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// momentum-flux preparation: dyn_UVFLX_prepare.py:249-439.
+// Threads cover is in [1,nx+1], js in [1,ny+1]; each output keeps its own staggered range.
+template <bool TURB>
+__global__ __launch_bounds__(TI *TJ) void k_prepare(Geo g, Ptrs p)
+{
+    DYC_IJ(1, 1)
+    if (i > g.nx + 1 || j > g.ny + 1) return;
+    const int P = g.P;
+    const size_t c = at2(g, i, j);
+    const int jg = j + g.joff;
+    const bool u_ok = (j <= g.ny);               // WWIND_UWIND, KMOM_dUWINDdz, S, T  rows
+    const bool v_ok = (i <= g.nx);               // WWIND_VWIND, KMOM_dVWINDdz, D, E  columns
+    const bool lo = (jg == 1), hi = (jg == g.ny_global);
+
+    // COLP_NEW*A at the nine points (2-D, reused for every level)
+    double ca[3][3];
+#pragma unroll
+    for (int b = 0; b < 3; b++)
+#pragma unroll
+        for (int a = 0; a < 3; a++) {
+            const int ii = i + a - 1, jj = j + b - 1;
+            const bool in = (ii <= g.nx + 1) && (jj <= g.ny + 1);
+            ca[b][a] = in ? p.COLP_NEW[at2(g, ii, jj)] * p.A[at2(g, ii, jj)] : 0.0;
+        }
+    if (u_ok) { p.WWIND_UWIND[c] = 0.0; p.WWIND_UWIND[c + (size_t)g.nz * g.plane] = 0.0; }
+    if (v_ok) { p.WWIND_VWIND[c] = 0.0; p.WWIND_VWIND[c + (size_t)g.nz * g.plane] = 0.0; }
+    if (TURB) {
+        // k = 0 and k = nz: never consumed (dyn_UFLX.py:158-167); the reference returns an
+        // unassigned local there (dyn_functions.py:310/377) -> 0
+        if (u_ok) { put_c(p.KMOM_dUWINDdz, g, i, j, 0, 0.0, 1); put_c(p.KMOM_dUWINDdz, g, i, j, g.nz, 0.0, 1); }
+        if (v_ok) { put_s(p.KMOM_dVWINDdz, g, i, j, 0, 0.0); put_s(p.KMOM_dVWINDdz, g, i, j, g.nz, 0.0); }
+    }
+
+    double u_km1 = 0.0, v_km1 = 0.0;
+    for (int k = 0; k < g.nz; k++) {
+        const size_t q = c + (size_t)k * g.plane;
+        // ---- interface quantities (k = 1..nz-1) ----
+        const double u_k = u_ok ? p.UWIND[q] : 0.0;
+        const double v_k = v_ok ? p.VWIND[q] : 0.0;
+        if (k >= 1) {
+            const double ds = p.dsigma[k], ds_km1 = p.dsigma[k - 1];
+            // W(a,b) = COLP_NEW*A*WWIND at (i+a-1, j+b-1)
+#define WT(a, b) (ca[b][a] * p.WWIND[q + ((b) - 1) * P + ((a) - 1)])
+#define WT2(a, b) (2.0 * ca[b][a] * p.WWIND[q + ((b) - 1) * P + ((a) - 1)])
+            if (u_ok) {   // dyn_functions.py:211-270, d = i, p = j, rigid wall at the poles
+                double s;
+                if (lo) s = 0.25 * (WT(0, 2) + WT(1, 2) + WT(0, 1) + WT(1, 1));
+                else if (hi) s = 0.25 * (WT(0, 1) + WT(1, 1) + WT(0, 0) + WT(1, 0));
+                else s = 0.125 * (WT(0, 2) + WT(1, 2) + WT2(0, 1) + WT2(1, 1) + WT(0, 0) + WT(1, 0));
+                const double u_ks = (ds * u_km1 + ds_km1 * u_k) / (ds + ds_km1);
+                p.WWIND_UWIND[q] = s * u_ks;
+            }
+            if (v_ok) {   // d = j, p = i, no wall
+                const double s = 0.125 * (WT(2, 0) + WT(2, 1) + WT2(1, 0) + WT2(1, 1) + WT(0, 0) + WT(0, 1));
+                const double v_ks = (ds * v_km1 + ds_km1 * v_k) / (ds + ds_km1);
+                p.WWIND_VWIND[q] = s * v_ks;
+            }
+#undef WT
+#undef WT2
+            if (TURB) {   // dyn_functions.py:276-377 (uses COLP, not COLP_NEW: dyn_UVFLX_prepare.py:318-320)
+#define KT(a, b) (p.RHOVB[q + ((b) - 1) * P + ((a) - 1)] * p.COLP[c + ((b) - 1) * P + ((a) - 1)] * p.A[c + ((b) - 1) * P + ((a) - 1)] * p.KMOM[q + ((b) - 1) * P + ((a) - 1)])
+#define KT2(a, b) (2.0 * p.RHOVB[q + ((b) - 1) * P + ((a) - 1)] * p.COLP[c + ((b) - 1) * P + ((a) - 1)] * p.A[c + ((b) - 1) * P + ((a) - 1)] * p.KMOM[q + ((b) - 1) * P + ((a) - 1)])
+#define PH(a, b) p.PHI[q + ((b) - 1) * P + ((a) - 1)]
+#define PHM(a, b) p.PHI[q - g.plane + ((b) - 1) * P + ((a) - 1)]
+                if (u_ok) {
+                    double k6, alt_km1, alt;
+                    if (lo) {
+                        k6 = 0.25 * (KT(0, 2) + KT(1, 2) + KT(0, 1) + KT(1, 1));
+                        alt_km1 = 0.25 * (PHM(0, 2) + PHM(1, 2) + PHM(0, 1) + PHM(1, 1)) / CON_G;
+                        alt = 0.25 * (PH(0, 2) + PH(1, 2) + PH(0, 1) + PH(1, 1)) / CON_G;
+                    } else if (hi) {
+                        k6 = 0.25 * (KT(0, 1) + KT(1, 1) + KT(0, 0) + KT(1, 0));
+                        alt_km1 = 0.25 * (PHM(0, 1) + PHM(1, 1) + PHM(0, 0) + PHM(1, 0)) / CON_G;
+                        alt = 0.25 * (PH(0, 1) + PH(1, 1) + PH(0, 0) + PH(1, 0)) / CON_G;
+                    } else {
+                        k6 = 0.125 * (KT(0, 2) + KT(1, 2) + KT2(0, 1) + KT2(1, 1) + KT(0, 0) + KT(1, 0));
+                        alt_km1 = 0.125 * (PHM(0, 2) + PHM(1, 2) + 2.0 * PHM(0, 1) + 2.0 * PHM(1, 1) + PHM(0, 0) + PHM(1, 0)) / CON_G;
+                        alt = 0.125 * (PH(0, 2) + PH(1, 2) + 2.0 * PH(0, 1) + 2.0 * PH(1, 1) + PH(0, 0) + PH(1, 0)) / CON_G;
+                    }
+                    put_c(p.KMOM_dUWINDdz, g, i, j, k, k6 * ((u_km1 - u_k) / (alt_km1 - alt)), 1);
+                }
+                if (v_ok) {
+                    const double k6 = 0.125 * (KT(2, 0) + KT(2, 1) + KT2(1, 0) + KT2(1, 1) + KT(0, 0) + KT(0, 1));
+                    const double alt_km1 = 0.125 * (PHM(2, 0) + PHM(2, 1) + 2.0 * PHM(1, 0) + 2.0 * PHM(1, 1) + PHM(0, 0) + PHM(0, 1)) / CON_G;
+                    const double alt = 0.125 * (PH(2, 0) + PH(2, 1) + 2.0 * PH(1, 0) + 2.0 * PH(1, 1) + PH(0, 0) + PH(0, 1)) / CON_G;
+                    put_s(p.KMOM_dVWINDdz, g, i, j, k, k6 * ((v_km1 - v_k) / (alt_km1 - alt)));
+                }
+#undef KT
+#undef KT2
+#undef PH
+#undef PHM
+            }
+        }
+        u_km1 = u_k;
+        v_km1 = v_k;
+        // ---- the eight Arakawa-C fluxes (dyn_functions.py:429-536) ----
+        // UF/VF(a,b) at (i+a-1, j+b-1); loads outside a field's extent are not issued
+#define UF(a, b) p.UFLX[q + ((b) - 1) * P + ((a) - 1)]
+#define VF(a, b) p.VFLX[q + ((b) - 1) * P + ((a) - 1)]
+        {   // (is,js): C, Q
+            p.CFLX[q] = 1.0 / 12.0 * (VF(0, 0) + VF(1, 0) + 2.0 * (VF(0, 1) + VF(1, 1)) + VF(0, 2) + VF(1, 2));
+            p.QFLX[q] = 1.0 / 12.0 * (UF(0, 0) + UF(0, 1) + 2.0 * (UF(1, 0) + UF(1, 1)) + UF(2, 0) + UF(2, 1));
+        }
+        if (v_ok) {   // (i,js): D, E
+            const double vs = VF(1, 0) + 2.0 * VF(1, 1) + VF(1, 2);
+            p.DFLX[q] = 1.0 / 24.0 * (vs + UF(1, 0) + UF(1, 1) + UF(2, 0) + UF(2, 1));
+            p.EFLX[q] = 1.0 / 24.0 * (vs - UF(1, 0) - UF(1, 1) - UF(2, 0) - UF(2, 1));
+        }
+        if (u_ok) {   // (is,j): S, T
+            const double vs = VF(0, 1) + VF(0, 2) + VF(1, 1) + VF(1, 2);
+            p.SFLX[q] = 1.0 / 24.0 * (vs + UF(0, 1) + 2.0 * UF(1, 1) + UF(2, 1));
+            p.TFLX[q] = 1.0 / 24.0 * (vs - UF(0, 1) - 2.0 * UF(1, 1) - UF(2, 1));
+        }
+        if (u_ok && v_ok) {   // (i,j): B, R
+            p.BFLX[q] = 1.0 / 12.0 * (UF(1, 0) + UF(2, 0) + 2.0 * (UF(1, 1) + UF(2, 1)) + UF(1, 2) + UF(2, 2));
+            p.RFLX[q] = 1.0 / 12.0 * (VF(0, 1) + VF(0, 2) + 2.0 * (VF(1, 1) + VF(1, 2)) + VF(2, 1) + VF(2, 2));
+        }
+#undef UF
+#undef VF
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// dyn_functions.py:383-424 (divides by g itself)
+__device__ __forceinline__ double var_ds(double v0, double v_dm1, double v_pm1, double v_pp1,
+                                         double v_pm1_dm1, double v_pp1_dm1, bool lo, bool hi)
+{
+    if (lo) return 0.25 * (v_pp1_dm1 + v_pp1 + v_dm1 + v0) / CON_G;
+    if (hi) return 0.25 * (v_dm1 + v0 + v_pm1_dm1 + v_pm1) / CON_G;
+    return 0.125 * (v_pp1_dm1 + v_pp1 + 2.0 * v_dm1 + 2.0 * v0 + v_pm1_dm1 + v_pm1) / CON_G;
+}
+
+// dyn_functions.py:177-207
+__device__ __forceinline__ double pre_grad(double phi, double phi_dm1, double colp, double colp_dm1,
+                                           double pott, double pott_dm1, double pvtf, double pvtf_dm1,
+                                           double pvtfvb, double pvtfvb_dm1, double pvtfvb_dm1_kp1,
+                                           double pvtfvb_kp1, double dsig, double svb, double svb_kp1,
+                                           double dgrid)
+{
+    return -dgrid * ((phi - phi_dm1) * (colp + colp_dm1) / 2.0 +
+                     (colp - colp_dm1) * CON_CP / 2.0 *
+                         (pott_dm1 / dsig * (svb_kp1 * (pvtfvb_dm1_kp1 - pvtf_dm1) + svb * (pvtf_dm1 - pvtfvb_dm1)) +
+                          pott / dsig * (svb_kp1 * (pvtfvb_kp1 - pvtf) + svb * (pvtf - pvtfvb))));
+}
+
+// ------------------------------------------------------------------------------------
+// dUFLXdt: dyn_UFLX.py:339-434 (loop) and :69-199 (terms).  Owned is in [1,nx], j in [1,ny];
+// column nx+1 is the periodic duplicate the reference computes from NaN halos and discards.
+template <bool TURB>
+__global__ __launch_bounds__(TI *TJ) void k_uflx_tendency(Geo g, Ptrs p)
+{
+    DYC_IJ(1, 1)
+    if (i > g.nx || j > g.ny) return;
+    const int P = g.P;
+    const size_t c = at2(g, i, j);
+    const int jg = j + g.joff;
+    const bool lo = (jg == 1), hi = (jg == g.ny_global);
+    const int dm = (i == 1) ? (g.nx - 1) : -1;        // offset to the i-1 flux column (dyn_UFLX.py:366-374)
+    const double colp = p.COLP[c], colp_im1 = p.COLP[c - 1];
+    const double corf = p.corf_is[c], lat = p.lat_is_rad[c];
+    const double coslat = cos(lat), sinlat = sin(lat);
+    const double dlon = p.dlon_rad[c], dlat = p.dlat_rad[c], dyis = p.dyis[c];
+    double smom_is = 0.0;
+    if (TURB)
+        smom_is = var_ds(p.SMOMXFLX[c], p.SMOMXFLX[c - 1], p.SMOMXFLX[c - P], p.SMOMXFLX[c + P],
+                         p.SMOMXFLX[c - P - 1], p.SMOMXFLX[c + P - 1], lo, hi);
+    double wu_k = p.WWIND_UWIND[c];
+    double pvb_k = p.PVTFVB[c], pvb_im1_k = p.PVTFVB[c - 1];
+    for (int k = 0; k < g.nz; k++) {
+        const size_t q = c + (size_t)k * g.plane;
+        double bflx = p.BFLX[q], bflx_im1 = p.BFLX[q + dm];
+        double cflx = p.CFLX[q], cflx_jp1 = p.CFLX[q + P];
+        double dflx_im1 = p.DFLX[q + dm], dflx_jp1 = p.DFLX[q + P];
+        double eflx = p.EFLX[q], eflx_im1_jp1 = p.EFLX[q + P + dm];
+        if (lo) { dflx_im1 = 0.0; cflx = 0.0; eflx = 0.0; }
+        if (hi) { dflx_jp1 = 0.0; cflx_jp1 = 0.0; eflx_im1_jp1 = 0.0; }
+#define U(a, b) p.UWIND[q + (b) * P + (a)]
+#define V(a, b) p.VWIND[q + (b) * P + (a)]
+        const double u = U(0, 0), u_im1 = U(-1, 0), u_ip1 = U(1, 0);
+        double t = 0.0;
+        t = t + (+bflx_im1 * (u_im1 + u) / 2.0 - bflx * (u + u_ip1) / 2.0
+                 + cflx * (U(0, -1) + u) / 2.0 - cflx_jp1 * (u + U(0, 1)) / 2.0
+                 + dflx_im1 * (U(-1, -1) + u) / 2.0 - dflx_jp1 * (u + U(1, 1)) / 2.0
+                 + 1.0 * (+eflx * (U(1, -1) + u) / 2.0 - eflx_im1_jp1 * (u + U(-1, 1)) / 2.0));
+        const double wu_kp1 = p.WWIND_UWIND[q + g.plane];
+        t = t + (wu_k - wu_kp1) / p.dsigma[k];
+        wu_k = wu_kp1;
+        if (TURB) {
+#define PV(a, b, kk) p.PHIVB[q + (size_t)(kk) * g.plane + (b) * P + (a)]
+#define RH(a, b) p.RHO[q + (b) * P + (a)]
+            const double altvb = var_ds(PV(0, 0, 0), PV(-1, 0, 0), PV(0, -1, 0), PV(0, 1, 0), PV(-1, -1, 0), PV(-1, 1, 0), lo, hi) / CON_G;
+            const double altvb_kp1 = var_ds(PV(0, 0, 1), PV(-1, 0, 1), PV(0, -1, 1), PV(0, 1, 1), PV(-1, -1, 1), PV(-1, 1, 1), lo, hi) / CON_G;
+            const double rho_is = var_ds(RH(0, 0), RH(-1, 0), RH(0, -1), RH(0, 1), RH(-1, -1), RH(-1, 1), lo, hi);
+            const double kd = p.KMOM_dUWINDdz[q], kd_kp1 = p.KMOM_dUWINDdz[q + g.plane];
+            double turb;
+            if (k == 0) turb = (0.0 - kd_kp1) / ((altvb - altvb_kp1) * rho_is);
+            else if (k == g.nz - 1) turb = (kd + smom_is) / ((altvb - altvb_kp1) * rho_is);
+            else turb = (kd - kd_kp1) / ((altvb - altvb_kp1) * rho_is);
+            t = t + turb;
+            p.dUFLXdt_TURB[q] = turb;
+#undef PV
+#undef RH
+        }
+        // Coriolis + metric: dyn_UFLX.py:39-66
+        t = t + CON_RE * dlon * dlat / 2.0 *
+                    (colp_im1 * (V(-1, 0) + V(-1, 1)) / 2.0 * (corf * CON_RE * coslat + (u_im1 + u) / 2.0 * sinlat) +
+                     colp * (V(0, 0) + V(0, 1)) / 2.0 * (corf * CON_RE * coslat + (u + u_ip1) / 2.0 * sinlat));
+        const double pvb_kp1 = p.PVTFVB[q + g.plane], pvb_im1_kp1 = p.PVTFVB[q + g.plane - 1];
+        t = t + pre_grad(p.PHI[q], p.PHI[q - 1], colp, colp_im1, p.POTT[q], p.POTT[q - 1],
+                         p.PVTF[q], p.PVTF[q - 1], pvb_k, pvb_im1_k, pvb_im1_kp1, pvb_kp1,
+                         p.dsigma[k], p.sigma_vb[k], p.sigma_vb[k + 1], dyis);
+        pvb_k = pvb_kp1;
+        pvb_im1_k = pvb_im1_kp1;
+        const double dif = p.UVFLX_dif_coef[k];
+        if (dif > 0.0)
+            t = t + dif * (p.UFLX[q - 1] + p.UFLX[q + 1] + p.UFLX[q - P] + p.UFLX[q + P] - 4.0 * p.UFLX[q]);
+        p.dUFLXdt[q] = t;
+#undef U
+#undef V
+    }
+}
+
+// dVFLXdt: dyn_VFLX.py:322-408 and :67-198.  Owned i in [1,nx], js in [2,ny] globally (the
+// pole rows js = 1, nys read NaN halos in the reference and VWIND is zeroed there).
+template <bool TURB>
+__global__ __launch_bounds__(TI *TJ) void k_vflx_tendency(Geo g, Ptrs p, int jlo, int jhi)
+{
+    DYC_IJ(1, 0)
+    const int jj = j + jlo;
+    if (i > g.nx || jj > jhi) return;
+    const int P = g.P;
+    const size_t c = at2(g, i, jj);
+    const int dp = (i == g.nx) ? -(g.nx - 1) : 1;       // offset to the i+1 flux column (dyn_VFLX.py:349-356)
+    const double colp = p.COLP[c], colp_jm1 = p.COLP[c - P];
+    const double corf = p.corf[c], corf_jm1 = p.corf[c - P];
+    const double lat = p.lat_rad[c], lat_jm1 = p.lat_rad[c - P];
+    const double coslat = cos(lat), sinlat = sin(lat), coslat_jm1 = cos(lat_jm1), sinlat_jm1 = sin(lat_jm1);
+    const double dlon = p.dlon_rad[c], dlat = p.dlat_rad[c], dxjs = p.dxjs[c];
+    double smom_js = 0.0;
+    if (TURB)
+        smom_js = var_ds(p.SMOMYFLX[c], p.SMOMYFLX[c - P], p.SMOMYFLX[c - 1], p.SMOMYFLX[c + 1],
+                         p.SMOMYFLX[c - P - 1], p.SMOMYFLX[c - P + 1], false, false);
+    double wv_k = p.WWIND_VWIND[c];
+    double pvb_k = p.PVTFVB[c], pvb_jm1_k = p.PVTFVB[c - P];
+    for (int k = 0; k < g.nz; k++) {
+        const size_t q = c + (size_t)k * g.plane;
+        const double rflx = p.RFLX[q], rflx_jm1 = p.RFLX[q - P];
+        const double qflx = p.QFLX[q], qflx_ip1 = p.QFLX[q + dp];
+        const double sflx_jm1 = p.SFLX[q - P], sflx_ip1 = p.SFLX[q + dp];
+        const double tflx = p.TFLX[q], tflx_ip1_jm1 = p.TFLX[q - P + dp];
+#define U(a, b) p.UWIND[q + (b) * P + (a)]
+#define V(a, b) p.VWIND[q + (b) * P + (a)]
+        const double v = V(0, 0);
+        double t = 0.0;
+        t = t + (+rflx_jm1 * (V(0, -1) + v) / 2.0 - rflx * (v + V(0, 1)) / 2.0
+                 + qflx * (V(-1, 0) + v) / 2.0 - qflx_ip1 * (v + V(1, 0)) / 2.0
+                 + sflx_jm1 * (V(-1, -1) + v) / 2.0 - sflx_ip1 * (v + V(1, 1)) / 2.0
+                 + -1.0 * (+tflx * (V(-1, 1) + v) / 2.0 - tflx_ip1_jm1 * (v + V(1, -1)) / 2.0));
+        const double wv_kp1 = p.WWIND_VWIND[q + g.plane];
+        t = t + (wv_k - wv_kp1) / p.dsigma[k];
+        wv_k = wv_kp1;
+        if (TURB) {
+#define PV(a, b, kk) p.PHIVB[q + (size_t)(kk) * g.plane + (b) * P + (a)]
+#define RH(a, b) p.RHO[q + (b) * P + (a)]
+            const double altvb = var_ds(PV(0, 0, 0), PV(0, -1, 0), PV(-1, 0, 0), PV(1, 0, 0), PV(-1, -1, 0), PV(1, -1, 0), false, false) / CON_G;
+            const double altvb_kp1 = var_ds(PV(0, 0, 1), PV(0, -1, 1), PV(-1, 0, 1), PV(1, 0, 1), PV(-1, -1, 1), PV(1, -1, 1), false, false) / CON_G;
+            const double rho_js = var_ds(RH(0, 0), RH(0, -1), RH(-1, 0), RH(1, 0), RH(-1, -1), RH(1, -1), false, false);
+            const double kd = p.KMOM_dVWINDdz[q], kd_kp1 = p.KMOM_dVWINDdz[q + g.plane];
+            double turb;
+            if (k == 0) turb = (0.0 - kd_kp1) / ((altvb - altvb_kp1) * rho_js);
+            else if (k == g.nz - 1) turb = (kd + smom_js) / ((altvb - altvb_kp1) * rho_js);
+            else turb = (kd - kd_kp1) / ((altvb - altvb_kp1) * rho_js);
+            t = t + turb;
+            p.dVFLXdt_TURB[q] = turb;
+#undef PV
+#undef RH
+        }
+        // Coriolis + metric: dyn_VFLX.py:39-64
+        const double ub_jm1 = (U(0, -1) + U(1, -1)) / 2.0, ub = (U(0, 0) + U(1, 0)) / 2.0;
+        t = t + -CON_RE * dlon * dlat / 2.0 *
+                    (colp_jm1 * ub_jm1 * (corf_jm1 * CON_RE * coslat_jm1 + ub_jm1 * sinlat_jm1) +
+                     colp * ub * (corf * CON_RE * coslat + ub * sinlat));
+        const double pvb_kp1 = p.PVTFVB[q + g.plane], pvb_jm1_kp1 = p.PVTFVB[q + g.plane - P];
+        t = t + pre_grad(p.PHI[q], p.PHI[q - P], colp, colp_jm1, p.POTT[q], p.POTT[q - P],
+                         p.PVTF[q], p.PVTF[q - P], pvb_k, pvb_jm1_k, pvb_jm1_kp1, pvb_kp1,
+                         p.dsigma[k], p.sigma_vb[k], p.sigma_vb[k + 1], dxjs);
+        pvb_k = pvb_kp1;
+        pvb_jm1_k = pvb_jm1_kp1;
+        const double dif = p.UVFLX_dif_coef[k];
+        if (dif > 0.0)
+            t = t + dif * (p.VFLX[q - 1] + p.VFLX[q + 1] + p.VFLX[q - P] + p.VFLX[q + P] - 4.0 * p.VFLX[q]);
+        p.dVFLXdt[q] = t;
+#undef U
+#undef V
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// dPOTTdt: dyn_POTT.py:180-216 and :55-110.  Owned i in [1,nx], j in [1,ny].
+template <bool TURB>
+__global__ __launch_bounds__(TI *TJ) void k_pott_tendency(Geo g, Ptrs p)
+{
+    DYC_IJ(1, 1)
+    if (i > g.nx || j > g.ny) return;
+    const int P = g.P;
+    const size_t c = at2(g, i, j);
+    const double colp = p.COLP[c], colp_new = p.COLP_NEW[c];
+    const double c_im1 = p.COLP[c - 1], c_ip1 = p.COLP[c + 1], c_jm1 = p.COLP[c - P], c_jp1 = p.COLP[c + P];
+    const double area = p.A[c];
+    double surf = 0.0;
+    if (TURB) surf = p.SSHFLX[c] / CON_CP;
+    double w_k = 0.0, pvb_k = 0.0;     // k = 0: first term omitted (dyn_functions.py:124-127)
+    double pott_km1 = 0.0, phi_km1 = 0.0;
+    for (int k = 0; k < g.nz; k++) {
+        const size_t q = c + (size_t)k * g.plane;
+        const double pt = p.POTT[q];
+        const double p_im1 = p.POTT[q - 1], p_ip1 = p.POTT[q + 1], p_jm1 = p.POTT[q - P], p_jp1 = p.POTT[q + P];
+        double t = 0.0;
+        t = t + (+p.UFLX[q] * (p_im1 + pt) / 2.0 - p.UFLX[q + 1] * (pt + p_ip1) / 2.0
+                 + p.VFLX[q] * (p_jm1 + pt) / 2.0 - p.VFLX[q + P] * (pt + p_jp1) / 2.0) / area;
+        const double w_kp1 = p.WWIND[q + g.plane], pvb_kp1 = p.POTTVB[q + g.plane];
+        if (k == 0) t = t + colp_new * (-w_kp1 * pvb_kp1) / p.dsigma[k];
+        else t = t + colp_new * (+w_k * pvb_k - w_kp1 * pvb_kp1) / p.dsigma[k];
+        w_k = w_kp1;
+        pvb_k = pvb_kp1;
+        if (TURB) {   // dyn_functions.py:26-67
+            const double phi = p.PHI[q];
+            const double alt = phi / CON_G;
+            const double altvb = p.PHIVB[q] / CON_G, altvb_kp1 = p.PHIVB[q + g.plane] / CON_G;
+            const double rho = p.RHO[q];
+            double turb;
+            if (k == 0) {
+                const double alt_kp1 = p.PHI[q + g.plane] / CON_G;
+                turb = colp * ((0.0 - ((pt - p.POTT[q + g.plane]) / (alt - alt_kp1) * p.RHOVB[q + g.plane] * p.KHEAT[q + g.plane])) /
+                               ((altvb - altvb_kp1) * rho));
+            } else if (k == g.nz - 1) {
+                const double alt_km1 = phi_km1 / CON_G;
+                turb = colp * ((((pott_km1 - pt) / (alt_km1 - alt) * p.RHOVB[q] * p.KHEAT[q]) + surf) /
+                               ((altvb - altvb_kp1) * rho));
+            } else {
+                const double alt_kp1 = p.PHI[q + g.plane] / CON_G, alt_km1 = phi_km1 / CON_G;
+                turb = colp * ((((pott_km1 - pt) / (alt_km1 - alt) * p.RHOVB[q] * p.KHEAT[q])
+                                - ((pt - p.POTT[q + g.plane]) / (alt - alt_kp1) * p.RHOVB[q + g.plane] * p.KHEAT[q + g.plane])) /
+                               ((altvb - altvb_kp1) * rho));
+            }
+            t = t + turb;
+            p.dPOTTdt_TURB[q] = turb / colp * 3600.0;
+            phi_km1 = phi;
+        }
+        pott_km1 = pt;
+        const double dif = p.POTT_dif_coef[k];
+        if (dif > 0.0)
+            t = t + dif * (c_im1 * p_im1 + c_ip1 * p_ip1 + c_jm1 * p_jm1 + c_jp1 * p_jp1 - 4.0 * colp * pt);
+        if (g.i_rad) t = t + p.dPOTTdt_RAD[q] * colp;
+        p.dPOTTdt[q] = t;
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// Euler forward with pressure weighting: dyn_timestep.py:212-297 (+ exchange_BC of POTT,
+// VWIND, UWIND: dyn_org_discretizations.py:388-390).  Threads cover i in [1,nx],
+// j in [1,ny+1]; U and POTT own rows 1..ny, V owns js rows not on a pole.
+// `cur` pointers are the fields being written (UWIND, VWIND, POTT); *_OLD and the
+// tendencies are read at the same cell only, so writing in place is race-free.
+__global__ __launch_bounds__(TI *TJ) void k_euler_forward(Geo g, Ptrs p, double dt)
+{
+    DYC_IJ(1, 1)
+    if (i > g.nx || j > g.ny + 1) return;
+    const int P = g.P;
+    const size_t c = at2(g, i, j);
+    const int jg = j + g.joff;
+#define CN(a, b) (p.COLP[c + (b) * P + (a)] * p.A[c + (b) * P + (a)])
+#define CO(a, b) (p.COLP_OLD[c + (b) * P + (a)] * p.A[c + (b) * P + (a)])
+#define CN2(a, b) (2.0 * p.COLP[c + (b) * P + (a)] * p.A[c + (b) * P + (a)])
+#define CO2(a, b) (2.0 * p.COLP_OLD[c + (b) * P + (a)] * p.A[c + (b) * P + (a)])
+    const bool row_c = (j <= g.ny);
+    const bool v_pole = (jg == 1) || (jg == g.ny_global + 1);
+    const bool v_own = row_c || g.pole_n;   // js = ny+1 belongs to the northern neighbour band
+    double ca_is = 1.0, cao_is = 1.0, ca_js = 1.0, cao_js = 1.0, cn = 1.0, co = 1.0;
+    if (row_c) {
+        if (jg == 1) {
+            ca_is = 1.0 / 4.0 * (CN(-1, 1) + CN(0, 1) + CN(-1, 0) + CN(0, 0));
+            cao_is = 1.0 / 4.0 * (CO(-1, 1) + CO(0, 1) + CO(-1, 0) + CO(0, 0));
+        } else if (jg == g.ny_global) {
+            ca_is = 1.0 / 4.0 * (CN(-1, -1) + CN(0, -1) + CN(-1, 0) + CN(0, 0));
+            cao_is = 1.0 / 4.0 * (CO(-1, -1) + CO(0, -1) + CO(-1, 0) + CO(0, 0));
+        } else {
+            ca_is = 1.0 / 8.0 * (CN(-1, 1) + CN(0, 1) + CN2(-1, 0) + CN2(0, 0) + CN(-1, -1) + CN(0, -1));
+            cao_is = 1.0 / 8.0 * (CO(-1, 1) + CO(0, 1) + CO2(-1, 0) + CO2(0, 0) + CO(-1, -1) + CO(0, -1));
+        }
+        cn = p.COLP[c];
+        co = p.COLP_OLD[c];
+    }
+    if (!v_pole) {
+        ca_js = 1.0 / 8.0 * (CN(1, -1) + CN(1, 0) + CN2(0, -1) + CN2(0, 0) + CN(-1, -1) + CN(-1, 0));
+        cao_js = 1.0 / 8.0 * (CO(1, -1) + CO(1, 0) + CO2(0, -1) + CO2(0, 0) + CO(-1, -1) + CO(-1, 0));
+    }
+#undef CN
+#undef CO
+#undef CN2
+#undef CO2
+    for (int k = 0; k < g.nz; k++) {
+        const size_t q = c + (size_t)k * g.plane;
+        if (row_c) {
+            put_c(p.UWIND, g, i, j, k, p.UWIND_OLD[q] * cao_is / ca_is + dt * p.dUFLXdt[q] / ca_is, 1);
+            put_c(p.POTT, g, i, j, k, p.POTT_OLD[q] * co / cn + dt * p.dPOTTdt[q] / cn, 0);
+        }
+        if (v_own) {
+            if (!v_pole) put_s(p.VWIND, g, i, j, k, p.VWIND_OLD[q] * cao_js / ca_js + dt * p.dVFLXdt[q] / ca_js);
+            else put_s(p.VWIND, g, i, j, k, 0.0);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// primary diagnostics: dyn_diagnostics.py:139-195 (diag_PVTF, diag_PHI, diag_POTTVB) in one
+// bottom-up sweep over the whole array incl. halos (i in [0,nx+1], j in [0,ny+1]).
+// One pow() per interface instead of the reference's two per cell: PVTFVB[k+1] is carried.
+__global__ __launch_bounds__(TI *TJ) void k_primary_diag(Geo g, Ptrs p)
+{
+    DYC_IJ(0, 0)
+    if (i > g.nx + 1 || j > g.ny + 1) return;
+    const size_t c = at2(g, i, j);
+    const int nz = g.nz;
+    const double colp = p.COLP[c];
+    double p_kp12 = g.pair_top + p.sigma_vb[nz] * colp;
+    double pvb_kp1 = pow(p_kp12 / 100000.0, CON_KAPPA);
+    double phivb_kp1 = p.HSURF[c] * CON_G;
+    p.PVTFVB[c + (size_t)nz * g.plane] = pvb_kp1;
+    p.PHIVB[c + (size_t)nz * g.plane] = phivb_kp1;
+    double pott_kp1 = 0.0, pvtf_kp1 = 0.0, pottvb_first = 0.0;
+    for (int k = nz - 1; k >= 0; k--) {
+        const size_t q = c + (size_t)k * g.plane;
+        const double p_km12 = g.pair_top + p.sigma_vb[k] * colp;
+        const double pvb_k = pow(p_km12 / 100000.0, CON_KAPPA);
+        const double pvtf = 1.0 / (1.0 + CON_KAPPA) * (pvb_kp1 * p_kp12 - pvb_k * p_km12) / (p_kp12 - p_km12);
+        const double pott = p.POTT[q];
+        const double phi = phivb_kp1 - CON_CP * (pott * (pvtf - pvb_kp1));
+        const double phivb = phi - CON_CP * (pott * (pvb_k - pvtf));
+        p.PVTF[q] = pvtf;
+        p.PVTFVB[q] = pvb_k;
+        p.PHI[q] = phi;
+        p.PHIVB[q] = phivb;
+        if (k < nz - 1) {   // interface k+1 between levels k and k+1
+            const double vb = ((pvb_kp1 - pvtf) * pott + (pvtf_kp1 - pvb_kp1) * pott_kp1) / (pvtf_kp1 - pvtf);
+            p.POTTVB[q + g.plane] = vb;
+            if (k == nz - 2 && nz > 2)   // surface extrapolation (elif branch, dyn_diagnostics.py:191-194)
+                p.POTTVB[c + (size_t)nz * g.plane] = pott_kp1 - (vb - pott_kp1);
+            if (k == 0) pottvb_first = vb;
+        }
+        p_kp12 = p_km12;
+        pvb_kp1 = pvb_k;
+        phivb_kp1 = phivb;
+        pott_kp1 = pott;
+        pvtf_kp1 = pvtf;
+    }
+    if (nz >= 2) p.POTTVB[c] = pott_kp1 - (pottvb_first - pott_kp1);   // model top, :187-190
+}
+
+// secondary diagnostics, RHO / RHOVB only: dyn_diagnostics.py:199-222
+__global__ __launch_bounds__(TI *TJ) void k_diag_rho(Geo g, Ptrs p)
+{
+    DYC_IJ(0, 0)
+    if (i > g.nx + 1 || j > g.ny + 1) return;
+    const size_t c = at2(g, i, j);
+    for (int k = 0; k <= g.nz; k++) {
+        const size_t q = c + (size_t)k * g.plane;
+        const double pvb = p.PVTFVB[q];
+        p.RHOVB[q] = 100000.0 * pow(pvb, 1.0 / CON_KAPPA) / (CON_RD * (p.POTTVB[q] * pvb));
+        if (k < g.nz) {
+            const double pv = p.PVTF[q];
+            p.RHO[q] = 100000.0 * pow(pv, 1.0 / CON_KAPPA) / (CON_RD * (p.POTT[q] * pv));
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// lateral boundary conditions of one field: misc_boundaries.py:47-82.  Every halo cell
+// pulls from the interior cell it mirrors, so one pass suffices (corners included).
+__global__ void k_exchange_bc(Geo g, double *F, int stgx, int stgy, int nk)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int j = blockIdx.y;
+    const int k = blockIdx.z;
+    const int fnx = g.nx + 2 + stgx, fny = g.ny + 2 + stgy;
+    if (i >= fnx || j >= fny || k >= nk) return;
+    int si = i;
+    if (i == 0) si = g.nx;
+    else if (i == g.nx + 1) si = 1;
+    else if (stgx && i == g.nx + 2) si = 2;
+    double *pl = F + (size_t)k * g.plane;
+    if (stgy) {
+        const bool zero = (g.pole_s && j <= 1) || (g.pole_n && j >= g.ny + 1);
+        if (zero) pl[(size_t)j * g.P + i] = 0.0;
+        else if (si != i) pl[(size_t)j * g.P + i] = pl[(size_t)j * g.P + si];
+    } else {
+        int sj = j;
+        if (j == 0 && g.pole_s) sj = 1;
+        else if (j == g.ny + 1 && g.pole_n) sj = g.ny;
+        if (si != i || sj != j) pl[(size_t)j * g.P + i] = pl[(size_t)sj * g.P + si];
+    }
+}
+
+// ---- layout adaptor: host [i][j][k] (k contiguous) <-> device [k][j][i] ---------------
+// One workgroup transposes a 32(i) x 32(k) tile of row j through LDS, so both the read
+// and the write side are contiguous.
+__global__ void k_to_device(Geo g, const double *__restrict__ src, double *__restrict__ dst,
+                            int n0, int n1, int n2)
+{
+    __shared__ double tile[32][33];
+    const int j = blockIdx.z;
+    const int i0 = blockIdx.x * 32, k0 = blockIdx.y * 32;
+    for (int r = threadIdx.y; r < 32; r += blockDim.y) {
+        const int i = i0 + r, k = k0 + threadIdx.x;
+        if (i < n0 && k < n2) tile[r][threadIdx.x] = src[((size_t)i * n1 + j) * n2 + k];
+    }
+    __syncthreads();
+    for (int r = threadIdx.y; r < 32; r += blockDim.y) {
+        const int k = k0 + r, i = i0 + threadIdx.x;
+        if (i < n0 && k < n2) dst[(size_t)k * g.plane + (size_t)j * g.P + i] = tile[threadIdx.x][r];
+    }
+}
+__global__ void k_to_host(Geo g, const double *__restrict__ src, double *__restrict__ dst,
+                          int n0, int n1, int n2)
+{
+    __shared__ double tile[32][33];
+    const int j = blockIdx.z;
+    const int i0 = blockIdx.x * 32, k0 = blockIdx.y * 32;
+    for (int r = threadIdx.y; r < 32; r += blockDim.y) {
+        const int k = k0 + r, i = i0 + threadIdx.x;
+        if (i < n0 && k < n2) tile[r][threadIdx.x] = src[(size_t)k * g.plane + (size_t)j * g.P + i];
+    }
+    __syncthreads();
+    for (int r = threadIdx.y; r < 32; r += blockDim.y) {
+        const int i = i0 + r, k = k0 + threadIdx.x;
+        if (i < n0 && k < n2) dst[((size_t)i * n1 + j) * n2 + k] = tile[threadIdx.x][r];
+    }
+}
+__global__ void k_fill(double *dst, size_t n, double v)
+{
+    for (size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x; t < n; t += (size_t)gridDim.x * blockDim.x)
+        dst[t] = v;
+}
+
+}  // namespace dyc

@@ -83,10 +83,32 @@ def field_shape(name, nx, ny, nz, nb=1):
     return (nx + 2 * nb + stgx, ny + 2 * nb + stgy, nk)
 
 
+class _LazyHostFields(dict):
+    """name -> NaN-filled host array (main_fields.py:477-485), allocated on first access:
+    at 0.25 deg x 64 levels the full set is 24 GB, of which a driver touches a handful."""
+
+    def __init__(self, nx, ny, nz, dtype):
+        super().__init__()
+        self._ext = (nx, ny, nz)
+        self._dtype = dtype
+
+    def __missing__(self, name):
+        if name not in FIELD_TABLE:
+            raise KeyError(name)
+        a = np.full(field_shape(name, *self._ext), np.nan, dtype=self._dtype)
+        self[name] = a
+        return a
+
+    def get(self, name, default=None):
+        return self[name] if name in FIELD_TABLE else default
+
+    def keys(self):
+        return FIELD_TABLE.keys()
+
+
 def allocate_fields(nx, ny, nz, dtype=np.float64):
-    """NaN-filled host arrays for every hot-path field (main_fields.py:477-485)."""
-    return OrderedDict((name, np.full(field_shape(name, nx, ny, nz), np.nan, dtype=dtype))
-                       for name in FIELD_TABLE)
+    """Host arrays for every hot-path field, NaN-initialised like the reference's."""
+    return _LazyHostFields(nx, ny, nz, dtype)
 
 
 class DeviceField:
@@ -128,7 +150,7 @@ class ModelFields:
 
     def attach(self, core):
         self.core = core
-        self.device = {name: DeviceField(name, core) for name in self.host}
+        self.device = {name: DeviceField(name, core) for name in FIELD_TABLE}
         for name in PASS_THROUGH_FIELDS:
             self.device[name] = None
 
@@ -142,8 +164,12 @@ class ModelFields:
             dst[name] = field
 
     def copy_host_to_device(self, GR=None, field_group=ALL_FIELDS):
+        """Upload a field group.  Device buffers are NaN-filled at creation like the host
+        arrays, so fields whose host copy was never touched need no transfer."""
         names = self.field_groups.get(field_group, field_group)
         for name in names:
+            if field_group == self.ALL_FIELDS and not dict.__contains__(self.host, name):
+                continue
             self.core.upload(name, self.host[name])
 
     def copy_device_to_host(self, GR=None, field_group=ALL_FIELDS):

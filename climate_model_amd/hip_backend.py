@@ -1,0 +1,215 @@
+"""ctypes binding of libdycore_hip.so (C ABI: include/dycore.h).
+
+This is the only compute backend of the package.  There is no CPU fallback: if the
+shared library is missing or no MI355X is visible, construction raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'csrc', 'libdycore_hip.so')
+ABI_VERSION = 1
+
+
+class DycoreError(RuntimeError):
+    pass
+
+
+class DycoreConfig(C.Structure):
+    _fields_ = [('abi_version', C.c_int32), ('nx', C.c_int32), ('ny', C.c_int32), ('nz', C.c_int32),
+                ('ny_global', C.c_int32), ('j_offset', C.c_int32), ('device', C.c_int32),
+                ('i_turb', C.c_int32), ('i_radiation', C.c_int32), ('reserved', C.c_int32 * 7),
+                ('pair_top', C.c_double), ('stream', C.c_void_p)]
+
+
+# every symbol include/dycore.h declares (tests check the library exports all of them)
+ABI_SYMBOLS = [
+    'dycore_create', 'dycore_destroy', 'dycore_last_error', 'dycore_abi_version', 'dycore_sync',
+    'dycore_set_grid', 'dycore_field_shape', 'dycore_upload', 'dycore_download', 'dycore_field_ptr',
+    'dycore_copy_field', 'dycore_exchange_bc',
+    'dycore_continuity', 'dycore_momentum', 'dycore_momentum_prepare', 'dycore_uflx_tendency',
+    'dycore_vflx_tendency', 'dycore_pott_tendency', 'dycore_euler_forward', 'dycore_primary_diag',
+    'dycore_secondary_diag_rho', 'dycore_step_matsuno', 'dycore_time_steps',
+    'dycore_profile', 'dycore_n_kernels', 'dycore_kernel_stats',
+]
+
+_lib = None
+
+
+def load_library(path=None):
+    """Load libdycore_hip.so and declare its prototypes.  Raises if it is absent."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    path = path or LIB_PATH
+    if not os.path.exists(path):
+        raise DycoreError('HIP extension not built: %s is missing (run __graft_entry__.build() '
+                          'or `make -C climate_model_amd/csrc`); there is no CPU fallback' % path)
+    lib = C.CDLL(path)
+    hp = C.c_void_p
+    dp = C.POINTER(C.c_double)
+    lib.dycore_last_error.restype = C.c_char_p
+    lib.dycore_create.argtypes = [C.POINTER(DycoreConfig), C.POINTER(hp)]
+    lib.dycore_destroy.argtypes = [hp]
+    lib.dycore_sync.argtypes = [hp]
+    lib.dycore_set_grid.argtypes = [hp, C.c_char_p, dp, C.c_int32, C.c_int32, C.c_int32]
+    lib.dycore_field_shape.argtypes = [hp, C.c_char_p, C.POINTER(C.c_int32 * 3)]
+    lib.dycore_upload.argtypes = [hp, C.c_char_p, dp]
+    lib.dycore_download.argtypes = [hp, C.c_char_p, dp]
+    lib.dycore_field_ptr.argtypes = [hp, C.c_char_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int64),
+                                     C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+    lib.dycore_copy_field.argtypes = [hp, C.c_char_p, C.c_char_p]
+    lib.dycore_exchange_bc.argtypes = [hp, C.c_char_p]
+    for n in ('dycore_continuity', 'dycore_euler_forward'):
+        getattr(lib, n).argtypes = [hp, C.c_double]
+    for n in ('dycore_momentum', 'dycore_momentum_prepare', 'dycore_uflx_tendency',
+              'dycore_vflx_tendency', 'dycore_pott_tendency', 'dycore_primary_diag',
+              'dycore_secondary_diag_rho'):
+        getattr(lib, n).argtypes = [hp]
+    lib.dycore_step_matsuno.argtypes = [hp, C.c_double, C.c_int32, C.c_int32]
+    lib.dycore_time_steps.argtypes = [hp, C.c_double, C.c_int32, C.c_int32, C.POINTER(C.c_double)]
+    lib.dycore_profile.argtypes = [hp, C.c_int32]
+    lib.dycore_kernel_stats.argtypes = [hp, C.c_int32, C.POINTER(C.c_char_p), C.POINTER(C.c_int64),
+                                        C.POINTER(C.c_double)]
+    if lib.dycore_abi_version() != ABI_VERSION:
+        raise DycoreError('libdycore_hip.so ABI %d != binding ABI %d' % (lib.dycore_abi_version(), ABI_VERSION))
+    if path == LIB_PATH:
+        _lib = lib
+    return lib
+
+
+GRID_ARRAYS = ['A', 'dxjs', 'dyis', 'corf', 'corf_is', 'lat_rad', 'lat_is_rad', 'dlon_rad',
+               'dlat_rad', 'sigma_vb', 'dsigma', 'UVFLX_dif_coef', 'POTT_dif_coef']
+
+
+class HipDycore:
+    """One dycore handle = one GPU (or one latitude band of a decomposed grid)."""
+
+    def __init__(self, nx, ny, nz, pair_top=10000., i_turb=0, i_radiation=0, device=0,
+                 ny_global=None, j_offset=0, stream=None):
+        self.lib = load_library()
+        self.nx, self.ny, self.nz = int(nx), int(ny), int(nz)
+        cfg = DycoreConfig()
+        cfg.abi_version = ABI_VERSION
+        cfg.nx, cfg.ny, cfg.nz = self.nx, self.ny, self.nz
+        cfg.ny_global = int(ny_global if ny_global is not None else ny)
+        cfg.j_offset = int(j_offset)
+        cfg.device = int(device)
+        cfg.i_turb = int(bool(i_turb))
+        cfg.i_radiation = int(bool(i_radiation))
+        cfg.pair_top = float(pair_top)
+        cfg.stream = C.c_void_p(stream) if stream else None
+        self._h = C.c_void_p()
+        self._check(self.lib.dycore_create(C.byref(cfg), C.byref(self._h)))
+        self.i_turb = bool(i_turb)
+
+    # ---- plumbing ----
+    def _check(self, rc):
+        if rc != 0:
+            raise DycoreError('libdycore_hip: %s (code %d)' % (self.lib.dycore_last_error().decode(), rc))
+
+    def close(self):
+        if getattr(self, '_h', None) and self._h.value:
+            self.lib.dycore_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def sync(self):
+        self._check(self.lib.dycore_sync(self._h))
+
+    # ---- grid constants / fields ----
+    def set_grid(self, GRF):
+        for name in GRID_ARRAYS:
+            a = np.ascontiguousarray(np.asarray(GRF[name], dtype=np.float64))
+            shp = a.shape if a.ndim == 3 else (a.size, 1, 1)
+            self._check(self.lib.dycore_set_grid(self._h, name.encode(), a.ctypes.data_as(C.POINTER(C.c_double)),
+                                                 shp[0], shp[1], shp[2]))
+
+    def field_shape(self, name):
+        s = (C.c_int32 * 3)()
+        self._check(self.lib.dycore_field_shape(self._h, name.encode(), C.byref(s)))
+        return tuple(s)
+
+    def upload(self, name, host):
+        a = np.ascontiguousarray(np.asarray(host, dtype=np.float64))
+        if a.shape != self.field_shape(name):
+            raise DycoreError('upload(%s): host shape %s != %s' % (name, a.shape, self.field_shape(name)))
+        self._check(self.lib.dycore_upload(self._h, name.encode(), a.ctypes.data_as(C.POINTER(C.c_double))))
+
+    def download(self, name, out=None):
+        shp = self.field_shape(name)
+        if out is None:
+            out = np.empty(shp, dtype=np.float64)
+        if out.shape != shp or out.dtype != np.float64 or not out.flags.c_contiguous:
+            raise DycoreError('download(%s): need a C-contiguous float64 array of shape %s' % (name, shp))
+        self._check(self.lib.dycore_download(self._h, name.encode(), out.ctypes.data_as(C.POINTER(C.c_double))))
+        return out
+
+    def field_ptr(self, name):
+        dev, pitch, rows, lev = C.c_void_p(), C.c_int64(), C.c_int64(), C.c_int64()
+        self._check(self.lib.dycore_field_ptr(self._h, name.encode(), C.byref(dev), C.byref(pitch),
+                                              C.byref(rows), C.byref(lev)))
+        return dev.value, pitch.value, rows.value, lev.value
+
+    def copy_field(self, dst, src):
+        self._check(self.lib.dycore_copy_field(self._h, dst.encode(), src.encode()))
+
+    def exchange_bc(self, name):
+        self._check(self.lib.dycore_exchange_bc(self._h, name.encode()))
+
+    # ---- stages ----
+    def continuity(self, dt):
+        self._check(self.lib.dycore_continuity(self._h, float(dt)))
+
+    def momentum(self):
+        self._check(self.lib.dycore_momentum(self._h))
+
+    def momentum_prepare(self):
+        self._check(self.lib.dycore_momentum_prepare(self._h))
+
+    def uflx_tendency(self):
+        self._check(self.lib.dycore_uflx_tendency(self._h))
+
+    def vflx_tendency(self):
+        self._check(self.lib.dycore_vflx_tendency(self._h))
+
+    def pott_tendency(self):
+        self._check(self.lib.dycore_pott_tendency(self._h))
+
+    def euler_forward(self, dt):
+        self._check(self.lib.dycore_euler_forward(self._h, float(dt)))
+
+    def primary_diag(self):
+        self._check(self.lib.dycore_primary_diag(self._h))
+
+    def secondary_diag_rho(self):
+        self._check(self.lib.dycore_secondary_diag_rho(self._h))
+
+    def step_matsuno(self, dt, nsteps=1, with_rho=None):
+        with_rho = self.i_turb if with_rho is None else with_rho
+        self._check(self.lib.dycore_step_matsuno(self._h, float(dt), int(nsteps), int(bool(with_rho))))
+
+    # ---- measurement ----
+    def time_steps(self, dt, nsteps, with_rho=None):
+        with_rho = self.i_turb if with_rho is None else with_rho
+        ms = C.c_double()
+        self._check(self.lib.dycore_time_steps(self._h, float(dt), int(nsteps), int(bool(with_rho)), C.byref(ms)))
+        return ms.value
+
+    def profile(self, enable=True):
+        self._check(self.lib.dycore_profile(self._h, int(bool(enable))))
+
+    def kernel_stats(self):
+        out = {}
+        for idx in range(self.lib.dycore_n_kernels()):
+            name, n, ms = C.c_char_p(), C.c_int64(), C.c_double()
+            self._check(self.lib.dycore_kernel_stats(self._h, idx, C.byref(name), C.byref(n), C.byref(ms)))
+            out[name.value.decode()] = (n.value, ms.value)
+        return out

@@ -1,0 +1,65 @@
+"""Run configuration of the dycore hot path.
+
+The reference keeps its configuration as module globals of `namelist.py` that
+numba freezes into the kernels (namelist.py:30-316, io_read_namelist.py:30-92).
+Here the same names live on a `Namelist` object that is handed to `Grid`; the
+values that reach the device travel in `DycoreConfig` (include/dycore.h).
+Only the entries the Matsuno step uses are kept.
+"""
+from dataclasses import dataclass
+
+
+# namelist.py:286-316: UVFLX diffusion coefficient by resolution, then doubled
+_UVFLX_DIF_TABLE = {10: 1.5, 8: 1.5, 6: 1.8, 5: 2, 4: 2.5, 3: 3.3, 2: 5, 1.5: 7.5}
+
+
+def uvflx_dif_coef_for(dlat_deg):
+    if dlat_deg in _UVFLX_DIF_TABLE:
+        c = _UVFLX_DIF_TABLE[dlat_deg]
+    elif dlat_deg <= 1:
+        c = 10
+    else:
+        c = 0
+    return c * 2.0
+
+
+@dataclass
+class Namelist:
+    # grid (namelist.py:30-40, 243-278)
+    nz: int = 32
+    nb: int = 1
+    lon0_deg: float = 0.
+    lon1_deg: float = 360.
+    lat0_deg: float = -90.
+    lat1_deg: float = 90.
+    dlat_deg: float = 1.0
+    dlon_deg: float = 1.0
+    pair_top: float = 10000.
+    # dynamics switches (namelist.py:62-88).  The dry dycore runs with the
+    # turbulence/radiation couplings off (their inputs are identically zero).
+    i_UVFLX_vert_turb: int = 0
+    i_POTT_vert_turb: int = 0
+    i_POTT_radiation: int = 0
+    # diffusion (namelist.py:281-316); None = table value for dlat_deg
+    UVFLX_dif_coef: float = None
+    POTT_dif_coef: float = 1E-5
+    # time stepping (namelist.py:219-221)
+    CFL: float = 0.7
+    dt: float = None            # None = reference rule int(CFL*min(dx)/400)
+    working_precision: str = 'float64'
+
+    def __post_init__(self):
+        if self.nb != 1:
+            raise NotImplementedError('nb > 1 not implemented (io_read_namelist.py:30-31)')
+        if self.lon0_deg != 0 or self.lon1_deg != 360:
+            raise NotImplementedError('only periodic longitude 0..360 (io_read_namelist.py:32-34)')
+        if self.working_precision != 'float64':
+            raise NotImplementedError('the HIP dycore computes in float64')
+        if bool(self.i_UVFLX_vert_turb) != bool(self.i_POTT_vert_turb):
+            raise NotImplementedError('i_UVFLX_vert_turb and i_POTT_vert_turb must agree')
+        if self.UVFLX_dif_coef is None:
+            self.UVFLX_dif_coef = uvflx_dif_coef_for(self.dlat_deg)
+
+    @property
+    def i_turb(self):
+        return int(bool(self.i_UVFLX_vert_turb))

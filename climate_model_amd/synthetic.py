@@ -1,0 +1,56 @@
+"""Deterministic, file-free initial state for benchmarks and property tests.
+
+Recipe of SURVEY.md 8(d): Gaussian-hill topography, hydrostatic column pressure,
+isothermal (288 K) potential-temperature profile, the reference's Gaussian wind bump
+(io_initial_conditions.py:67-78: 10 m/s at lon 135 deg / lat 0, sigma = pi/10, scaled by
+sqrt(1-(k+1)/nz)) plus seeded uniform noise so that no field is constant.  The
+physics-produced inputs (KMOM, KHEAT, surface fluxes) stay zero: dry dycore.
+"""
+import numpy as np
+
+from .constants import con_kappa
+from .grid import exchange_BC_host
+
+
+def _gauss(lon, lat, lon0, lat0, slon, slat):
+    return np.exp(-(lon - lon0) ** 2 / (2 * slon ** 2) - (lat - lat0) ** 2 / (2 * slat ** 2))
+
+
+def initialize_fields(GR, F, seed=3, noise_wind=0.1, noise_pott=0.1):
+    """Fill F.host with the synthetic state (in place) and apply the lateral BCs."""
+    nx, ny, nz = GR.nx, GR.ny, GR.nz
+    rng = np.random.default_rng(seed)
+    ii, jj, iis, jjs = GR.ii, GR.jj, GR.iis, GR.jjs
+    pair_top = GR.nl.pair_top
+    h = F.host
+
+    lon, lat = GR.lon_rad[ii, jj, 0], GR.lat_rad[ii, jj, 0]
+    hs = (3000. * _gauss(lon, lat, np.pi * 0.5, 0.6, 0.35, 0.25) +
+          1500. * _gauss(lon, lat, np.pi * 1.4, -0.4, 0.5, 0.3) +
+          500. * _gauss(lon, lat, np.pi * 1.9, 0.9, 0.3, 0.2))
+    h['HSURF'][ii, jj, 0] = hs
+    exchange_BC_host(h['HSURF'], nx, ny)
+    h['COLP'][ii, jj, 0] = 101325. * np.exp(-hs / 8000.) - pair_top
+    exchange_BC_host(h['COLP'], nx, ny)
+
+    sig = GR.sigma_vb.reshape(-1)
+    sig_mid = 0.5 * (sig[:-1] + sig[1:])
+    bump_u = 10. * _gauss(GR.lon_is_rad[iis, jj, 0], GR.lat_is_rad[iis, jj, 0], np.pi * 3 / 4, 0., np.pi / 10, np.pi / 10)
+    bump_v = 10. * _gauss(GR.lon_js_rad[ii, jjs, 0], GR.lat_js_rad[ii, jjs, 0], np.pi * 3 / 4, 0., np.pi / 10, np.pi / 10)
+    colp = h['COLP'][ii, jj, 0]
+    for k in range(nz):
+        vert = (1 - (k + 1) / nz) ** 0.5
+        h['UWIND'][iis, jj, k] = bump_u * vert + noise_wind * rng.uniform(-1, 1, bump_u.shape)
+        h['VWIND'][ii, jjs, k] = bump_v * vert + noise_wind * rng.uniform(-1, 1, bump_v.shape)
+        p_mid = pair_top + sig_mid[k] * colp
+        h['POTT'][ii, jj, k] = 288. * (100000. / p_mid) ** con_kappa + noise_pott * rng.uniform(-1, 1, colp.shape)
+    for n in ('UWIND', 'VWIND', 'POTT'):
+        exchange_BC_host(h[n], nx, ny)
+    # x-staggered arrays carry one more periodic column than Grid.exchange_BC fills
+    h['UWIND'][nx + 2] = h['UWIND'][2]
+    return F
+
+
+def stable_dt(GR, safety=0.5):
+    """A CFL-safe time step for grids where the reference's int() rule gives 0."""
+    return safety * GR.nl.CFL * float(np.nanmin(GR.dx)) / 400.

@@ -1,0 +1,133 @@
+/*
+ * dycore.h -- C ABI of libdycore_hip.so, the MI355X (gfx950) implementation of the
+ * hydrostatic dynamical-core Matsuno time step.
+ *
+ * This is the drop-in boundary for the hot path of Potopoles/Climate_Model.  The
+ * reference has no FFI of its own: the path sits behind the three factory classes
+ * of dyn_org_discretizations.py, which dispatch to numba CPU/CUDA kernels.  Each
+ * entry point below names the reference interface it replaces (file:line relative
+ * to the reference tree).  The Python classes in climate_model_amd/ bind these
+ * symbols with ctypes and reproduce the factories' method names and `fields_*`
+ * lists; INTEGRATION.md shows the stub a maintainer of the reference would add.
+ *
+ * Conventions
+ *  - plain C: opaque handle, POD config struct, raw pointers and sizes; every
+ *    function returns 0 on success or a DYCORE_E* code and never throws;
+ *    dycore_last_error() gives the message for the calling thread's last failure.
+ *  - host arrays cross the boundary in the reference's layout: C-order [i][j][k],
+ *    k contiguous, halo nb = 1, shapes as in main_fields.py:477-485
+ *    (nx+2+stgx, ny+2+stgy, nz | nz+1 | 1).  Device storage is [k][j][i] with a
+ *    padded i-pitch; dycore_upload/_download convert on the device.
+ *  - fields are addressed by the reference's names ("UWIND", "COLP_NEW", ...).
+ *  - all work of one handle is issued on one HIP stream; calls return without
+ *    synchronising unless documented (download, sync).
+ *  - one handle per GPU / per latitude band; a handle is not thread-safe, distinct
+ *    handles are independent.
+ */
+#ifndef DYCORE_H
+#define DYCORE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DYCORE_ABI_VERSION 1
+
+enum {
+    DYCORE_OK = 0,
+    DYCORE_EINVAL = 1,     /* bad argument / unknown field name / shape mismatch */
+    DYCORE_EHIP = 2,       /* a HIP runtime call failed                           */
+    DYCORE_ENOMEM = 3,
+    DYCORE_ESTATE = 4      /* call not valid in the handle's current state       */
+};
+
+typedef struct dycore dycore_t;
+
+/* Replaces the module-level globals the reference freezes into its kernels:
+ * main_grid.py:42-51 (extents), namelist.py:62-88 (switches), pair_top. */
+typedef struct DycoreConfig {
+    int32_t abi_version;   /* DYCORE_ABI_VERSION                                        */
+    int32_t nx;            /* number of longitudes (periodic)                           */
+    int32_t ny;            /* number of latitude rows held by THIS handle (band height) */
+    int32_t nz;            /* number of sigma levels                                    */
+    int32_t ny_global;     /* rows of the whole grid; == ny for a single-GPU run        */
+    int32_t j_offset;      /* global row of local row 1, minus 1 (0 for the first band) */
+    int32_t device;        /* HIP device ordinal                                        */
+    int32_t i_turb;        /* i_UVFLX_vert_turb & i_POTT_vert_turb (namelist.py:66,77)  */
+    int32_t i_radiation;   /* i_POTT_radiation (io_read_namelist.py:66-67)              */
+    int32_t reserved[7];
+    double  pair_top;      /* model-top pressure [Pa] (namelist.py:37)                  */
+    void   *stream;        /* hipStream_t to issue work on; NULL = handle creates one   */
+} DycoreConfig;
+
+/* ---- lifetime ------------------------------------------------------------------- */
+int dycore_create(const DycoreConfig *cfg, dycore_t **out);
+int dycore_destroy(dycore_t *h);
+const char *dycore_last_error(void);
+int dycore_abi_version(void);
+/* blocks until all work issued on the handle's stream has finished */
+int dycore_sync(dycore_t *h);
+
+/* ---- grid constants: main_grid.py:299-314 (GRF dict) ------------------------------ */
+/* name in {A,dxjs,dyis,corf,corf_is,lat_rad,lat_is_rad,dlon_rad,dlat_rad} with host
+ * shape (n0,n1,1), or {sigma_vb,dsigma,UVFLX_dif_coef,POTT_dif_coef} with n0*n1*n2
+ * = nz+1 / nz elements. */
+int dycore_set_grid(dycore_t *h, const char *name, const double *host,
+                    int32_t n0, int32_t n1, int32_t n2);
+
+/* ---- fields: main_fields.py:184-215 (copy_host_to_device / copy_device_to_host) ---- */
+int dycore_field_shape(dycore_t *h, const char *name, int32_t shape[3]);
+int dycore_upload(dycore_t *h, const char *name, const double *host);
+int dycore_download(dycore_t *h, const char *name, double *host);   /* synchronises */
+/* raw device view for callers that keep data resident (torch, other kernels):
+ * element (i,j,k) is dev[(k*rows + j)*pitch + i] */
+int dycore_field_ptr(dycore_t *h, const char *name, void **dev,
+                     int64_t *pitch, int64_t *rows, int64_t *levels);
+/* dst <- src, whole field: misc_gpu_functions.py:35-40 (set_equal) and the slice
+ * copies of dyn_matsuno.py:34-49,64-67 */
+int dycore_copy_field(dycore_t *h, const char *dst, const char *src);
+/* lateral boundary conditions of one field: misc_boundaries.py:22-82 */
+int dycore_exchange_bc(dycore_t *h, const char *name);
+
+/* ---- stages: one entry per factory method of dyn_org_discretizations.py ----------- */
+/* TendencyFactory.continuity  (:89-117)  incl. exchange of UFLX,VFLX,WWIND,COLP_NEW  */
+int dycore_continuity(dycore_t *h, double dt);
+/* TendencyFactory.momentum    (:121-249) = prepare + UFLX + VFLX tendencies           */
+int dycore_momentum(dycore_t *h);
+/*   the three kernels of .momentum individually (dyn_UVFLX_prepare.py:249,
+ *   dyn_UFLX.py:339, dyn_VFLX.py:322) */
+int dycore_momentum_prepare(dycore_t *h);
+int dycore_uflx_tendency(dycore_t *h);
+int dycore_vflx_tendency(dycore_t *h);
+/* TendencyFactory.temperature (:253-273) */
+int dycore_pott_tendency(dycore_t *h);
+/* PrognosticsFactory.euler_forward (:359-393) incl. exchange of POTT,VWIND,UWIND      */
+int dycore_euler_forward(dycore_t *h, double dt);
+/* DiagnosticsFactory.primary_diag (:310-326): PVTF, PVTFVB, PHI, PHIVB, POTTVB         */
+int dycore_primary_diag(dycore_t *h);
+/* DiagnosticsFactory.secondary_diag (:329-347), the part the dycore consumes: RHO, RHOVB */
+int dycore_secondary_diag_rho(dycore_t *h);
+
+/* ---- the whole hot loop body: dyn_matsuno.py:28-131, nsteps times ------------------- */
+/* with_rho != 0 re-diagnoses RHO/RHOVB before each step (solver.py:99-101); needed only
+ * when i_turb is set. */
+int dycore_step_matsuno(dycore_t *h, double dt, int32_t nsteps, int32_t with_rho);
+
+/* ---- measurement ------------------------------------------------------------------- */
+/* Runs nsteps Matsuno steps bracketed by HIP events on the handle's stream and returns
+ * the elapsed device time in milliseconds (synchronises). */
+int dycore_time_steps(dycore_t *h, double dt, int32_t nsteps, int32_t with_rho, double *ms);
+/* Per-kernel device time accumulated by HIP events since the last reset, for the kernel
+ * with the given index (0 <= idx < dycore_n_kernels()); enable with dycore_profile(h,1). */
+int dycore_profile(dycore_t *h, int32_t enable);
+int dycore_n_kernels(void);
+int dycore_kernel_stats(dycore_t *h, int32_t idx, const char **name,
+                        int64_t *launches, double *total_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DYCORE_H */

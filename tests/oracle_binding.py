@@ -78,8 +78,6 @@ def load_oracle():
         for n in ('oracle_diag_phi', 'oracle_diag_pottvb', 'oracle_diag_rho'):
             getattr(lib, n).argtypes = [cp, fp]
         lib.oracle_step_matsuno.argtypes = [cp, gp, fp, C.c_double, C.c_int, C.c_int]
-        for n in dir(lib):
-            pass
         _lib = lib
     return _lib
 
@@ -88,7 +86,7 @@ class Oracle:
     """The CPU restatement bound to one set of numpy arrays (reference layout)."""
 
     def __init__(self, nx, ny, nz, grid, fields=None, pair_top=10000., i_turb=1,
-                 i_radiation=0, nthreads=0):
+                 i_radiation=0, nthreads=0, fill_nan=True):
         self.lib = load_oracle()
         self.nx, self.ny, self.nz = int(nx), int(ny), int(nz)
         self.cfg = OracleCfg(self.nx, self.ny, self.nz, int(i_turb), int(i_radiation),
@@ -106,8 +104,10 @@ class Oracle:
             if fields is not None and n in fields:
                 a = np.array(fields[n], dtype=np.float64, order='C')
                 assert a.shape == shp, (n, a.shape, shp)
-            else:
+            elif fill_nan:
                 a = np.full(shp, np.nan)
+            else:               # benchmark use: untouched pages cost nothing
+                a = np.empty(shp)
             self.F[n] = a
             setattr(self.fields, n, a.ctypes.data_as(_dp))
 

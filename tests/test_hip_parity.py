@@ -1,0 +1,126 @@
+"""HIP path (through the C ABI) against the golden vectors and the CPU oracle.
+Needs a real MI355X: run with  pytest -m gpu."""
+import numpy as np
+import pytest
+
+from golden_util import load_golden, stage_tags, fields_of, rel_max_err
+from oracle_binding import oracle_from_golden, ORACLE_FIELDS
+from hip_util import grid_from_golden, make_core, fields_from
+
+from climate_model_amd import step_matsuno, step_matsuno_fused
+from climate_model_amd.fields import FIELD_TABLE
+from climate_model_amd.matsuno import Tendencies, Prognostics, Diagnostics
+
+pytestmark = pytest.mark.gpu
+
+# Tolerances (max-norm relative, the reference's own testsuite.py:46-60 norm; its own
+# acceptance threshold is 1e-4).  The device differs from the fp64 golden vectors by
+# FMA contraction and by ocml pow/sin/cos vs libm: a few ulp per operation, amplified by
+# the cancellation in the pressure-gradient and flux-difference terms.
+STAGE_TOL = 1e-11
+STEP_TOL = 1e-9
+PROGNOSTIC = ['COLP', 'UWIND', 'VWIND', 'POTT']
+
+
+@pytest.mark.parametrize('case,i_turb', [('g10x4_dry', 0), ('g10x4_dry', 1), ('g10x4_turb', 1)])
+def test_stage_by_stage_vs_golden(case, i_turb):
+    z = load_golden(case)
+    nx, ny = int(z['meta/nx']), int(z['meta/ny'])
+    GR = grid_from_golden(z, i_turb)
+    core = make_core(GR, i_turb)
+    F = fields_from(GR, core, fields_of(z, 'st00_pre'))
+    tags = stage_tags(z)
+    checked = 0
+    for n, tag in enumerate(tags[1:], start=1):
+        stage = tag.split('_', 1)[1]
+        ref_out = fields_of(z, tag)
+        if n == 1:
+            for a in PROGNOSTIC:
+                core.copy_field(a + '_OLD', a)
+        if stage == 'continuity':
+            Tendencies.continuity(GR, GR.GRF['HIP'], **F.get(Tendencies.fields_continuity, target='HIP'))
+        elif stage == 'momentum':
+            Tendencies.momentum(GR.GRF['HIP'], **F.get(Tendencies.fields_momentum, target='HIP'))
+        elif stage == 'temperature':
+            Tendencies.temperature(GR.GRF['HIP'], **F.get(Tendencies.fields_temperature, target='HIP'))
+        elif stage == 'moisture':
+            Tendencies.moisture(GR.GRF['HIP'], **F.get(Tendencies.fields_moisture, target='HIP'))
+        elif stage == 'euler_forward':
+            core.copy_field('COLP', 'COLP_NEW')
+            Prognostics.euler_forward(GR, GR.GRF['HIP'], **F.get(Prognostics.fields_prognostic, target='HIP'))
+        elif stage == 'primary_diag':
+            Diagnostics.primary_diag(GR.GRF['HIP'], **F.get(Diagnostics.fields_primary_diag, target='HIP'))
+        for name, ref in ref_out.items():
+            if name not in FIELD_TABLE:
+                continue
+            if not i_turb and (name.endswith('_TURB') or name.startswith('KMOM_d')):
+                continue            # not produced with the turbulence coupling off
+            got = core.download(name)
+            err, ncmp, bad = rel_max_err(got, ref, name, nx, ny)
+            assert bad == 0, '%s %s: %d non-finite cells' % (tag, name, bad)
+            assert err <= STAGE_TOL, '%s %s: rel err %.3e' % (tag, name, err)
+            checked += 1
+            # continue from the reference values (finite cells only)
+            m = np.isfinite(ref)
+            got[m] = ref[m]
+            core.upload(name, got)
+    assert checked > 40
+
+
+@pytest.mark.parametrize('case,steps', [('g10x4_dry', (1, 2, 10)), ('g4x8_dry', (1, 10))])
+@pytest.mark.parametrize('driver', ['staged', 'fused'])
+def test_whole_steps_vs_golden(case, steps, driver):
+    z = load_golden(case)
+    nx, ny = int(z['meta/nx']), int(z['meta/ny'])
+    GR = grid_from_golden(z, 0)
+    core = make_core(GR, 0)
+    ic = {k[3:]: z[k] for k in z.files if k.startswith('ic/')}
+    F = fields_from(GR, core, ic)
+    core.primary_diag()
+    done = 0
+    for s in steps:
+        if driver == 'fused':
+            step_matsuno_fused(GR, F, s - done)
+        else:
+            for _ in range(s - done):
+                step_matsuno(GR, F)
+        done = s
+        for name in PROGNOSTIC:
+            got = core.download(name)
+            err, ncmp, bad = rel_max_err(got, z['step%03d/%s' % (s, name)], name, nx, ny)
+            assert bad == 0 and ncmp > 0
+            assert err <= STEP_TOL, '%s %s step %d %s: rel err %.3e' % (case, driver, s, name, err)
+
+
+def test_turb_whole_step_vs_oracle():
+    """Turbulence-coupled step (random K, surface fluxes): HIP fused step vs the oracle."""
+    z = load_golden('g10x4_turb')
+    nx, ny = int(z['meta/nx']), int(z['meta/ny'])
+    dt = float(z['meta/dt'])
+    o = oracle_from_golden(z, None, i_turb=1)
+    o.primary_diag()
+    GR = grid_from_golden(z, 1)
+    core = make_core(GR, 1)
+    F = fields_from(GR, core, {n: o.F[n] for n in ORACLE_FIELDS})
+    o.step_matsuno(dt, 3, with_rho=True)
+    core.step_matsuno(dt, 3, with_rho=True)
+    for name in PROGNOSTIC + ['PHI', 'PVTF', 'POTTVB', 'WWIND', 'UFLX', 'VFLX']:
+        err, ncmp, bad = rel_max_err(core.download(name), o.F[name], name, nx, ny)
+        assert bad == 0 and err <= STEP_TOL, '%s: rel err %.3e (%d bad)' % (name, err, bad)
+
+
+def test_layout_adaptor_roundtrip_and_exchange():
+    z = load_golden('g10x4_dry')
+    GR = grid_from_golden(z, 0)
+    core = make_core(GR, 0)
+    rng = np.random.default_rng(5)
+    from oracle_binding import Oracle, GRID_2D, GRID_1D
+    o = Oracle(GR.nx, GR.ny, GR.nz, {n: z['grid/' + n] for n in GRID_2D + GRID_1D})
+    for name in ['UWIND', 'VWIND', 'POTT', 'COLP', 'WWIND', 'CFLX', 'PVTFVB']:
+        a = rng.standard_normal(core.field_shape(name))
+        core.upload(name, a)
+        np.testing.assert_array_equal(core.download(name), a)      # bit-exact round trip
+        core.exchange_bc(name)
+        o.F[name][...] = a
+        o.exchange_bc(name)
+        np.testing.assert_array_equal(core.download(name), o.F[name])

@@ -1,0 +1,225 @@
+#!/usr/bin/env python3
+"""Benchmark of the Matsuno dycore step on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+One "step" = one full Matsuno step (predictor + corrector) of the dry hydrostatic dycore
+over the whole synthetic grid; the metric is BASELINE.json's: cell-updates/s
+(cells = nx*ny*nz) at 0.25 deg x 64 levels (1440 x 720 x 64), fp64, inputs resident in HBM.
+N > 1 (launched by torch.distributed.run, one rank per GPU) cuts the SAME grid into N
+latitude bands with RCCL neighbour send/recv between them: strong scaling.
+
+Rank 0 prints one JSON line (contract in the task statement) with two extra objects:
+  roofline     : dominant kernel's algorithmic bytes per launch / its mean HIP-event duration
+                 in the timed region, against the 8 TB/s HBM3E peak; `step_*` keys give the
+                 same for the whole step (130 field passes x 8 B per cell-update)
+  cpu_baseline : the CPU restatement (oracle/, "port") timed on this box's host cores on a
+                 bounded sample of the same workload (N = 1, rank 0 only)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+PASSES_PER_STEP = 130          # compulsory 3-D field passes per Matsuno step
+# algorithmic 3-D field passes per launch of each kernel (SURVEY.md 8d stage table)
+KERNEL_PASSES = {
+    'k_continuity': 5, 'k_prepare': 15, 'k_uflx_tendency': 13, 'k_vflx_tendency': 13,
+    'k_pott_tendency': 6, 'k_euler_forward': 9, 'k_primary_diag': 5, 'k_diag_rho': 6,
+    'k_momentum_fused': 29, 'k_tendencies_fused': 35,
+}
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--dlat', type=float, default=0.25, help='grid spacing in degrees (workload)')
+    ap.add_argument('--nz', type=int, default=64)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-seconds', type=float, default=15.0, help='CPU baseline budget')
+    return ap.parse_args()
+
+
+def host_cores():
+    """CPU cores this process may really use: the cgroup quota when there is one (a GPU box
+    shares its host; the affinity mask shows every core of the machine), else the affinity."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()[:2]
+        if quota != 'max':
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    env = os.environ.get('DYCORE_CPU_THREADS')
+    if env:
+        n = int(env)
+    return min(n, 64) if n > 64 else n
+
+
+def cpu_baseline(GR, state, budget_s):
+    """Times the CPU restatement on the same workload for about `budget_s` seconds."""
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    from oracle_binding import Oracle, ORACLE_FIELDS
+    ncores = host_cores()
+    need_gb = 46 * (GR.nx + 3) * (GR.ny + 3) * (GR.nz + 1) * 8 / 1e9
+    avail_gb = 0.0
+    for line in open('/proc/meminfo'):
+        if line.startswith('MemAvailable'):
+            avail_gb = int(line.split()[1]) / 1e6
+    if avail_gb < 1.5 * need_gb + 8:
+        return {'value': None, 'unit': 'cell-updates/s', 'cores': ncores, 'kind': 'port',
+                'sample': 'skipped: %.0f GB host memory needed, %.0f GB available' % (need_gb, avail_gb)}
+    o = Oracle(GR.nx, GR.ny, GR.nz, GR.GRF['CPU'], {n: state[n] for n in state if n in ORACLE_FIELDS},
+               pair_top=GR.nl.pair_top, i_turb=0, nthreads=ncores, fill_nan=False)
+    for n in ('WWIND', 'POTTVB'):
+        if n not in state:
+            o.F[n][...] = 0.
+    o.primary_diag()
+    t0 = time.perf_counter()
+    o.step_matsuno(GR.dt, 1, with_rho=False)          # first touch of every array + warm-up
+    t_first = time.perf_counter() - t0
+    nsteps = int(max(1, min(20, budget_s / max(t_first, 1e-3))))
+    t0 = time.perf_counter()
+    o.step_matsuno(GR.dt, nsteps, with_rho=False)
+    t = (time.perf_counter() - t0) / nsteps
+    cells = GR.nx * GR.ny * GR.nz
+    return {'value': cells / t, 'unit': 'cell-updates/s', 'cores': ncores, 'kind': 'port',
+            'sample': '%d Matsuno steps of the full %dx%dx%d grid (C/OpenMP restatement of the '
+                      'reference CPU kernels, %.2f s/step, after 1 untimed step)' % (nsteps, GR.nx, GR.ny, GR.nz, t)}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get('RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    local_rank = int(os.environ.get('LOCAL_RANK', 0))
+    if world != args.gpus:
+        raise SystemExit('--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d'
+                         % (args.gpus, world, args.gpus))
+    import torch
+    import torch.distributed as dist
+    from climate_model_amd import Namelist, Grid, ModelFields, HipDycore
+    from climate_model_amd.bands import BandLayout, DistributedBands, band_grid_arrays
+    from climate_model_amd.fields import FIELD_TABLE
+    from climate_model_amd.synthetic import initialize_fields
+
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+    stream = torch.cuda.Stream()
+    torch.cuda.set_stream(stream)
+
+    # ---- workload: synthetic dry state on the global grid, this rank's latitude band ----
+    GR = Grid(Namelist(nz=args.nz, dlat_deg=args.dlat, dlon_deg=args.dlat))
+    L = BandLayout(GR.ny, world)
+    F = ModelFields(GR)
+    initialize_fields(GR, F)        # index-hash noise: identical on every rank
+    names = ['HSURF', 'COLP', 'UWIND', 'VWIND', 'POTT', 'WWIND', 'POTTVB']
+    state = {n: F.host[n] for n in names}
+    core = HipDycore(GR.nx, L.ny(rank), GR.nz, pair_top=GR.nl.pair_top, device=local_rank,
+                     ny_global=GR.ny, j_offset=L.j_offset(rank), stream=stream.cuda_stream)
+    core.set_grid(band_grid_arrays(GR.GRF['HIP'], L, rank))
+    for n in names:
+        core.upload(n, L.slice_rows(state[n], rank, FIELD_TABLE[n][1]))
+    core.primary_diag()
+    core.sync()
+    bands = DistributedBands(core, L, rank, torch.device('cuda', local_rank)) if world > 1 else None
+
+    def run(nsteps):
+        if bands is None:
+            core.step_matsuno(GR.dt, nsteps)
+        else:
+            bands.step_matsuno(GR.dt, nsteps)
+
+    def fence():
+        torch.cuda.synchronize()
+        core.sync()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    run(args.warmup)
+    core.profile(True)
+    fence()
+    t0 = time.perf_counter()
+    run(args.steps)
+    fence()
+    elapsed = time.perf_counter() - t0
+    stats = core.kernel_stats()
+    core.profile(False)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # sanity: the state must still be finite (a diverged run is not a measurement)
+    u = core.download('UWIND')
+    if not np.isfinite(u[1:GR.nx + 1, 1:-1]).all():
+        raise SystemExit('non-finite UWIND after the timed steps')
+
+    cells = GR.nx * GR.ny * GR.nz
+    ms_per_step = 1e3 * elapsed / args.steps
+    value = cells * args.steps / elapsed
+    band_cells = GR.nx * L.ny(rank) * GR.nz
+    # dominant kernel on this rank
+    dom, dom_n, dom_ms = None, 0, 0.0
+    for k, (n, tot) in stats.items():
+        if n and tot > dom_ms and k in KERNEL_PASSES:
+            dom, dom_n, dom_ms = k, n, tot
+    roof = None
+    if dom:
+        per_launch_bytes = KERNEL_PASSES[dom] * band_cells * 8
+        avg_s = dom_ms / dom_n / 1e3
+        ach = per_launch_bytes / avg_s / 1e9
+        step_ach = PASSES_PER_STEP * 8 * value / 1e9 / world      # per GPU
+        traffic = None
+        tfile = os.path.join(ROOT, 'profiles', 'traffic_latest.json')
+        if os.path.exists(tfile) and world == 1:
+            try:
+                tj = json.load(open(tfile))
+                if tj.get('kernel') == dom and tj.get('grid') == [GR.nx, GR.ny, GR.nz]:
+                    traffic = tj.get('bytes_per_launch')
+            except Exception:
+                traffic = None
+        roof = {'bound': 'hbm', 'kernel': dom, 'achieved': ach, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                'frac': ach / HBM_PEAK_GBS, 'traffic': traffic,
+                'algorithmic_bytes_per_launch': per_launch_bytes, 'avg_launch_ms': dom_ms / dom_n,
+                'launches': dom_n,
+                'step_achieved': step_ach, 'step_frac': step_ach / HBM_PEAK_GBS,
+                'kernels_ms_per_step': {k: tot / args.steps for k, (n, tot) in stats.items() if n}}
+
+    line = {
+        'metric': 'cell-updates/sec per Matsuno step at 0.25deg x 64L (achieved HBM GB/s in roofline)',
+        'value': value, 'unit': 'cell-updates/s', 'n_gpus': world, 'steps': args.steps,
+        'warmup': args.warmup, 'ms_per_step': ms_per_step, 'higher_is_better': True,
+        'scaling': 'strong', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
+        'config': {'workload': 'dry hydrostatic dycore, Matsuno step, %g deg lat-lon (%d x %d) x %d sigma levels, '
+                               'dt=%.4g s' % (args.dlat, GR.nx, GR.ny, GR.nz, GR.dt),
+                   'cells': cells, 'parallelism': 'latitude bands x%d' % world if world > 1 else 'single GPU'},
+        'roofline': roof,
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        core.close()
+        try:
+            line['cpu_baseline'] = cpu_baseline(GR, state, args.cpu_seconds)
+        except Exception as e:        # the baseline is a report, never a reason to lose the GPU number
+            line['cpu_baseline'] = {'value': None, 'unit': 'cell-updates/s', 'cores': None, 'kind': 'port',
+                                    'sample': 'failed: %r' % (e,)}
+    if rank == 0:
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,254 @@
+"""Latitude-band decomposition of the lat-lon grid across the GPUs of one node.
+
+New functionality (the reference is single-device; its "halo exchange" is the in-array
+copy of misc_boundaries.py).  The grid is cut into contiguous bands of latitude rows, one
+band per GPU / process; longitude stays whole, so the periodic-i boundary remains local.
+A band keeps the reference's halo convention (one row north and south; two for the
+y-staggered VFLX) and refreshes those rows from its neighbours twice per Matsuno substep:
+
+  phase 'A' after continuity : UFLX, VFLX, WWIND, COLP_NEW   (feed the 3x3 momentum fluxes)
+  phase 'B' after Euler step : UWIND, VWIND, POTT            (the new state)
+
+Ownership: band r owns mass rows j in [j0, j0+ny) and the v-rows (js) on the southern edge
+of each of them; the northernmost band also owns js = ny_global+1 (the pole).  Every
+exchanged row therefore has exactly one owner, and an N-band run reproduces the 1-band
+result bit for bit (same arithmetic per cell).  The polar bands apply the wall rule of
+misc_boundaries.py:36-41 instead of a receive.
+
+Transport: neighbour send/recv through torch.distributed -- backend "nccl" (= RCCL over
+xGMI on MI355X) on device buffers, or "gloo" with host staging for tests.  There is no
+collective on the path: each neighbour pair uses its own point-to-point link.
+"""
+import numpy as np
+
+from .fields import FIELD_TABLE
+
+# (field, row to send); 'N' stands for the band's last owned row ny
+SEND_NORTH = {
+    'A': [('UFLX', 'N'), ('VFLX', 'N'), ('WWIND', 'N'), ('COLP_NEW', 'N')],
+    'B': [('UWIND', 'N'), ('VWIND', 'N'), ('POTT', 'N')],
+}
+SEND_SOUTH = {
+    'A': [('UFLX', 1), ('VFLX', 1), ('VFLX', 2), ('WWIND', 1), ('COLP_NEW', 1)],
+    'B': [('UWIND', 1), ('VWIND', 1), ('POTT', 1)],
+}
+# rows at which the RECEIVER stores what its southern / northern neighbour sent
+# (offsets relative to the receiver's own ny: 'N+1' = north halo row, 'N+2' = second one)
+RECV_FROM_SOUTH = {'A': [0, 0, 0, 0], 'B': [0, 0, 0]}
+RECV_FROM_NORTH = {'A': ['N+1', 'N+1', 'N+2', 'N+1', 'N+1'], 'B': ['N+1', 'N+1', 'N+1']}
+
+
+class BandLayout:
+    """Split of ny_global latitude rows into nbands contiguous bands (pure logic)."""
+
+    def __init__(self, ny_global, nbands):
+        if nbands < 1 or ny_global < 2 * nbands:
+            raise ValueError('need at least 2 rows per band: ny=%d, bands=%d' % (ny_global, nbands))
+        self.ny_global, self.nbands = int(ny_global), int(nbands)
+        base, rem = divmod(self.ny_global, self.nbands)
+        self.heights = [base + (1 if r < rem else 0) for r in range(self.nbands)]
+        self.offsets = [sum(self.heights[:r]) for r in range(self.nbands)]   # j_offset of band r
+
+    def ny(self, r):
+        return self.heights[r]
+
+    def j_offset(self, r):
+        return self.offsets[r]
+
+    def south(self, r):
+        return r - 1 if r > 0 else None
+
+    def north(self, r):
+        return r + 1 if r < self.nbands - 1 else None
+
+    def slice_rows(self, arr, r, stgy):
+        """Band r's local array (halo rows included) out of a global [i, j, k] array."""
+        j0 = self.offsets[r]
+        return np.ascontiguousarray(arr[:, j0:j0 + self.heights[r] + 2 + stgy])
+
+    def owned_rows(self, r, stgy):
+        """Local row range [lo, hi) a band owns (used to reassemble a global field)."""
+        hi = self.heights[r] + 1
+        if stgy and r == self.nbands - 1:
+            hi += 1
+        return 1, hi
+
+
+def _resolve(rows, ny):
+    out = []
+    for r in rows:
+        if r == 'N':
+            out.append(ny)
+        elif r == 'N+1':
+            out.append(ny + 1)
+        elif r == 'N+2':
+            out.append(ny + 2)
+        else:
+            out.append(int(r))
+    return out
+
+
+class BandHalo:
+    """Message plan of one band: what to pack for / unpack from each neighbour."""
+
+    def __init__(self, core, ny, has_south, has_north):
+        self.core, self.ny = core, ny
+        self.has_south, self.has_north = has_south, has_north
+        self.plan = {}
+        for ph in ('A', 'B'):
+            sn = [f for f, _ in SEND_NORTH[ph]]
+            ss = [f for f, _ in SEND_SOUTH[ph]]
+            self.plan[ph] = dict(
+                send_north=(sn, _resolve([r for _, r in SEND_NORTH[ph]], ny)),
+                send_south=(ss, _resolve([r for _, r in SEND_SOUTH[ph]], ny)),
+                recv_south=(sn, _resolve(RECV_FROM_SOUTH[ph], ny)),      # neighbour's send_north list
+                recv_north=(ss, _resolve(RECV_FROM_NORTH[ph], ny)),      # neighbour's send_south list
+            )
+
+    def sizes(self, ph):
+        p = self.plan[ph]
+        return {k: self.core.rows_size(p[k][0]) for k in p}
+
+
+class _TorchBuffers:
+    def __init__(self, halo, device):
+        import torch
+        self.buf = {}
+        for ph in ('A', 'B'):
+            sz = halo.sizes(ph)
+            self.buf[ph] = {k: torch.empty(n, dtype=torch.float64, device=device) for k, n in sz.items()}
+
+
+class DistributedBands:
+    """One process = one band.  Drives the Matsuno step in parts with neighbour exchanges
+    through torch.distributed (RCCL when the process group's backend is nccl)."""
+
+    def __init__(self, core, layout, rank, device, group=None):
+        import torch.distributed as dist
+        self.dist = dist
+        self.core, self.layout, self.rank = core, layout, rank
+        self.group = group
+        self.south, self.north = layout.south(rank), layout.north(rank)
+        self.halo = BandHalo(core, layout.ny(rank), self.south is not None, self.north is not None)
+        self.bufs = _TorchBuffers(self.halo, device).buf
+        self.staged = dist.get_backend(group) != 'nccl' and str(device) != 'cpu'
+
+    def exchange(self, ph):
+        import torch
+        dist, p, b = self.dist, self.halo.plan[ph], self.bufs[ph]
+        core = self.core
+        if self.north is not None:
+            core.pack_rows(*p['send_north'], b['send_north'].data_ptr())
+        if self.south is not None:
+            core.pack_rows(*p['send_south'], b['send_south'].data_ptr())
+        if self.staged:     # gloo: through host memory
+            send = {k: b[k].cpu() for k in ('send_north', 'send_south')}
+            recv = {k: torch.empty(b[k].shape, dtype=b[k].dtype) for k in ('recv_north', 'recv_south')}
+        else:
+            send, recv = b, b
+        ops = []
+        if self.north is not None:
+            ops.append(dist.P2POp(dist.isend, send['send_north'], self.north, self.group))
+            ops.append(dist.P2POp(dist.irecv, recv['recv_north'], self.north, self.group))
+        if self.south is not None:
+            ops.append(dist.P2POp(dist.isend, send['send_south'], self.south, self.group))
+            ops.append(dist.P2POp(dist.irecv, recv['recv_south'], self.south, self.group))
+        if ops:
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()
+        if self.staged:
+            for k in ('recv_north', 'recv_south'):
+                b[k].copy_(recv[k])
+        if self.north is not None:
+            core.unpack_rows(*p['recv_north'], b['recv_north'].data_ptr())
+        if self.south is not None:
+            core.unpack_rows(*p['recv_south'], b['recv_south'].data_ptr())
+
+    def step_matsuno(self, dt, nsteps=1, with_rho=None):
+        core = self.core
+        for _ in range(nsteps):
+            core.step_begin(with_rho)
+            for sub in (0, 1):
+                core.substep_part(dt, sub, 0)
+                self.exchange('A')
+                core.substep_part(dt, sub, 1)
+                self.exchange('B')
+                core.substep_part(dt, sub, 2)
+
+
+class LocalBands:
+    """All bands inside one process (one or several handles on the same GPU), exchanging
+    through device-to-device copies.  Test vehicle for the band-aware kernels."""
+
+    def __init__(self, cores, layout, device):
+        self.cores, self.layout = cores, layout
+        self.halos = [BandHalo(c, layout.ny(r), layout.south(r) is not None, layout.north(r) is not None)
+                      for r, c in enumerate(cores)]
+        self.bufs = [_TorchBuffers(h, device).buf for h in self.halos]
+
+    def exchange(self, ph):
+        n = len(self.cores)
+        for r in range(n):
+            p, b = self.halos[r].plan[ph], self.bufs[r][ph]
+            if r < n - 1:
+                self.cores[r].pack_rows(*p['send_north'], b['send_north'].data_ptr())
+            if r > 0:
+                self.cores[r].pack_rows(*p['send_south'], b['send_south'].data_ptr())
+        for c in self.cores:
+            c.sync()
+        for r in range(n):
+            p, b = self.halos[r].plan[ph], self.bufs[r][ph]
+            if r < n - 1:
+                b['recv_north'].copy_(self.bufs[r + 1][ph]['send_south'])
+            if r > 0:
+                b['recv_south'].copy_(self.bufs[r - 1][ph]['send_north'])
+        import torch
+        torch.cuda.synchronize()
+        for r in range(n):
+            p, b = self.halos[r].plan[ph], self.bufs[r][ph]
+            if r < n - 1:
+                self.cores[r].unpack_rows(*p['recv_north'], b['recv_north'].data_ptr())
+            if r > 0:
+                self.cores[r].unpack_rows(*p['recv_south'], b['recv_south'].data_ptr())
+
+    def step_matsuno(self, dt, nsteps=1, with_rho=None):
+        for _ in range(nsteps):
+            for c in self.cores:
+                c.step_begin(with_rho)
+            for sub in (0, 1):
+                for c in self.cores:
+                    c.substep_part(dt, sub, 0)
+                self.exchange('A')
+                for c in self.cores:
+                    c.substep_part(dt, sub, 1)
+                self.exchange('B')
+                for c in self.cores:
+                    c.substep_part(dt, sub, 2)
+
+
+def band_grid_arrays(GRF, layout, r):
+    """Band r's slice (halo rows included) of the global grid-constant dict."""
+    out = {}
+    for name, a in GRF.items():
+        a = np.asarray(a)
+        if a.ndim == 3 and a.shape[0] > 1:      # 2-D horizontal array (n0, n1, 1)
+            stgy = 1 if name in ('dxjs', 'dlon_rad') else 0
+            out[name] = layout.slice_rows(a, r, stgy)
+        else:
+            out[name] = a
+    return out
+
+
+def gather_global(layout, band_arrays, name):
+    """Reassemble a global [i, j, k] array from per-band local arrays (owned rows only;
+    the global halo rows 0 and ny+1(+1) come from the polar bands)."""
+    stgy = FIELD_TABLE[name][1]
+    parts = []
+    for r, a in enumerate(band_arrays):
+        lo, hi = layout.owned_rows(r, stgy)
+        if r == 0:
+            lo = 0
+        if r == layout.nbands - 1:
+            hi = a.shape[1]
+        parts.append(a[:, lo:hi])
+    return np.concatenate(parts, axis=1)

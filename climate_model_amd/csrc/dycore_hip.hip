@@ -85,12 +85,12 @@ constexpr int kNGrid = sizeof(kGrid) / sizeof(kGrid[0]);
 
 // kernels tracked by the profiler
 enum KernelId {
-    K_CONTINUITY = 0, K_PREPARE, K_UFLX, K_VFLX, K_POTT, K_EULER, K_DIAG, K_RHO, K_EXCHANGE, K_COPY,
+    K_CONTINUITY = 0, K_PREPARE, K_UFLX, K_VFLX, K_POTT, K_EULER, K_DIAG, K_RHO, K_EXCHANGE, K_COPY, K_HALO,
     K_COUNT
 };
 const char *kKernelNames[K_COUNT] = {
     "k_continuity", "k_prepare", "k_uflx_tendency", "k_vflx_tendency", "k_pott_tendency",
-    "k_euler_forward", "k_primary_diag", "k_diag_rho", "k_exchange_bc", "copy_field",
+    "k_euler_forward", "k_primary_diag", "k_diag_rho", "k_exchange_bc", "copy_field", "k_rows",
 };
 
 struct ProfRec { int kid; hipEvent_t a, b; };
@@ -189,7 +189,7 @@ int do_continuity(dycore *h, const Ptrs &p, double dt)
 int do_prepare(dycore *h, const Ptrs &p)
 {
     Scope s(h, K_PREPARE);
-    dim3 gr = grid_for(h->g, h->g.nx + 1, h->g.ny + 1);
+    dim3 gr = grid_for(h->g, h->g.nx + 1, h->g.ny + 2);      // rows 0..ny+1
     if (h->g.i_turb) hipLaunchKernelGGL(k_prepare<true>, gr, dim3(TI, TJ), 0, h->stream, h->g, p);
     else hipLaunchKernelGGL(k_prepare<false>, gr, dim3(TI, TJ), 0, h->stream, h->g, p);
     return launch_check("k_prepare");
@@ -272,7 +272,9 @@ int do_momentum(dycore *h, const Ptrs &p)
 // X_OLD holds the state at step start; the predictor evaluates tendencies on X_OLD and
 // writes the estimate into X, the corrector evaluates on X and overwrites X in place
 // (k_euler_forward reads X_OLD and the tendency at the written cell only).
-int do_step(dycore *h, double dt, int with_rho)
+// The step is cut into parts at the two points where a latitude band needs rows from its
+// neighbours (after continuity, after the Euler step); a single band runs them back to back.
+int step_begin(dycore *h, int with_rho)
 {
     int rc;
     Ptrs &p = h->p;
@@ -281,19 +283,42 @@ int do_step(dycore *h, double dt, int with_rho)
     std::swap(p.VWIND, p.VWIND_OLD);
     std::swap(p.POTT, p.POTT_OLD);
     std::swap(p.COLP, p.COLP_OLD);
-    for (int sub = 0; sub < 2; sub++) {
-        Ptrs q = p;
-        if (sub == 0) {            // predictor: the current state IS the *_OLD buffers
-            q.UWIND = p.UWIND_OLD; q.VWIND = p.VWIND_OLD; q.POTT = p.POTT_OLD; q.COLP = p.COLP_OLD;
-        }
-        if ((rc = do_continuity(h, q, dt))) return rc;
+    return 0;
+}
+Ptrs substep_view(dycore *h, int sub)
+{
+    Ptrs q = h->p;
+    if (sub == 0) {                // predictor: the current state IS the *_OLD buffers
+        q.UWIND = h->p.UWIND_OLD; q.VWIND = h->p.VWIND_OLD; q.POTT = h->p.POTT_OLD; q.COLP = h->p.COLP_OLD;
+    }
+    return q;
+}
+int substep_part(dycore *h, double dt, int sub, int part)
+{
+    int rc;
+    Ptrs &p = h->p;
+    const Ptrs q = substep_view(h, sub);
+    switch (part) {
+    case 0:                         // -> needs UFLX, VFLX, WWIND, COLP_NEW halo rows afterwards
+        return do_continuity(h, q, dt);
+    case 1:
         if ((rc = do_momentum(h, q))) return rc;
         if ((rc = do_pott(h, q))) return rc;
         // COLP <- COLP_NEW (dyn_matsuno.py:64-67), then the Euler step writes p.UWIND/VWIND/POTT
         if ((rc = do_copy(h, p.COLP, p.COLP_NEW, (size_t)h->g.plane))) return rc;
-        if ((rc = do_euler(h, p, dt))) return rc;
-        if ((rc = do_diag(h, p))) return rc;
+        return do_euler(h, p, dt);  // -> needs UWIND, VWIND, POTT halo rows afterwards
+    case 2:
+        return do_diag(h, p);
     }
+    return fail(DYCORE_EINVAL, "substep part %d out of range", part);
+}
+int do_step(dycore *h, double dt, int with_rho)
+{
+    int rc;
+    if ((rc = step_begin(h, with_rho))) return rc;
+    for (int sub = 0; sub < 2; sub++)
+        for (int part = 0; part < 3; part++)
+            if ((rc = substep_part(h, dt, sub, part))) return rc;
     return 0;
 }
 
@@ -523,6 +548,74 @@ int dycore_step_matsuno(dycore_t *h, double dt, int32_t nsteps, int32_t with_rho
     for (int s = 0; s < nsteps; s++)
         if ((rc = do_step(h, dt, with_rho))) return rc;
     return 0;
+}
+
+
+int dycore_step_begin(dycore_t *h, int32_t with_rho)
+{
+    int rc = check_ready(h);
+    return rc ? rc : step_begin(h, with_rho);
+}
+
+int dycore_substep_part(dycore_t *h, double dt, int32_t substep, int32_t part)
+{
+    int rc = check_ready(h);
+    if (rc) return rc;
+    if (substep < 0 || substep > 1) return fail(DYCORE_EINVAL, "substep must be 0 (estimate) or 1 (final)");
+    return substep_part(h, dt, substep, part);
+}
+
+static int rows_op(dycore_t *h, int32_t n, const char *const *names, const int32_t *rows,
+                   void *dev_buf, int64_t *n_doubles, int unpack)
+{
+    if (!h || n < 0 || (n && (!names || !rows))) return fail(DYCORE_EINVAL, "bad argument");
+    const Ptrs &q = h->p;
+    long long off = 0;
+    int done = 0;
+    while (done < n) {
+        RowList rl;
+        rl.n = 0;
+        int maxk = 1;
+        for (; done < n && rl.n < 8; done++) {
+            const FieldDesc *d;
+            int rc = find_field(h, names[done], &d);
+            if (rc) return rc;
+            if (rows[done] < 0 || rows[done] > h->g.ny + 1 + d->stgy)
+                return fail(DYCORE_EINVAL, "row %d outside field '%s'", rows[done], names[done]);
+            const int e = rl.n++;
+            rl.base[e] = q.*(d->member);
+            rl.row[e] = rows[done];
+            rl.nk[e] = h->nk_of(d->nk);
+            rl.off[e] = off;
+            off += (long long)rl.nk[e] * (h->g.nx + 3);
+            if (rl.nk[e] > maxk) maxk = rl.nk[e];
+        }
+        if (dev_buf && rl.n) {
+            Scope s(h, K_HALO);
+            hipLaunchKernelGGL(k_rows, dim3((h->g.nx + 3 + 255) / 256, maxk, rl.n), dim3(256), 0, h->stream,
+                               h->g, rl, (double *)dev_buf, unpack);
+            int rc = launch_check("k_rows");
+            if (rc) return rc;
+        }
+    }
+    if (n_doubles) *n_doubles = off;
+    return 0;
+}
+
+int dycore_rows_size(dycore_t *h, int32_t n, const char *const *names, int64_t *n_doubles)
+{
+    std::vector<int32_t> zero(n > 0 ? n : 0, 0);
+    return rows_op(h, n, names, zero.data(), nullptr, n_doubles, 0);
+}
+int dycore_pack_rows(dycore_t *h, int32_t n, const char *const *names, const int32_t *rows, void *dev_buf)
+{
+    if (!dev_buf) return fail(DYCORE_EINVAL, "null buffer");
+    return rows_op(h, n, names, rows, dev_buf, nullptr, 0);
+}
+int dycore_unpack_rows(dycore_t *h, int32_t n, const char *const *names, const int32_t *rows, const void *dev_buf)
+{
+    if (!dev_buf) return fail(DYCORE_EINVAL, "null buffer");
+    return rows_op(h, n, names, rows, const_cast<void *>(dev_buf), nullptr, 1);
 }
 
 int dycore_time_steps(dycore_t *h, double dt, int32_t nsteps, int32_t with_rho, double *ms)

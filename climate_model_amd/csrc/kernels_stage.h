@@ -65,13 +65,28 @@ __global__ __launch_bounds__(TI *TJ) void k_continuity(Geo g, Ptrs p, double dt)
 // ------------------------------------------------------------------------------------
 // momentum-flux preparation: dyn_UVFLX_prepare.py:249-439.
 // Threads cover is in [1,nx+1], js in [1,ny+1]; each output keeps its own staggered range.
+// A band that does not touch the south wall also produces R, S, T on its halo row j = 0
+// (dVFLXdt at its first v-row reads them at j-1); nothing else is computed there.
 template <bool TURB>
 __global__ __launch_bounds__(TI *TJ) void k_prepare(Geo g, Ptrs p)
 {
-    DYC_IJ(1, 1)
+    DYC_IJ(1, 0)
     if (i > g.nx + 1 || j > g.ny + 1) return;
     const int P = g.P;
     const size_t c = at2(g, i, j);
+    if (j == 0) {
+        if (g.pole_s || i > g.nx + 1) return;
+        for (int k = 0; k < g.nz; k++) {
+            const size_t q = c + (size_t)k * g.plane;
+            const double vs = p.VFLX[q - 1] + p.VFLX[q + P - 1] + p.VFLX[q] + p.VFLX[q + P];
+            p.SFLX[q] = 1.0 / 24.0 * (vs + p.UFLX[q - 1] + 2.0 * p.UFLX[q] + p.UFLX[q + 1]);
+            p.TFLX[q] = 1.0 / 24.0 * (vs - p.UFLX[q - 1] - 2.0 * p.UFLX[q] - p.UFLX[q + 1]);
+            if (i <= g.nx)
+                p.RFLX[q] = 1.0 / 12.0 * (p.VFLX[q - 1] + p.VFLX[q + P - 1] + 2.0 * (p.VFLX[q] + p.VFLX[q + P]) +
+                                          p.VFLX[q + 1] + p.VFLX[q + P + 1]);
+        }
+        return;
+    }
     const int jg = j + g.joff;
     const bool u_ok = (j <= g.ny);               // WWIND_UWIND, KMOM_dUWINDdz, S, T  rows
     const bool v_ok = (i <= g.nx);               // WWIND_VWIND, KMOM_dVWINDdz, D, E  columns
@@ -601,6 +616,26 @@ __global__ void k_to_host(Geo g, const double *__restrict__ src, double *__restr
         if (i < n0 && k < n2) dst[((size_t)i * n1 + j) * n2 + k] = tile[threadIdx.x][r];
     }
 }
+// ---- halo rows of a latitude band <-> contiguous message buffer (multi-GPU) -------------
+// One launch moves up to 8 (field,row) pairs: entry e copies the nk[e] levels of row
+// row[e], columns 0..nx+2, to/from buf + off[e].
+struct RowList {
+    int n;
+    double *base[8];
+    int row[8], nk[8];
+    long long off[8];
+};
+__global__ void k_rows(Geo g, RowList rl, double *buf, int unpack)
+{
+    const int e = blockIdx.z, k = blockIdx.y;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= rl.n || k >= rl.nk[e] || i > g.nx + 2) return;
+    double *f = rl.base[e] + (size_t)k * g.plane + (size_t)rl.row[e] * g.P + i;
+    double *b = buf + rl.off[e] + (size_t)k * (g.nx + 3) + i;
+    if (unpack) *f = *b;
+    else *b = *f;
+}
+
 __global__ void k_fill(double *dst, size_t n, double v)
 {
     for (size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x; t < n; t += (size_t)gridDim.x * blockDim.x)

@@ -32,6 +32,8 @@ ABI_SYMBOLS = [
     'dycore_continuity', 'dycore_momentum', 'dycore_momentum_prepare', 'dycore_uflx_tendency',
     'dycore_vflx_tendency', 'dycore_pott_tendency', 'dycore_euler_forward', 'dycore_primary_diag',
     'dycore_secondary_diag_rho', 'dycore_step_matsuno', 'dycore_time_steps',
+    'dycore_step_begin', 'dycore_substep_part', 'dycore_rows_size', 'dycore_pack_rows',
+    'dycore_unpack_rows',
     'dycore_profile', 'dycore_n_kernels', 'dycore_kernel_stats',
 ]
 
@@ -70,6 +72,12 @@ def load_library(path=None):
         getattr(lib, n).argtypes = [hp]
     lib.dycore_step_matsuno.argtypes = [hp, C.c_double, C.c_int32, C.c_int32]
     lib.dycore_time_steps.argtypes = [hp, C.c_double, C.c_int32, C.c_int32, C.POINTER(C.c_double)]
+    lib.dycore_step_begin.argtypes = [hp, C.c_int32]
+    lib.dycore_substep_part.argtypes = [hp, C.c_double, C.c_int32, C.c_int32]
+    cpp = C.POINTER(C.c_char_p)
+    lib.dycore_rows_size.argtypes = [hp, C.c_int32, cpp, C.POINTER(C.c_int64)]
+    lib.dycore_pack_rows.argtypes = [hp, C.c_int32, cpp, C.POINTER(C.c_int32), C.c_void_p]
+    lib.dycore_unpack_rows.argtypes = [hp, C.c_int32, cpp, C.POINTER(C.c_int32), C.c_void_p]
     lib.dycore_profile.argtypes = [hp, C.c_int32]
     lib.dycore_kernel_stats.argtypes = [hp, C.c_int32, C.POINTER(C.c_char_p), C.POINTER(C.c_int64),
                                         C.POINTER(C.c_double)]
@@ -195,6 +203,32 @@ class HipDycore:
     def step_matsuno(self, dt, nsteps=1, with_rho=None):
         with_rho = self.i_turb if with_rho is None else with_rho
         self._check(self.lib.dycore_step_matsuno(self._h, float(dt), int(nsteps), int(bool(with_rho))))
+
+    # ---- latitude bands: step in parts + halo rows <-> message buffers ----
+    def step_begin(self, with_rho=None):
+        with_rho = self.i_turb if with_rho is None else with_rho
+        self._check(self.lib.dycore_step_begin(self._h, int(bool(with_rho))))
+
+    def substep_part(self, dt, substep, part):
+        self._check(self.lib.dycore_substep_part(self._h, float(dt), int(substep), int(part)))
+
+    @staticmethod
+    def _names(names):
+        arr = (C.c_char_p * len(names))(*[n.encode() for n in names])
+        return arr
+
+    def rows_size(self, names):
+        n = C.c_int64()
+        self._check(self.lib.dycore_rows_size(self._h, len(names), self._names(names), C.byref(n)))
+        return n.value
+
+    def pack_rows(self, names, rows, dev_ptr):
+        r = (C.c_int32 * len(rows))(*rows)
+        self._check(self.lib.dycore_pack_rows(self._h, len(names), self._names(names), r, C.c_void_p(dev_ptr)))
+
+    def unpack_rows(self, names, rows, dev_ptr):
+        r = (C.c_int32 * len(rows))(*rows)
+        self._check(self.lib.dycore_unpack_rows(self._h, len(names), self._names(names), r, C.c_void_p(dev_ptr)))
 
     # ---- measurement ----
     def time_steps(self, dt, nsteps, with_rho=None):

@@ -16,10 +16,25 @@ def _gauss(lon, lat, lon0, lat0, slon, slat):
     return np.exp(-(lon - lon0) ** 2 / (2 * slon ** 2) - (lat - lat0) ** 2 / (2 * slat ** 2))
 
 
-def initialize_fields(GR, F, seed=3, noise_wind=0.1, noise_pott=0.1):
-    """Fill F.host with the synthetic state (in place) and apply the lateral BCs."""
+def _noise(i, j, k, salt):
+    """Uniform(-1,1) noise as a pure function of the GLOBAL cell index, so that a latitude
+    band generates exactly the values the whole grid would (integer hash, 2^-32 steps)."""
+    with np.errstate(over='ignore'):
+        x = (np.asarray(i, dtype=np.uint64) * np.uint64(0x9E3779B97F4A7C15)
+             + np.asarray(j, dtype=np.uint64) * np.uint64(0xC2B2AE3D27D4EB4F)
+             + np.uint64((k + 1) * 0x165667B19E3779F9 % (1 << 64)) + np.uint64(salt))
+        x ^= x >> np.uint64(31)
+        x *= np.uint64(0xBF58476D1CE4E5B9)
+        x ^= x >> np.uint64(29)
+        x *= np.uint64(0x94D049BB133111EB)
+        x ^= x >> np.uint64(32)
+    return (x >> np.uint64(32)).astype(np.float64) / 2147483648.0 - 1.0
+
+
+def initialize_fields(GR, F, seed=3, noise_wind=0.1, noise_pott=0.1, j_offset=0):
+    """Fill F.host with the synthetic state (in place) and apply the lateral BCs.
+    `j_offset` shifts local rows to global rows for the noise of a latitude band."""
     nx, ny, nz = GR.nx, GR.ny, GR.nz
-    rng = np.random.default_rng(seed)
     ii, jj, iis, jjs = GR.ii, GR.jj, GR.iis, GR.jjs
     pair_top = GR.nl.pair_top
     h = F.host
@@ -40,10 +55,10 @@ def initialize_fields(GR, F, seed=3, noise_wind=0.1, noise_pott=0.1):
     colp = h['COLP'][ii, jj, 0]
     for k in range(nz):
         vert = (1 - (k + 1) / nz) ** 0.5
-        h['UWIND'][iis, jj, k] = bump_u * vert + noise_wind * rng.uniform(-1, 1, bump_u.shape)
-        h['VWIND'][ii, jjs, k] = bump_v * vert + noise_wind * rng.uniform(-1, 1, bump_v.shape)
+        h['UWIND'][iis, jj, k] = bump_u * vert + noise_wind * _noise(iis, jj + j_offset, k, seed)
+        h['VWIND'][ii, jjs, k] = bump_v * vert + noise_wind * _noise(ii, jjs + j_offset, k, seed + 101)
         p_mid = pair_top + sig_mid[k] * colp
-        h['POTT'][ii, jj, k] = 288. * (100000. / p_mid) ** con_kappa + noise_pott * rng.uniform(-1, 1, colp.shape)
+        h['POTT'][ii, jj, k] = 288. * (100000. / p_mid) ** con_kappa + noise_pott * _noise(ii, jj + j_offset, k, seed + 202)
     for n in ('UWIND', 'VWIND', 'POTT'):
         exchange_BC_host(h[n], nx, ny)
     # x-staggered arrays carry one more periodic column than Grid.exchange_BC fills

@@ -116,6 +116,27 @@ int dycore_secondary_diag_rho(dycore_t *h);
  * when i_turb is set. */
 int dycore_step_matsuno(dycore_t *h, double dt, int32_t nsteps, int32_t with_rho);
 
+/* ---- latitude-band decomposition (multi-GPU; new functionality, the reference is
+ * single-device: SURVEY.md 5 and 8e) -------------------------------------------------
+ * A band handle (ny < ny_global) runs the step in parts and refreshes its north/south halo
+ * rows from the neighbouring bands in between; the transport (RCCL send/recv through
+ * torch.distributed) lives in climate_model_amd/bands.py, which owns the message buffers.
+ *   dycore_step_begin          rotate the time levels (the *_OLD copies of dyn_matsuno.py:34-49)
+ *   dycore_substep_part(s, 0)  continuity            -> exchange UFLX, VFLX, WWIND, COLP_NEW rows
+ *   dycore_substep_part(s, 1)  momentum, temperature, COLP<-COLP_NEW, Euler forward
+ *                                                     -> exchange UWIND, VWIND, POTT rows
+ *   dycore_substep_part(s, 2)  primary diagnostics (halo rows included)
+ * for s = 0 (estimate) and 1 (final).  pack/unpack move whole rows (columns 0..nx+2, all
+ * levels) of the named fields between the field buffers and one contiguous device buffer,
+ * entry e at offset sum_{e'<e} levels(e')*(nx+3) doubles. */
+int dycore_step_begin(dycore_t *h, int32_t with_rho);
+int dycore_substep_part(dycore_t *h, double dt, int32_t substep, int32_t part);
+int dycore_rows_size(dycore_t *h, int32_t n, const char *const *names, int64_t *n_doubles);
+int dycore_pack_rows(dycore_t *h, int32_t n, const char *const *names, const int32_t *rows,
+                     void *dev_buf);
+int dycore_unpack_rows(dycore_t *h, int32_t n, const char *const *names, const int32_t *rows,
+                       const void *dev_buf);
+
 /* ---- measurement ------------------------------------------------------------------- */
 /* Runs nsteps Matsuno steps bracketed by HIP events on the handle's stream and returns
  * the elapsed device time in milliseconds (synchronises). */

@@ -1,0 +1,71 @@
+"""CPU-only checks of the C-ABI library and the host-side mirror of the reference's
+operator boundary (no compute calls: there is no GPU here)."""
+import inspect
+import os
+import re
+
+import numpy as np
+import pytest
+
+from climate_model_amd import hip_backend as hb
+from climate_model_amd import (Namelist, Grid, ModelFields, TendencyFactory, DiagnosticsFactory,
+                               PrognosticsFactory, FIELD_TABLE)
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, 'include', 'dycore.h')).read()
+    declared = sorted(set(re.findall(r'\b(dycore_[a-z_]+)\s*\(', hdr)))
+    assert declared, 'no declarations parsed'
+    lib = hb.load_library()
+    missing = [s for s in declared if not hasattr(lib, s)]
+    assert missing == []
+    assert sorted(hb.ABI_SYMBOLS) == declared
+    assert lib.dycore_abi_version() == hb.ABI_VERSION
+
+
+def test_no_cpu_fallback_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip('a GPU is visible')
+    with pytest.raises(hb.DycoreError):
+        hb.HipDycore(36, 18, 4)
+
+
+def test_product_package_never_imports_oracle():
+    pkg = os.path.join(ROOT, 'climate_model_amd')
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(('.py', '.h', '.hip', '.cpp')):
+                txt = open(os.path.join(dirpath, f)).read()
+                assert 'oracle' not in txt.lower(), \
+                    '%s mentions the oracle' % os.path.join(dirpath, f)
+
+
+def test_factories_mirror_reference_signatures():
+    """Method names and argument lists of dyn_org_discretizations.py:89-393."""
+    T, D, P = TendencyFactory(), DiagnosticsFactory(), PrognosticsFactory()
+    assert T.fields_continuity == ['UFLX', 'VFLX', 'FLXDIV', 'UWIND', 'VWIND', 'WWIND',
+                                   'COLP', 'dCOLPdt', 'COLP_NEW', 'COLP_OLD']
+    assert T.fields_momentum[:7] == ['dUFLXdt', 'dVFLXdt', 'UWIND', 'VWIND', 'WWIND', 'UFLX', 'VFLX']
+    assert T.fields_momentum[-2:] == ['SMOMXFLX', 'SMOMYFLX'] and len(T.fields_momentum) == 33
+    assert T.fields_temperature == ['dPOTTdt', 'POTT', 'UFLX', 'VFLX', 'COLP', 'POTTVB', 'WWIND',
+                                    'COLP_NEW', 'PHI', 'PHIVB', 'KHEAT', 'RHO', 'RHOVB', 'SSHFLX',
+                                    'dPOTTdt_TURB', 'dPOTTdt_RAD']
+    assert P.fields_prognostic[:8] == ['UWIND_OLD', 'UWIND', 'VWIND_OLD', 'VWIND', 'COLP_OLD', 'COLP',
+                                       'POTT_OLD', 'POTT']
+    assert D.fields_primary_diag == ['COLP', 'PVTF', 'PVTFVB', 'PHI', 'PHIVB', 'POTT', 'POTTVB', 'HSURF']
+    with pytest.raises(ValueError):
+        TendencyFactory(target='CPU')
+
+
+def test_grid_and_fields_shapes():
+    GR = Grid(Namelist(nz=8, dlat_deg=4, dlon_deg=4))
+    assert (GR.nx, GR.ny, GR.nz, GR.dt) == (90, 45, 8, 27)      # BASELINE config 0
+    F = ModelFields(GR)
+    assert F.host['UWIND'].shape == (93, 47, 8) and F.host['VWIND'].shape == (92, 48, 8)
+    assert F.host['CFLX'].shape == (93, 48, 8) and F.host['WWIND'].shape == (92, 47, 9)
+    assert np.isnan(F.host['UFLX']).all() and (F.host['WWIND'] == 0).all()
+    for name in GR.GRID_FIELD_NAMES:
+        assert name in GR.GRF['HIP']

@@ -1,0 +1,93 @@
+"""Band-decomposed HIP path on one GPU: N bands must reproduce the 1-band result bit for
+bit (SURVEY.md 8e parity check).  In-process bands exchange by device copies; the
+2-process variant goes through torch.distributed (gloo, host-staged) like the N>1 bench."""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from golden_util import load_golden
+from hip_util import grid_from_golden
+
+from climate_model_amd import Namelist, Grid, ModelFields, HipDycore
+from climate_model_amd.bands import BandLayout, LocalBands, band_grid_arrays, gather_global
+from climate_model_amd.fields import FIELD_TABLE
+from climate_model_amd.synthetic import initialize_fields
+
+pytestmark = pytest.mark.gpu
+CHECK = ['COLP', 'UWIND', 'VWIND', 'POTT', 'PHI', 'PVTF', 'POTTVB', 'WWIND', 'UFLX', 'VFLX', 'dUFLXdt', 'dVFLXdt', 'dPOTTdt']
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _initial_state(d, nz, i_turb):
+    GR = Grid(Namelist(nz=nz, dlat_deg=d, dlon_deg=d, i_UVFLX_vert_turb=i_turb, i_POTT_vert_turb=i_turb))
+    F = ModelFields(GR)
+    initialize_fields(GR, F)
+    if i_turb:
+        rng = np.random.default_rng(9)
+        for n, lo, hi in [('KMOM', 0.5, 20.), ('KHEAT', 0.5, 20.), ('SSHFLX', -50., 150.),
+                          ('SMOMXFLX', -0.2, 0.2), ('SMOMYFLX', -0.2, 0.2)]:
+            F.host[n][...] = rng.uniform(lo, hi, F.host[n].shape)
+    names = ['HSURF', 'COLP', 'UWIND', 'VWIND', 'POTT', 'WWIND', 'POTTVB', 'KMOM', 'KHEAT',
+             'SSHFLX', 'SMOMXFLX', 'SMOMYFLX', 'dPOTTdt_RAD']
+    return GR, {n: F.host[n] for n in names}
+
+
+def _single(GR, state, i_turb, nsteps):
+    core = HipDycore(GR.nx, GR.ny, GR.nz, i_turb=i_turb)
+    core.set_grid(GR.GRF['HIP'])
+    for n, a in state.items():
+        core.upload(n, a)
+    core.primary_diag()
+    core.step_matsuno(GR.dt, nsteps)
+    out = {n: core.download(n) for n in CHECK}
+    core.close()
+    return out
+
+
+@pytest.mark.parametrize('nbands', [2, 3, 5])
+@pytest.mark.parametrize('i_turb', [0, 1])
+def test_local_bands_bitwise_equal_single(nbands, i_turb):
+    import torch
+    GR, state = _initial_state(4, 8, i_turb)
+    ref = _single(GR, state, i_turb, 3)
+    L = BandLayout(GR.ny, nbands)
+    cores = []
+    for r in range(nbands):
+        c = HipDycore(GR.nx, L.ny(r), GR.nz, i_turb=i_turb, ny_global=GR.ny, j_offset=L.j_offset(r))
+        c.set_grid(band_grid_arrays(GR.GRF['HIP'], L, r))
+        for n, a in state.items():
+            c.upload(n, L.slice_rows(a, r, FIELD_TABLE[n][1]))
+        c.primary_diag()
+        cores.append(c)
+    lb = LocalBands(cores, L, torch.device('cuda:0'))
+    lb.step_matsuno(GR.dt, 3)
+    for n in CHECK:
+        got = gather_global(L, [c.download(n) for c in cores], n)
+        si = slice(1, GR.nx + 1)
+        sj = slice(2, GR.ny + 1) if n == 'dVFLXdt' else slice(1, GR.ny + 1)
+        np.testing.assert_array_equal(got[si, sj], ref[n][si, sj], err_msg='%s (%d bands)' % (n, nbands))
+        if n in ('COLP', 'UWIND', 'VWIND', 'POTT'):   # halos of the state too
+            np.testing.assert_array_equal(got, ref[n], err_msg='%s incl. halos' % n)
+    for c in cores:
+        c.close()
+
+
+def test_two_process_gloo_bands_equal_single(tmp_path):
+    """bench.py-style launch: 2 ranks share the one GPU, exchange through torch.distributed."""
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+    out = tmp_path / 'bands.npz'
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0', DYCORE_BANDS_BACKEND='gloo', DYCORE_BANDS_ONE_GPU='1')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
+           '--master-addr', '127.0.0.1', '--master-port', str(port),
+           os.path.join(ROOT, 'tests', 'band_worker.py'), str(out)]
+    r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    GR, state = _initial_state(4, 8, 0)
+    ref = _single(GR, state, 0, 3)
+    z = np.load(out)
+    for n in ('COLP', 'UWIND', 'VWIND', 'POTT'):
+        np.testing.assert_array_equal(z[n], ref[n], err_msg=n)

@@ -50,19 +50,27 @@ def parse():
 
 
 def host_cores():
-    """CPU cores this process may really use: the cgroup quota when there is one (a GPU box
-    shares its host; the affinity mask shows every core of the machine), else the affinity."""
-    n = len(os.sched_getaffinity(0))
-    try:
-        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()[:2]
-        if quota != 'max':
-            n = min(n, max(1, int(int(quota) / int(period))))
-    except Exception:
-        pass
+    """Threads for the CPU baseline: the cgroup CPU quota when one is set, else the affinity
+    mask, capped at 16 -- a one-GPU box owns a 16-core share of its host although the mask
+    shows every core of the machine.  DYCORE_CPU_THREADS overrides."""
     env = os.environ.get('DYCORE_CPU_THREADS')
     if env:
-        n = int(env)
-    return min(n, 64) if n > 64 else n
+        return int(env)
+    n = len(os.sched_getaffinity(0))
+    for path in ('/sys/fs/cgroup/cpu.max', '/sys/fs/cgroup/cpu/cpu.cfs_quota_us'):
+        try:
+            txt = open(path).read().split()
+            if path.endswith('cpu.max'):
+                if txt[0] != 'max':
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0])
+                per = int(open('/sys/fs/cgroup/cpu/cpu.cfs_period_us').read())
+                if q > 0:
+                    n = min(n, max(1, q // per))
+        except Exception:
+            pass
+    return min(n, 16)
 
 
 def cpu_baseline(GR, state, budget_s):

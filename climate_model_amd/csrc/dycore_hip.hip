@@ -8,6 +8,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <string>
@@ -16,6 +17,7 @@
 
 #include "dycore_common.h"
 #include "kernels_stage.h"
+#include "kernels_fused.h"
 
 using namespace dyc;
 
@@ -85,12 +87,12 @@ constexpr int kNGrid = sizeof(kGrid) / sizeof(kGrid[0]);
 
 // kernels tracked by the profiler
 enum KernelId {
-    K_CONTINUITY = 0, K_PREPARE, K_UFLX, K_VFLX, K_POTT, K_EULER, K_DIAG, K_RHO, K_EXCHANGE, K_COPY, K_HALO,
+    K_CONTINUITY = 0, K_PREPARE, K_UFLX, K_VFLX, K_POTT, K_EULER, K_DIAG, K_RHO, K_EXCHANGE, K_COPY, K_HALO, K_MOM_FUSED,
     K_COUNT
 };
 const char *kKernelNames[K_COUNT] = {
     "k_continuity", "k_prepare", "k_uflx_tendency", "k_vflx_tendency", "k_pott_tendency",
-    "k_euler_forward", "k_primary_diag", "k_diag_rho", "k_exchange_bc", "copy_field", "k_rows",
+    "k_euler_forward", "k_primary_diag", "k_diag_rho", "k_exchange_bc", "copy_field", "k_rows", "k_momentum_fused",
 };
 
 struct ProfRec { int kid; hipEvent_t a, b; };
@@ -108,6 +110,7 @@ struct dycore {
     double *stage = nullptr;        // staging buffer for the layout adaptor
     size_t stage_elems = 0;
     int grid_set = 0;
+    bool fused = true;              // production kernels in dycore_step_matsuno (DYCORE_FUSED=0: stage kernels)
     // profiler
     bool prof = false;
     std::vector<ProfRec> recs;
@@ -253,6 +256,16 @@ int do_copy(dycore *h, double *dst, const double *src, size_t elems)
     return 0;
 }
 
+int do_momentum_fused(dycore *h, const Ptrs &p)
+{
+    Scope s(h, K_MOM_FUSED);
+    const int gbx = (h->g.nx + TI - 1) / TI, gby = (h->g.ny + FTJ - 1) / FTJ;
+    const int nblk = gbx * gby;
+    hipLaunchKernelGGL(k_momentum_fused, dim3(8 * ((nblk + 7) / 8)), dim3(TI, FTJ), 0, h->stream,
+                       h->g, p, gbx, gby, h->g.pole_s ? 2 : 1);
+    return launch_check("k_momentum_fused");
+}
+
 int do_momentum(dycore *h, const Ptrs &p)
 {
     int rc;
@@ -302,7 +315,7 @@ int substep_part(dycore *h, double dt, int sub, int part)
     case 0:                         // -> needs UFLX, VFLX, WWIND, COLP_NEW halo rows afterwards
         return do_continuity(h, q, dt);
     case 1:
-        if ((rc = do_momentum(h, q))) return rc;
+        if ((rc = (h->fused && !h->g.i_turb) ? do_momentum_fused(h, q) : do_momentum(h, q))) return rc;
         if ((rc = do_pott(h, q))) return rc;
         // COLP <- COLP_NEW (dyn_matsuno.py:64-67), then the Euler step writes p.UWIND/VWIND/POTT
         if ((rc = do_copy(h, p.COLP, p.COLP_NEW, (size_t)h->g.plane))) return rc;
@@ -357,6 +370,7 @@ int dycore_create(const DycoreConfig *cfg, dycore_t **out)
     g.i_turb = cfg->i_turb != 0; g.i_rad = cfg->i_radiation != 0;
     g.pair_top = cfg->pair_top;
     memset(&h->p, 0, sizeof h->p);
+    if (const char *e = getenv("DYCORE_FUSED")) h->fused = atoi(e) != 0;
     if (cfg->stream) h->stream = (hipStream_t)cfg->stream;
     else {
         hipError_t e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);

@@ -1,0 +1,237 @@
+// kernels_fused.h -- the production kernels of dycore_step_matsuno (dry dycore).
+//
+// k_momentum_fused : dyn_UVFLX_prepare.py:249-439 + dyn_UFLX.py:339-434 + dyn_VFLX.py:322-408
+//                    in one pass.  The eight Arakawa-C fluxes B,C,D,E,R,Q,S,T and the
+//                    interface products WWIND*U, WWIND*V are never written to HBM: they are
+//                    re-derived per thread from UFLX/VFLX/WWIND tiles that the workgroup
+//                    stages through LDS once per level (3x3 halo, and one more column /
+//                    row for the radius-2 composite stencil).  HBM traffic per launch:
+//                    9 reads + 2 writes instead of the 41 passes of the three stage kernels.
+//
+// Mapping: lane <-> longitude i (64 per wavefront), threadIdx.y <-> latitude row, k loop in
+// the thread; one workgroup = 64 x FTJ columns.  Tiles are (FTJ+3) rows x 68 columns of
+// doubles, rows 512-B+ apart, read with conflict-free ds_read_b64 (consecutive lanes ->
+// consecutive doubles).  Workgroups are dealt to the XCDs in contiguous latitude bands so
+// that the halo rows two workgroups share are served by one L2.
+#pragma once
+#include "dycore_common.h"
+#include "kernels_stage.h"
+
+namespace dyc {
+
+constexpr int FTJ = 8;                 // rows per workgroup
+constexpr int FTW = 68;                // tile width: i-1 .. i+2 for 64 lanes (67), padded
+constexpr int FTH = FTJ + 3;           // tile height: j-1 .. j+2
+constexpr int FTN = FTW * FTH;         // doubles per tile
+constexpr int FNT = TI * FTJ;          // threads per workgroup
+constexpr int FNF = 9;                 // staged fields
+
+// XCD-aware workgroup order: hardware deals workgroup b to XCD b % 8; give every XCD a
+// contiguous chunk of the (bx fastest, by slowest) tile order.  Pure speed; any placement
+// is correct.
+__device__ __forceinline__ bool xcd_tile(int gbx, int gby, int &bx, int &by)
+{
+    const int nblk = gbx * gby;
+    const int b = blockIdx.x;
+    const int chunk = (nblk + 7) / 8;
+    const int lin = (b % 8) * chunk + b / 8;
+    if (lin >= nblk) return false;
+    bx = lin % gbx;
+    by = lin / gbx;
+    return true;
+}
+
+__global__ __launch_bounds__(FNT) void k_momentum_fused(Geo g, Ptrs p, int gbx, int gby, int jv_lo)
+{
+    __shared__ double sm[FNF][FTN];
+    int bx, by;
+    if (!xcd_tile(gbx, gby, bx, by)) return;
+    const int tx = threadIdx.x, ty = threadIdx.y;
+    const int tid = ty * TI + tx;
+    const int i0 = bx * TI + 1, j0 = by * FTJ + 1;
+    const int i = i0 + tx, j = j0 + ty;
+    const int P = g.P;
+    const bool active = (i <= g.nx) && (j <= g.ny);
+
+    // tile element(s) this thread stages: e0 = tid, e1 = tid + FNT
+    const int e0 = tid, e1 = tid + FNT;
+    const bool has1 = e1 < FTN;
+    int goff0, goff1 = 0;
+    {
+        int r = e0 / FTW, c = e0 - r * FTW;
+        int gi = min(i0 - 1 + c, P - 1), gj = min(j0 - 1 + r, g.NJ - 1);
+        goff0 = gj * P + gi;
+        if (has1) {
+            r = e1 / FTW; c = e1 - r * FTW;
+            gi = min(i0 - 1 + c, P - 1); gj = min(j0 - 1 + r, g.NJ - 1);
+            goff1 = gj * P + gi;
+        }
+    }
+    const double *src[FNF] = {p.UFLX, p.VFLX, p.UWIND, p.VWIND, p.WWIND, p.PHI, p.POTT, p.PVTF, p.PVTFVB};
+    // WWIND and PVTFVB are staged at interface k+1
+    const int kofs[FNF] = {0, 0, 0, 0, 1, 0, 0, 0, 1};
+    enum { S_UF = 0, S_VF, S_UW, S_VW, S_W, S_PHI, S_POTT, S_PVTF, S_PVB };
+
+    // ---- per-column (2-D) quantities ----
+    const size_t c = at2(g, active ? i : 1, active ? j : 1);
+    const int jg = j + g.joff;
+    const bool lo = (jg == 1), hi = (jg == g.ny_global);
+    const bool v_on = active && (j >= jv_lo);            // dVFLXdt row owned and not a pole
+    double ca[3][3];                                     // COLP_NEW * A at (i+a-1, j+b-1)
+#pragma unroll
+    for (int b = 0; b < 3; b++)
+#pragma unroll
+        for (int a = 0; a < 3; a++) {
+            const size_t q2 = c + (b - 1) * P + (a - 1);
+            ca[b][a] = p.COLP_NEW[q2] * p.A[q2];
+        }
+    const double colp = p.COLP[c], colp_im1 = p.COLP[c - 1], colp_jm1 = p.COLP[c - P];
+    const double corf_is = p.corf_is[c], lat_is = p.lat_is_rad[c];
+    const double cos_is = cos(lat_is), sin_is = sin(lat_is);
+    const double corf = p.corf[c], corf_jm1 = p.corf[c - P];
+    const double lat = p.lat_rad[c], lat_jm1 = p.lat_rad[c - P];
+    const double cos_c = cos(lat), sin_c = sin(lat), cos_jm1 = cos(lat_jm1), sin_jm1 = sin(lat_jm1);
+    const double dlon = p.dlon_rad[c], dlat = p.dlat_rad[c], dyis = p.dyis[c], dxjs = p.dxjs[c];
+
+    const int lx = tx + 1, ly = ty + 1;                  // own cell inside the tile
+#define SM(f, a, b) sm[f][(ly + (b)) * FTW + (lx + (a))]
+
+    double wu_k = 0.0, wv_k = 0.0;                       // interface products at k (0 at the top)
+    double u_k = active ? p.UWIND[c] : 0.0, v_k = active ? p.VWIND[c] : 0.0;
+    double pvb_k = p.PVTFVB[c], pvb_im1_k = p.PVTFVB[c - 1], pvb_jm1_k = p.PVTFVB[c - P];
+
+    for (int k = 0; k < g.nz; k++) {
+        // ---- stage the nine tiles of this level ----
+        double r0[FNF], r1[FNF];
+#pragma unroll
+        for (int f = 0; f < FNF; f++) {
+            const double *s = src[f] + (size_t)(k + kofs[f]) * g.plane;
+            r0[f] = s[goff0];
+            r1[f] = has1 ? s[goff1] : 0.0;
+        }
+        // next level's own-cell winds (vertical interpolation to interface k+1)
+        const bool last = (k == g.nz - 1);
+        const size_t qn = c + (size_t)(last ? k : k + 1) * g.plane;
+        const double u_kp1 = p.UWIND[qn], v_kp1 = p.VWIND[qn];
+        __syncthreads();                                  // previous level fully consumed
+#pragma unroll
+        for (int f = 0; f < FNF; f++) {
+            sm[f][e0] = r0[f];
+            if (has1) sm[f][e1] = r1[f];
+        }
+        __syncthreads();
+
+        if (active) {
+            const size_t q = c + (size_t)k * g.plane;
+            const double ds = p.dsigma[k];
+            // ---- UFLX (i-1..i+2, j-1..j+1) and VFLX (i-1..i+1, j-1..j+2) neighbourhoods ----
+            double uf[3][4], vf[4][3];
+#pragma unroll
+            for (int b = 0; b < 3; b++)
+#pragma unroll
+                for (int a = 0; a < 4; a++) uf[b][a] = SM(S_UF, a - 1, b - 1);
+#pragma unroll
+            for (int b = 0; b < 4; b++)
+#pragma unroll
+                for (int a = 0; a < 3; a++) vf[b][a] = SM(S_VF, a - 1, b - 1);
+#define UF(a, b) uf[(b) + 1][(a) + 1]
+#define VF(a, b) vf[(b) + 1][(a) + 1]
+            // wind neighbourhoods
+            double uw[3][3], vw[3][3];
+#pragma unroll
+            for (int b = 0; b < 3; b++)
+#pragma unroll
+                for (int a = 0; a < 3; a++) { uw[b][a] = SM(S_UW, a - 1, b - 1); vw[b][a] = SM(S_VW, a - 1, b - 1); }
+#define U(a, b) uw[(b) + 1][(a) + 1]
+#define V(a, b) vw[(b) + 1][(a) + 1]
+            // ---- interface k+1: WWIND*U, WWIND*V (dyn_functions.py:211-270) ----
+            double wu_kp1 = 0.0, wv_kp1 = 0.0;
+            if (!last) {
+                const double ds1 = p.dsigma[k + 1];
+#define WT(a, b) (ca[(b) + 1][(a) + 1] * SM(S_W, a, b))
+#define WT2(a, b) (2.0 * ca[(b) + 1][(a) + 1] * SM(S_W, a, b))
+                double s;
+                if (lo) s = 0.25 * (WT(-1, 1) + WT(0, 1) + WT(-1, 0) + WT(0, 0));
+                else if (hi) s = 0.25 * (WT(-1, 0) + WT(0, 0) + WT(-1, -1) + WT(0, -1));
+                else s = 0.125 * (WT(-1, 1) + WT(0, 1) + WT2(-1, 0) + WT2(0, 0) + WT(-1, -1) + WT(0, -1));
+                wu_kp1 = s * ((ds1 * u_k + ds * u_kp1) / (ds1 + ds));
+                const double sv = 0.125 * (WT(1, -1) + WT(1, 0) + WT2(0, -1) + WT2(0, 0) + WT(-1, -1) + WT(-1, 0));
+                wv_kp1 = sv * ((ds1 * v_k + ds * v_kp1) / (ds1 + ds));
+#undef WT
+#undef WT2
+            }
+            const double svb = p.sigma_vb[k], svb1 = p.sigma_vb[k + 1];
+            const double dif = p.UVFLX_dif_coef[k];
+            const double pvb_kp1 = SM(S_PVB, 0, 0), pvb_im1_kp1 = SM(S_PVB, -1, 0), pvb_jm1_kp1 = SM(S_PVB, 0, -1);
+            const double phi = SM(S_PHI, 0, 0), pott = SM(S_POTT, 0, 0), pvtf = SM(S_PVTF, 0, 0);
+
+            // =============================== dUFLXdt ===============================
+            {
+                double bflx = 1.0 / 12.0 * (UF(0, -1) + UF(1, -1) + 2.0 * (UF(0, 0) + UF(1, 0)) + UF(0, 1) + UF(1, 1));
+                double bflx_im1 = 1.0 / 12.0 * (UF(-1, -1) + UF(0, -1) + 2.0 * (UF(-1, 0) + UF(0, 0)) + UF(-1, 1) + UF(0, 1));
+                double cflx = 1.0 / 12.0 * (VF(-1, -1) + VF(0, -1) + 2.0 * (VF(-1, 0) + VF(0, 0)) + VF(-1, 1) + VF(0, 1));
+                double cflx_jp1 = 1.0 / 12.0 * (VF(-1, 0) + VF(0, 0) + 2.0 * (VF(-1, 1) + VF(0, 1)) + VF(-1, 2) + VF(0, 2));
+                double dflx_im1 = 1.0 / 24.0 * (VF(-1, -1) + 2.0 * VF(-1, 0) + VF(-1, 1) + UF(-1, -1) + UF(-1, 0) + UF(0, -1) + UF(0, 0));
+                double dflx_jp1 = 1.0 / 24.0 * (VF(0, 0) + 2.0 * VF(0, 1) + VF(0, 2) + UF(0, 0) + UF(0, 1) + UF(1, 0) + UF(1, 1));
+                double eflx = 1.0 / 24.0 * (VF(0, -1) + 2.0 * VF(0, 0) + VF(0, 1) - UF(0, -1) - UF(0, 0) - UF(1, -1) - UF(1, 0));
+                double eflx_im1_jp1 = 1.0 / 24.0 * (VF(-1, 0) + 2.0 * VF(-1, 1) + VF(-1, 2) - UF(-1, 0) - UF(-1, 1) - UF(0, 0) - UF(0, 1));
+                if (lo) { dflx_im1 = 0.0; cflx = 0.0; eflx = 0.0; }
+                if (hi) { dflx_jp1 = 0.0; cflx_jp1 = 0.0; eflx_im1_jp1 = 0.0; }
+                const double u = U(0, 0), u_im1 = U(-1, 0), u_ip1 = U(1, 0);
+                double t = 0.0;
+                t = t + (+bflx_im1 * (u_im1 + u) / 2.0 - bflx * (u + u_ip1) / 2.0
+                         + cflx * (U(0, -1) + u) / 2.0 - cflx_jp1 * (u + U(0, 1)) / 2.0
+                         + dflx_im1 * (U(-1, -1) + u) / 2.0 - dflx_jp1 * (u + U(1, 1)) / 2.0
+                         + 1.0 * (+eflx * (U(1, -1) + u) / 2.0 - eflx_im1_jp1 * (u + U(-1, 1)) / 2.0));
+                t = t + (wu_k - wu_kp1) / ds;
+                t = t + CON_RE * dlon * dlat / 2.0 *
+                            (colp_im1 * (V(-1, 0) + V(-1, 1)) / 2.0 * (corf_is * CON_RE * cos_is + (u_im1 + u) / 2.0 * sin_is) +
+                             colp * (V(0, 0) + V(0, 1)) / 2.0 * (corf_is * CON_RE * cos_is + (u + u_ip1) / 2.0 * sin_is));
+                t = t + pre_grad(phi, SM(S_PHI, -1, 0), colp, colp_im1, pott, SM(S_POTT, -1, 0),
+                                 pvtf, SM(S_PVTF, -1, 0), pvb_k, pvb_im1_k, pvb_im1_kp1, pvb_kp1,
+                                 ds, svb, svb1, dyis);
+                if (dif > 0.0)
+                    t = t + dif * (UF(-1, 0) + UF(1, 0) + UF(0, -1) + UF(0, 1) - 4.0 * UF(0, 0));
+                p.dUFLXdt[q] = t;
+            }
+            // =============================== dVFLXdt ===============================
+            if (v_on) {
+                const double rflx = 1.0 / 12.0 * (VF(-1, 0) + VF(-1, 1) + 2.0 * (VF(0, 0) + VF(0, 1)) + VF(1, 0) + VF(1, 1));
+                const double rflx_jm1 = 1.0 / 12.0 * (VF(-1, -1) + VF(-1, 0) + 2.0 * (VF(0, -1) + VF(0, 0)) + VF(1, -1) + VF(1, 0));
+                const double qflx = 1.0 / 12.0 * (UF(-1, -1) + UF(-1, 0) + 2.0 * (UF(0, -1) + UF(0, 0)) + UF(1, -1) + UF(1, 0));
+                const double qflx_ip1 = 1.0 / 12.0 * (UF(0, -1) + UF(0, 0) + 2.0 * (UF(1, -1) + UF(1, 0)) + UF(2, -1) + UF(2, 0));
+                const double sflx_jm1 = 1.0 / 24.0 * (VF(-1, -1) + VF(-1, 0) + VF(0, -1) + VF(0, 0) + UF(-1, -1) + 2.0 * UF(0, -1) + UF(1, -1));
+                const double sflx_ip1 = 1.0 / 24.0 * (VF(0, 0) + VF(0, 1) + VF(1, 0) + VF(1, 1) + UF(0, 0) + 2.0 * UF(1, 0) + UF(2, 0));
+                const double tflx = 1.0 / 24.0 * (VF(-1, 0) + VF(-1, 1) + VF(0, 0) + VF(0, 1) - UF(-1, 0) - 2.0 * UF(0, 0) - UF(1, 0));
+                const double tflx_ip1_jm1 = 1.0 / 24.0 * (VF(0, -1) + VF(0, 0) + VF(1, -1) + VF(1, 0) - UF(0, -1) - 2.0 * UF(1, -1) - UF(2, -1));
+                const double v = V(0, 0);
+                double t = 0.0;
+                t = t + (+rflx_jm1 * (V(0, -1) + v) / 2.0 - rflx * (v + V(0, 1)) / 2.0
+                         + qflx * (V(-1, 0) + v) / 2.0 - qflx_ip1 * (v + V(1, 0)) / 2.0
+                         + sflx_jm1 * (V(-1, -1) + v) / 2.0 - sflx_ip1 * (v + V(1, 1)) / 2.0
+                         + -1.0 * (+tflx * (V(-1, 1) + v) / 2.0 - tflx_ip1_jm1 * (v + V(1, -1)) / 2.0));
+                t = t + (wv_k - wv_kp1) / ds;
+                const double ub_jm1 = (U(0, -1) + U(1, -1)) / 2.0, ub = (U(0, 0) + U(1, 0)) / 2.0;
+                t = t + -CON_RE * dlon * dlat / 2.0 *
+                            (colp_jm1 * ub_jm1 * (corf_jm1 * CON_RE * cos_jm1 + ub_jm1 * sin_jm1) +
+                             colp * ub * (corf * CON_RE * cos_c + ub * sin_c));
+                t = t + pre_grad(phi, SM(S_PHI, 0, -1), colp, colp_jm1, pott, SM(S_POTT, 0, -1),
+                                 pvtf, SM(S_PVTF, 0, -1), pvb_k, pvb_jm1_k, pvb_jm1_kp1, pvb_kp1,
+                                 ds, svb, svb1, dxjs);
+                if (dif > 0.0)
+                    t = t + dif * (VF(-1, 0) + VF(1, 0) + VF(0, -1) + VF(0, 1) - 4.0 * VF(0, 0));
+                p.dVFLXdt[q] = t;
+            }
+#undef UF
+#undef VF
+#undef U
+#undef V
+            wu_k = wu_kp1; wv_k = wv_kp1;
+            pvb_k = pvb_kp1; pvb_im1_k = pvb_im1_kp1; pvb_jm1_k = pvb_jm1_kp1;
+        }
+        u_k = u_kp1; v_k = v_kp1;
+    }
+#undef SM
+}
+
+}  // namespace dyc

@@ -94,6 +94,7 @@ class BandHalo:
     def __init__(self, core, ny, has_south, has_north):
         self.core, self.ny = core, ny
         self.has_south, self.has_north = has_south, has_north
+        self._resolved = {}
         self.plan = {}
         for ph in ('A', 'B'):
             sn = [f for f, _ in SEND_NORTH[ph]]
@@ -108,6 +109,18 @@ class BandHalo:
     def sizes(self, ph):
         p = self.plan[ph]
         return {k: self.core.rows_size(p[k][0]) for k in p}
+
+    def resolved(self, ph, sub):
+        """The plan with state-field names mapped to the buffer the given substep wrote
+        (the fused library step keeps the predictor state in *_EST scratch fields)."""
+        key = (ph, sub)
+        if key not in self._resolved:
+            fn = getattr(self.core, 'substep_field', None)
+            out = {}
+            for k, (names, rows) in self.plan[ph].items():
+                out[k] = ([fn(sub, n) if (fn and ph == 'B') else n for n in names], rows)
+            self._resolved[key] = out
+        return self._resolved[key]
 
 
 class _TorchBuffers:
@@ -133,9 +146,9 @@ class DistributedBands:
         self.bufs = _TorchBuffers(self.halo, device).buf
         self.staged = dist.get_backend(group) != 'nccl' and str(device) != 'cpu'
 
-    def exchange(self, ph):
+    def exchange(self, ph, sub=1):
         import torch
-        dist, p, b = self.dist, self.halo.plan[ph], self.bufs[ph]
+        dist, p, b = self.dist, self.halo.resolved(ph, sub), self.bufs[ph]
         core = self.core
         if self.north is not None:
             core.pack_rows(*p['send_north'], b['send_north'].data_ptr())
@@ -170,9 +183,9 @@ class DistributedBands:
             core.step_begin(with_rho)
             for sub in (0, 1):
                 core.substep_part(dt, sub, 0)
-                self.exchange('A')
+                self.exchange('A', sub)
                 core.substep_part(dt, sub, 1)
-                self.exchange('B')
+                self.exchange('B', sub)
                 core.substep_part(dt, sub, 2)
 
 
@@ -186,10 +199,10 @@ class LocalBands:
                       for r, c in enumerate(cores)]
         self.bufs = [_TorchBuffers(h, device).buf for h in self.halos]
 
-    def exchange(self, ph):
+    def exchange(self, ph, sub=1):
         n = len(self.cores)
         for r in range(n):
-            p, b = self.halos[r].plan[ph], self.bufs[r][ph]
+            p, b = self.halos[r].resolved(ph, sub), self.bufs[r][ph]
             if r < n - 1:
                 self.cores[r].pack_rows(*p['send_north'], b['send_north'].data_ptr())
             if r > 0:
@@ -197,7 +210,7 @@ class LocalBands:
         for c in self.cores:
             c.sync()
         for r in range(n):
-            p, b = self.halos[r].plan[ph], self.bufs[r][ph]
+            p, b = self.halos[r].resolved(ph, sub), self.bufs[r][ph]
             if r < n - 1:
                 b['recv_north'].copy_(self.bufs[r + 1][ph]['send_south'])
             if r > 0:
@@ -205,7 +218,7 @@ class LocalBands:
         import torch
         torch.cuda.synchronize()
         for r in range(n):
-            p, b = self.halos[r].plan[ph], self.bufs[r][ph]
+            p, b = self.halos[r].resolved(ph, sub), self.bufs[r][ph]
             if r < n - 1:
                 self.cores[r].unpack_rows(*p['recv_north'], b['recv_north'].data_ptr())
             if r > 0:
@@ -218,10 +231,10 @@ class LocalBands:
             for sub in (0, 1):
                 for c in self.cores:
                     c.substep_part(dt, sub, 0)
-                self.exchange('A')
+                self.exchange('A', sub)
                 for c in self.cores:
                     c.substep_part(dt, sub, 1)
-                self.exchange('B')
+                self.exchange('B', sub)
                 for c in self.cores:
                     c.substep_part(dt, sub, 2)
 

@@ -39,6 +39,7 @@ struct Ptrs {
     double *COLP, *COLP_OLD, *COLP_NEW, *dCOLPdt, *HSURF;
     // 3-D
     double *UWIND, *UWIND_OLD, *VWIND, *VWIND_OLD, *WWIND;
+    double *UWIND_EST, *VWIND_EST, *POTT_EST;   // predictor state of the fused step (library scratch)
     double *POTT, *POTT_OLD, *POTTVB;
     double *UFLX, *VFLX, *FLXDIV;
     double *BFLX, *CFLX, *DFLX, *EFLX, *RFLX, *QFLX, *SFLX, *TFLX;
@@ -61,37 +62,6 @@ __device__ __forceinline__ size_t at(const Geo &g, int i, int j, int k)
 __device__ __forceinline__ size_t at2(const Geo &g, int i, int j)
 {
     return (size_t)j * (size_t)g.P + (size_t)i;
-}
-
-// ---- stores that also refresh the lateral halo (misc_boundaries.py:22-42 fused into the
-// producing kernel).  The thread that owns interior cell (i,j) writes every halo image of
-// that cell; halo cells have exactly one owner, so there is no race and no second pass.
-// Zonal: periodic (i = nx -> 0, 1 -> nx+1, and 2 -> nx+2 for x-staggered fields).
-__device__ __forceinline__ void put_row(double *row, const Geo &g, int i, double v, int stgx)
-{
-    row[i] = v;
-    if (i == g.nx) row[0] = v;
-    if (i == 1) row[g.nx + 1] = v;
-    if (stgx && i == 2) row[g.nx + 2] = v;
-}
-// y-unstaggered field: wall rows copy their neighbour (F[:,0]=F[:,1], F[:,ny+1]=F[:,ny]),
-// only where the band touches the wall.
-__device__ __forceinline__ void put_c(double *F, const Geo &g, int i, int j, int k, double v, int stgx)
-{
-    double *pl = F + (size_t)k * (size_t)g.plane;
-    put_row(pl + (size_t)j * g.P, g, i, v, stgx);
-    if (j == 1 && g.pole_s) put_row(pl, g, i, v, stgx);
-    if (j == g.ny && g.pole_n) put_row(pl + (size_t)(g.ny + 1) * g.P, g, i, v, stgx);
-}
-// y-staggered field (x-unstaggered), j in [1, ny+1]: rows 0,1,nys,nys+1 are zero at the walls.
-__device__ __forceinline__ void put_s(double *F, const Geo &g, int i, int j, int k, double v)
-{
-    double *pl = F + (size_t)k * (size_t)g.plane;
-    const bool s = (j == 1 && g.pole_s), n = (j == g.ny + 1 && g.pole_n);
-    if (s || n) v = 0.0;
-    put_row(pl + (size_t)j * g.P, g, i, v, 0);
-    if (s) put_row(pl, g, i, 0.0, 0);
-    if (n) put_row(pl + (size_t)(g.ny + 2) * g.P, g, i, 0.0, 0);
 }
 
 }  // namespace dyc

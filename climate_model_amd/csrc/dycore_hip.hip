@@ -10,6 +10,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <initializer_list>
 #include <limits>
 #include <string>
 #include <unordered_map>
@@ -57,6 +58,7 @@ const FieldDesc kFields[] = {
     F_(COLP, 0, 0, 1), F_(COLP_OLD, 0, 0, 1), F_(COLP_NEW, 0, 0, 1), F_(dCOLPdt, 0, 0, 1), F_(HSURF, 0, 0, 1),
     F_(UWIND, 1, 0, 0), F_(UWIND_OLD, 1, 0, 0), F_(VWIND, 0, 1, 0), F_(VWIND_OLD, 0, 1, 0), F_(WWIND, 0, 0, -1),
     F_(POTT, 0, 0, 0), F_(POTT_OLD, 0, 0, 0), F_(POTTVB, 0, 0, -1),
+    F_(UWIND_EST, 1, 0, 0), F_(VWIND_EST, 0, 1, 0), F_(POTT_EST, 0, 0, 0),
     F_(UFLX, 1, 0, 0), F_(VFLX, 0, 1, 0), F_(FLXDIV, 0, 0, 0),
     F_(BFLX, 0, 0, 0), F_(CFLX, 1, 1, 0), F_(DFLX, 0, 1, 0), F_(EFLX, 0, 1, 0),
     F_(RFLX, 0, 0, 0), F_(QFLX, 1, 1, 0), F_(SFLX, 1, 0, 0), F_(TFLX, 1, 0, 0),
@@ -87,12 +89,12 @@ constexpr int kNGrid = sizeof(kGrid) / sizeof(kGrid[0]);
 
 // kernels tracked by the profiler
 enum KernelId {
-    K_CONTINUITY = 0, K_PREPARE, K_UFLX, K_VFLX, K_POTT, K_EULER, K_DIAG, K_RHO, K_EXCHANGE, K_COPY, K_HALO, K_MOM_FUSED,
+    K_CONTINUITY = 0, K_PREPARE, K_UFLX, K_VFLX, K_POTT, K_EULER, K_DIAG, K_RHO, K_EXCHANGE, K_COPY, K_HALO, K_MOM_FUSED, K_POTT_FUSED, K_DIAG_ROWS, K_HALO_MULTI,
     K_COUNT
 };
 const char *kKernelNames[K_COUNT] = {
     "k_continuity", "k_prepare", "k_uflx_tendency", "k_vflx_tendency", "k_pott_tendency",
-    "k_euler_forward", "k_primary_diag", "k_diag_rho", "k_exchange_bc", "copy_field", "k_rows", "k_momentum_fused",
+    "k_euler_forward", "k_primary_diag", "k_diag_rho", "k_exchange_bc", "copy_field", "k_rows", "k_momentum_fused", "k_pott_fused", "k_primary_diag_rows", "k_halo_multi",
 };
 
 struct ProfRec { int kid; hipEvent_t a, b; };
@@ -182,20 +184,50 @@ int launch_check(const char *what)
     return 0;
 }
 
+// lateral halo (misc_boundaries.py:22-42) of up to 12 fields in one launch
+struct HaloSpec { double *ptr; int stgx, stgy, nk; };
+int do_halo(dycore *h, std::initializer_list<HaloSpec> fields)
+{
+    Scope s(h, K_HALO_MULTI);
+    HaloList l;
+    l.n = 0;
+    int maxk = 1, maxcells = 0;
+    for (const HaloSpec &f : fields) {
+        const int e = l.n++;
+        l.base[e] = f.ptr; l.stgx[e] = f.stgx; l.stgy[e] = f.stgy; l.nk[e] = f.nk;
+        if (f.nk > maxk) maxk = f.nk;
+        const int cells = 4 * (h->g.nx + 3) + 3 * (h->g.ny + 1);
+        if (cells > maxcells) maxcells = cells;
+    }
+    if (!l.n) return 0;
+    hipLaunchKernelGGL(k_halo_multi, dim3((maxcells + 255) / 256, maxk, l.n), dim3(256), 0, h->stream, h->g, l);
+    return launch_check("k_halo_multi");
+}
+
 // ---- stage launches -------------------------------------------------------------------
 int do_continuity(dycore *h, const Ptrs &p, double dt)
 {
-    Scope s(h, K_CONTINUITY);
-    hipLaunchKernelGGL(k_continuity, grid_for(h->g, h->g.nx, h->g.ny), dim3(TI, TJ), 0, h->stream, h->g, p, dt);
-    return launch_check("k_continuity");
+    {
+        Scope s(h, K_CONTINUITY);
+        hipLaunchKernelGGL(k_continuity, grid_for(h->g, h->g.nx, h->g.ny), dim3(TI, TJ), 0, h->stream, h->g, p, dt);
+        int rc = launch_check("k_continuity");
+        if (rc) return rc;
+    }
+    const int nz = h->g.nz;
+    return do_halo(h, {{p.UFLX, 1, 0, nz}, {p.VFLX, 0, 1, nz}, {p.WWIND, 0, 0, nz + 1}, {p.COLP_NEW, 0, 0, 1}});
 }
 int do_prepare(dycore *h, const Ptrs &p)
 {
-    Scope s(h, K_PREPARE);
-    dim3 gr = grid_for(h->g, h->g.nx + 1, h->g.ny + 2);      // rows 0..ny+1
-    if (h->g.i_turb) hipLaunchKernelGGL(k_prepare<true>, gr, dim3(TI, TJ), 0, h->stream, h->g, p);
-    else hipLaunchKernelGGL(k_prepare<false>, gr, dim3(TI, TJ), 0, h->stream, h->g, p);
-    return launch_check("k_prepare");
+    {
+        Scope s(h, K_PREPARE);
+        dim3 gr = grid_for(h->g, h->g.nx + 1, h->g.ny + 2);      // rows 0..ny+1
+        if (h->g.i_turb) hipLaunchKernelGGL(k_prepare<true>, gr, dim3(TI, TJ), 0, h->stream, h->g, p);
+        else hipLaunchKernelGGL(k_prepare<false>, gr, dim3(TI, TJ), 0, h->stream, h->g, p);
+        int rc = launch_check("k_prepare");
+        if (rc) return rc;
+    }
+    if (!h->g.i_turb) return 0;     // dyn_org_discretizations.py:212-213
+    return do_halo(h, {{p.KMOM_dUWINDdz, 1, 0, h->g.nz + 1}, {p.KMOM_dVWINDdz, 0, 1, h->g.nz + 1}});
 }
 int do_uflx(dycore *h, const Ptrs &p)
 {
@@ -226,9 +258,14 @@ int do_pott(dycore *h, const Ptrs &p)
 }
 int do_euler(dycore *h, const Ptrs &p, double dt)
 {
-    Scope s(h, K_EULER);
-    hipLaunchKernelGGL(k_euler_forward, grid_for(h->g, h->g.nx, h->g.ny + 1), dim3(TI, TJ), 0, h->stream, h->g, p, dt);
-    return launch_check("k_euler_forward");
+    {
+        Scope s(h, K_EULER);
+        hipLaunchKernelGGL(k_euler_forward, grid_for(h->g, h->g.nx, h->g.ny + 1), dim3(TI, TJ), 0, h->stream, h->g, p, dt);
+        int rc = launch_check("k_euler_forward");
+        if (rc) return rc;
+    }
+    const int nz = h->g.nz;
+    return do_halo(h, {{p.POTT, 0, 0, nz}, {p.VWIND, 0, 1, nz}, {p.UWIND, 1, 0, nz}});
 }
 int do_diag(dycore *h, const Ptrs &p)
 {
@@ -256,14 +293,35 @@ int do_copy(dycore *h, double *dst, const double *src, size_t elems)
     return 0;
 }
 
-int do_momentum_fused(dycore *h, const Ptrs &p)
+// prepare + dUFLXdt + dVFLXdt (+ Euler step of the winds when u_out != nullptr)
+int do_momentum_fused(dycore *h, const Ptrs &p, const double *u_old, const double *v_old,
+                      double *u_out, double *v_out, double dt)
 {
     Scope s(h, K_MOM_FUSED);
     const int gbx = (h->g.nx + TI - 1) / TI, gby = (h->g.ny + FTJ - 1) / FTJ;
     const int nblk = gbx * gby;
-    hipLaunchKernelGGL(k_momentum_fused, dim3(8 * ((nblk + 7) / 8)), dim3(TI, FTJ), 0, h->stream,
-                       h->g, p, gbx, gby, h->g.pole_s ? 2 : 1);
+    const dim3 gr(8 * ((nblk + 7) / 8)), bl(TI, FTJ);
+    const int jv_lo = h->g.pole_s ? 2 : 1;
+    if (u_out)
+        hipLaunchKernelGGL(k_momentum_fused<true>, gr, bl, 0, h->stream, h->g, p, gbx, gby, jv_lo, u_old, v_old, u_out, v_out, dt);
+    else
+        hipLaunchKernelGGL(k_momentum_fused<false>, gr, bl, 0, h->stream, h->g, p, gbx, gby, jv_lo, u_old, v_old, u_out, v_out, dt);
     return launch_check("k_momentum_fused");
+}
+int do_pott_fused(dycore *h, const Ptrs &p, const double *pott_old, double *pott_out, double dt)
+{
+    Scope s(h, K_POTT_FUSED);
+    hipLaunchKernelGGL(k_pott_fused, grid_for(h->g, h->g.nx, h->g.ny), dim3(TI, TJ), 0, h->stream, h->g, p, pott_old, pott_out, dt);
+    return launch_check("k_pott_fused");
+}
+// primary diagnostics on the halo rows a band received from its neighbours
+int do_diag_band_halo(dycore *h, const Ptrs &p)
+{
+    if (h->g.pole_s && h->g.pole_n) return 0;
+    Scope s(h, K_DIAG_ROWS);
+    const int row_a = h->g.pole_s ? -1 : 0, row_b = h->g.pole_n ? -1 : h->g.ny + 1;
+    hipLaunchKernelGGL(k_primary_diag_rows, dim3((h->g.nx + 2 + TI - 1) / TI, 2), dim3(TI), 0, h->stream, h->g, p, row_a, row_b);
+    return launch_check("k_primary_diag_rows");
 }
 
 int do_momentum(dycore *h, const Ptrs &p)
@@ -287,21 +345,33 @@ int do_momentum(dycore *h, const Ptrs &p)
 // (k_euler_forward reads X_OLD and the tendency at the written cell only).
 // The step is cut into parts at the two points where a latitude band needs rows from its
 // neighbours (after continuity, after the Euler step); a single band runs them back to back.
+bool fused_path(const dycore *h) { return h->fused && !h->g.i_turb; }
+
+// Fused (production, dry) scheme -- no time-level swaps: X holds the state S0 at step start
+// through the predictor, X_EST receives the estimate S1, the corrector evaluates on X_EST and
+// overwrites X in place with S2 (it reads X at the own cell only).  X_OLD is not maintained.
+// Staged scheme (turbulence-coupled, or DYCORE_FUSED=0): time levels rotate by pointer swap,
+// after which X_OLD holds S0; the predictor evaluates on X_OLD and writes X, the corrector
+// evaluates on X and overwrites X in place.
 int step_begin(dycore *h, int with_rho)
 {
     int rc;
     Ptrs &p = h->p;
     if (with_rho && (rc = do_rho(h, p))) return rc;
+    if (fused_path(h)) return do_copy(h, p.COLP_OLD, p.COLP, (size_t)h->g.plane);
     std::swap(p.UWIND, p.UWIND_OLD);
     std::swap(p.VWIND, p.VWIND_OLD);
     std::swap(p.POTT, p.POTT_OLD);
     std::swap(p.COLP, p.COLP_OLD);
     return 0;
 }
+// the fields the tendencies of a substep are evaluated on
 Ptrs substep_view(dycore *h, int sub)
 {
     Ptrs q = h->p;
-    if (sub == 0) {                // predictor: the current state IS the *_OLD buffers
+    if (fused_path(h)) {
+        if (sub == 1) { q.UWIND = h->p.UWIND_EST; q.VWIND = h->p.VWIND_EST; q.POTT = h->p.POTT_EST; }
+    } else if (sub == 0) {         // predictor: the current state IS the *_OLD buffers
         q.UWIND = h->p.UWIND_OLD; q.VWIND = h->p.VWIND_OLD; q.POTT = h->p.POTT_OLD; q.COLP = h->p.COLP_OLD;
     }
     return q;
@@ -311,11 +381,35 @@ int substep_part(dycore *h, double dt, int sub, int part)
     int rc;
     Ptrs &p = h->p;
     const Ptrs q = substep_view(h, sub);
+    if (fused_path(h)) {
+        double *u_out = sub == 0 ? p.UWIND_EST : p.UWIND;
+        double *v_out = sub == 0 ? p.VWIND_EST : p.VWIND;
+        double *t_out = sub == 0 ? p.POTT_EST : p.POTT;
+        switch (part) {
+        case 0:                     // -> UFLX, VFLX, WWIND, COLP_NEW halo rows
+            return do_continuity(h, q, dt);
+        case 1: {                   // momentum reads the old diagnostics, so it runs first
+            if ((rc = do_momentum_fused(h, q, p.UWIND, p.VWIND, u_out, v_out, dt))) return rc;
+            if ((rc = do_pott_fused(h, q, p.POTT, t_out, dt))) return rc;
+            const int nz = h->g.nz;
+            if ((rc = do_halo(h, {{u_out, 1, 0, nz}, {v_out, 0, 1, nz}, {t_out, 0, 0, nz}, {p.PVTF, 0, 0, nz},
+                                  {p.PVTFVB, 0, 0, nz + 1}, {p.PHI, 0, 0, nz}, {p.PHIVB, 0, 0, nz + 1},
+                                  {p.POTTVB, 0, 0, nz + 1}}))) return rc;
+            return do_copy(h, p.COLP, p.COLP_NEW, (size_t)h->g.plane);   // -> winds, POTT halo rows
+        }
+        case 2: {
+            Ptrs d = p;
+            d.POTT = t_out;
+            return do_diag_band_halo(h, d);
+        }
+        }
+        return fail(DYCORE_EINVAL, "substep part %d out of range", part);
+    }
     switch (part) {
     case 0:                         // -> needs UFLX, VFLX, WWIND, COLP_NEW halo rows afterwards
         return do_continuity(h, q, dt);
     case 1:
-        if ((rc = (h->fused && !h->g.i_turb) ? do_momentum_fused(h, q) : do_momentum(h, q))) return rc;
+        if ((rc = do_momentum(h, q))) return rc;
         if ((rc = do_pott(h, q))) return rc;
         // COLP <- COLP_NEW (dyn_matsuno.py:64-67), then the Euler step writes p.UWIND/VWIND/POTT
         if ((rc = do_copy(h, p.COLP, p.COLP_NEW, (size_t)h->g.plane))) return rc;
@@ -577,6 +671,17 @@ int dycore_substep_part(dycore_t *h, double dt, int32_t substep, int32_t part)
     if (rc) return rc;
     if (substep < 0 || substep > 1) return fail(DYCORE_EINVAL, "substep must be 0 (estimate) or 1 (final)");
     return substep_part(h, dt, substep, part);
+}
+
+const char *dycore_substep_field(dycore_t *h, int32_t substep, const char *name)
+{
+    if (!h || !name) return nullptr;
+    if (fused_path(h) && substep == 0) {
+        if (!strcmp(name, "UWIND")) return "UWIND_EST";
+        if (!strcmp(name, "VWIND")) return "VWIND_EST";
+        if (!strcmp(name, "POTT")) return "POTT_EST";
+    }
+    return name;
 }
 
 static int rows_op(dycore_t *h, int32_t n, const char *const *names, const int32_t *rows,

@@ -41,7 +41,15 @@ __device__ __forceinline__ bool xcd_tile(int gbx, int gby, int &bx, int &by)
     return true;
 }
 
-__global__ __launch_bounds__(FNT) void k_momentum_fused(Geo g, Ptrs p, int gbx, int gby, int jv_lo)
+// EULER: the pressure-weighted Euler step (dyn_timestep.py:212-297, UWIND/VWIND part) is
+// applied in the same thread -- dUFLXdt/dVFLXdt never reach HBM; u_old/v_old hold the state at
+// step start (read at the own cell only), u_out/v_out receive the new winds (interior cells;
+// k_halo_multi refreshes the lateral halo afterwards).  `p.UWIND/p.VWIND` are the winds the tendencies are evaluated on.
+// In the corrector u_out aliases u_old (in-place update of the own cell), hence no __restrict__.
+template <bool EULER>
+__global__ __launch_bounds__(FNT) void k_momentum_fused(Geo g, Ptrs p, int gbx, int gby, int jv_lo,
+                                                        const double *u_old, const double *v_old,
+                                                        double *u_out, double *v_out, double dt)
 {
     __shared__ double sm[FNF][FTN];
     int bx, by;
@@ -92,6 +100,34 @@ __global__ __launch_bounds__(FNT) void k_momentum_fused(Geo g, Ptrs p, int gbx, 
     const double lat = p.lat_rad[c], lat_jm1 = p.lat_rad[c - P];
     const double cos_c = cos(lat), sin_c = sin(lat), cos_jm1 = cos(lat_jm1), sin_jm1 = sin(lat_jm1);
     const double dlon = p.dlon_rad[c], dlat = p.dlat_rad[c], dyis = p.dyis[c], dxjs = p.dxjs[c];
+    // pressure weights of the Euler step at the u- and v-point: dyn_timestep.py:42-79
+    double ca_is = 1.0, cao_is = 1.0, ca_js = 1.0, cao_js = 1.0;
+    if (EULER) {
+        double co[3][3];                                 // COLP_OLD * A
+#pragma unroll
+        for (int b = 0; b < 3; b++)
+#pragma unroll
+            for (int a = 0; a < 3; a++) {
+                const size_t q2 = c + (b - 1) * P + (a - 1);
+                co[b][a] = p.COLP_OLD[q2] * p.A[q2];
+            }
+#define CA(a, b) ca[(b) + 1][(a) + 1]
+#define CO(a, b) co[(b) + 1][(a) + 1]
+        if (lo) {
+            ca_is = 1.0 / 4.0 * (CA(-1, 1) + CA(0, 1) + CA(-1, 0) + CA(0, 0));
+            cao_is = 1.0 / 4.0 * (CO(-1, 1) + CO(0, 1) + CO(-1, 0) + CO(0, 0));
+        } else if (hi) {
+            ca_is = 1.0 / 4.0 * (CA(-1, -1) + CA(0, -1) + CA(-1, 0) + CA(0, 0));
+            cao_is = 1.0 / 4.0 * (CO(-1, -1) + CO(0, -1) + CO(-1, 0) + CO(0, 0));
+        } else {
+            ca_is = 1.0 / 8.0 * (CA(-1, 1) + CA(0, 1) + 2.0 * CA(-1, 0) + 2.0 * CA(0, 0) + CA(-1, -1) + CA(0, -1));
+            cao_is = 1.0 / 8.0 * (CO(-1, 1) + CO(0, 1) + 2.0 * CO(-1, 0) + 2.0 * CO(0, 0) + CO(-1, -1) + CO(0, -1));
+        }
+        ca_js = 1.0 / 8.0 * (CA(1, -1) + CA(1, 0) + 2.0 * CA(0, -1) + 2.0 * CA(0, 0) + CA(-1, -1) + CA(-1, 0));
+        cao_js = 1.0 / 8.0 * (CO(1, -1) + CO(1, 0) + 2.0 * CO(0, -1) + 2.0 * CO(0, 0) + CO(-1, -1) + CO(-1, 0));
+#undef CA
+#undef CO
+    }
 
     const int lx = tx + 1, ly = ty + 1;                  // own cell inside the tile
 #define SM(f, a, b) sm[f][(ly + (b)) * FTW + (lx + (a))]
@@ -100,6 +136,7 @@ __global__ __launch_bounds__(FNT) void k_momentum_fused(Geo g, Ptrs p, int gbx, 
     double u_k = active ? p.UWIND[c] : 0.0, v_k = active ? p.VWIND[c] : 0.0;
     double pvb_k = p.PVTFVB[c], pvb_im1_k = p.PVTFVB[c - 1], pvb_jm1_k = p.PVTFVB[c - P];
 
+#pragma unroll 1
     for (int k = 0; k < g.nz; k++) {
         // ---- stage the nine tiles of this level ----
         double r0[FNF], r1[FNF];
@@ -192,7 +229,8 @@ __global__ __launch_bounds__(FNT) void k_momentum_fused(Geo g, Ptrs p, int gbx, 
                                  ds, svb, svb1, dyis);
                 if (dif > 0.0)
                     t = t + dif * (UF(-1, 0) + UF(1, 0) + UF(0, -1) + UF(0, 1) - 4.0 * UF(0, 0));
-                p.dUFLXdt[q] = t;
+                if (EULER) u_out[at(g, i, j, k)] = u_old[q] * cao_is / ca_is + dt * t / ca_is;
+                else p.dUFLXdt[q] = t;
             }
             // =============================== dVFLXdt ===============================
             if (v_on) {
@@ -220,7 +258,8 @@ __global__ __launch_bounds__(FNT) void k_momentum_fused(Geo g, Ptrs p, int gbx, 
                                  ds, svb, svb1, dxjs);
                 if (dif > 0.0)
                     t = t + dif * (VF(-1, 0) + VF(1, 0) + VF(0, -1) + VF(0, 1) - 4.0 * VF(0, 0));
-                p.dVFLXdt[q] = t;
+                if (EULER) v_out[at(g, i, j, k)] = v_old[q] * cao_js / ca_js + dt * t / ca_js;
+                else p.dVFLXdt[q] = t;
             }
 #undef UF
 #undef VF
@@ -232,6 +271,81 @@ __global__ __launch_bounds__(FNT) void k_momentum_fused(Geo g, Ptrs p, int gbx, 
         u_k = u_kp1; v_k = v_kp1;
     }
 #undef SM
+}
+
+
+// ------------------------------------------------------------------------------------
+// k_pott_fused: dPOTTdt (dyn_POTT.py:180-216) + Euler step of POTT (dyn_timestep.py:70-79)
+// + primary diagnostics PVTF, PVTFVB, PHI, PHIVB, POTTVB of the NEW state
+// (dyn_diagnostics.py:139-195) in one bottom-up sweep per column.  dPOTTdt never reaches
+// HBM.  `p.POTT` is the field the tendency is evaluated on (5-point neighbourhood);
+// pott_old is the state at step start (own cell only); pott_out gets the new POTT (interior
+// cells; halos of every output by k_halo_multi afterwards).  POTTVB is updated in place: interface k+1 is rewritten only after its old
+// value has been consumed by the vertical advection of levels k+1 and k.
+// Dry dycore only (the turbulence-coupled path uses the stage kernels).
+__global__ __launch_bounds__(TI *TJ) void k_pott_fused(Geo g, Ptrs p, const double *pott_old, double *pott_out, double dt)
+{
+    DYC_IJ(1, 1)
+    if (i > g.nx || j > g.ny) return;
+    const int P = g.P, nz = g.nz;
+    const size_t c = at2(g, i, j);
+    const double colp = p.COLP[c], cnew = p.COLP_NEW[c], cold = p.COLP_OLD[c];
+    const double c_im1 = p.COLP[c - 1], c_ip1 = p.COLP[c + 1], c_jm1 = p.COLP[c - P], c_jp1 = p.COLP[c + P];
+    const double area = p.A[c];
+    // surface interface of the new column
+    double p_kp12 = g.pair_top + p.sigma_vb[nz] * cnew;
+    double pvb_kp1 = pow(p_kp12 / 100000.0, CON_KAPPA);
+    double phivb_kp1 = p.HSURF[c] * CON_G;
+    p.PVTFVB[at(g, i, j, nz)] = pvb_kp1;
+    p.PHIVB[at(g, i, j, nz)] = phivb_kp1;
+    double w_kp1 = p.WWIND[c + (size_t)nz * g.plane];
+    double pvbo_kp1 = p.POTTVB[c + (size_t)nz * g.plane];        // old interface values
+    double pottn_kp1 = 0.0, pvtf_kp1 = 0.0, pottvb_first = 0.0;
+#pragma unroll 1
+    for (int k = nz - 1; k >= 0; k--) {
+        const size_t q = c + (size_t)k * g.plane;
+        const double pt = p.POTT[q];
+        const double p_im1 = p.POTT[q - 1], p_ip1 = p.POTT[q + 1], p_jm1 = p.POTT[q - P], p_jp1 = p.POTT[q + P];
+        const double ds = p.dsigma[k];
+        double t = 0.0;
+        t = t + (+p.UFLX[q] * (p_im1 + pt) / 2.0 - p.UFLX[q + 1] * (pt + p_ip1) / 2.0
+                 + p.VFLX[q] * (p_jm1 + pt) / 2.0 - p.VFLX[q + P] * (pt + p_jp1) / 2.0) / area;
+        double w_k = 0.0, pvbo_k = 0.0;
+        if (k == 0) {
+            t = t + cnew * (-w_kp1 * pvbo_kp1) / ds;
+        } else {
+            w_k = p.WWIND[q];
+            pvbo_k = p.POTTVB[q];
+            t = t + cnew * (+w_k * pvbo_k - w_kp1 * pvbo_kp1) / ds;
+        }
+        const double dif = p.POTT_dif_coef[k];
+        if (dif > 0.0)
+            t = t + dif * (c_im1 * p_im1 + c_ip1 * p_ip1 + c_jm1 * p_jm1 + c_jp1 * p_jp1 - 4.0 * colp * pt);
+        if (g.i_rad) t = t + p.dPOTTdt_RAD[q] * colp;
+        // Euler forward, pressure weighted
+        const double pott = pott_old[q] * cold / cnew + dt * t / cnew;
+        pott_out[at(g, i, j, k)] = pott;
+        // diagnostics of the new column, level k
+        const double p_km12 = g.pair_top + p.sigma_vb[k] * cnew;
+        const double pvb_k = pow(p_km12 / 100000.0, CON_KAPPA);
+        const double pvtf = 1.0 / (1.0 + CON_KAPPA) * (pvb_kp1 * p_kp12 - pvb_k * p_km12) / (p_kp12 - p_km12);
+        const double phi = phivb_kp1 - CON_CP * (pott * (pvtf - pvb_kp1));
+        const double phivb = phi - CON_CP * (pott * (pvb_k - pvtf));
+        p.PVTF[at(g, i, j, k)] = pvtf;
+        p.PVTFVB[at(g, i, j, k)] = pvb_k;
+        p.PHI[at(g, i, j, k)] = phi;
+        p.PHIVB[at(g, i, j, k)] = phivb;
+        if (k < nz - 1) {
+            const double vb = ((pvb_kp1 - pvtf) * pott + (pvtf_kp1 - pvb_kp1) * pottn_kp1) / (pvtf_kp1 - pvtf);
+            p.POTTVB[at(g, i, j, k + 1)] = vb;
+            if (k == nz - 2 && nz > 2) p.POTTVB[at(g, i, j, nz)] = pottn_kp1 - (vb - pottn_kp1);
+            if (k == 0) pottvb_first = vb;
+        }
+        p_kp12 = p_km12; pvb_kp1 = pvb_k; phivb_kp1 = phivb;
+        pottn_kp1 = pott; pvtf_kp1 = pvtf;
+        w_kp1 = w_k; pvbo_kp1 = pvbo_k;
+    }
+    if (nz >= 2) p.POTTVB[at(g, i, j, 0)] = pottn_kp1 - (pottvb_first - pottn_kp1);
 }
 
 }  // namespace dyc

@@ -19,8 +19,9 @@ constexpr int TJ = 4;    // rows per workgroup
     const int j = blockIdx.y * TJ + threadIdx.y + (j0);
 
 // ------------------------------------------------------------------------------------
-// continuity: dyn_continuity.py:170-232 (+ exchange_BC of UFLX, VFLX, WWIND, COLP_NEW,
-// dyn_org_discretizations.py:107-117).  Owned cells i in [1,nx], j in [1,ny].
+// continuity: dyn_continuity.py:170-232.  Owned cells i in [1,nx], j in [1,ny]; the lateral
+// halo of UFLX, VFLX, WWIND, COLP_NEW (dyn_org_discretizations.py:107-117) is refreshed by
+// one k_halo_multi launch afterwards.
 __global__ __launch_bounds__(TI *TJ) void k_continuity(Geo g, Ptrs p, double dt)
 {
     DYC_IJ(1, 1)
@@ -32,7 +33,6 @@ __global__ __launch_bounds__(TI *TJ) void k_continuity(Geo g, Ptrs p, double dt)
     const double dy_i = p.dyis[c], dy_ip1 = p.dyis[c + 1];
     const double dx_j = p.dxjs[c], dx_jp1 = p.dxjs[c + g.P];
     const double area = p.A[c];
-    const bool top_row = (j == g.ny && g.pole_n);
     double sum = 0.0;
     for (int k = 0; k < g.nz; k++) {
         const size_t q = c + (size_t)k * g.plane;
@@ -40,9 +40,8 @@ __global__ __launch_bounds__(TI *TJ) void k_continuity(Geo g, Ptrs p, double dt)
         const double uflx_ip1 = (colp + c_ip1) / 2.0 * p.UWIND[q + 1] * dy_ip1;
         const double vflx_j = (c_jm1 + colp) / 2.0 * p.VWIND[q] * dx_j;
         const double vflx_jp1 = (colp + c_jp1) / 2.0 * p.VWIND[q + g.P] * dx_jp1;
-        put_c(p.UFLX, g, i, j, k, uflx_i, 1);
-        put_s(p.VFLX, g, i, j, k, vflx_j);
-        if (top_row) put_s(p.VFLX, g, i, j + 1, k, 0.0);
+        p.UFLX[at(g, i, j, k)] = uflx_i;
+        p.VFLX[at(g, i, j, k)] = vflx_j;
         const double div = (uflx_ip1 - uflx_i + vflx_jp1 - vflx_j) * p.dsigma[k] / area;
         p.FLXDIV[q] = div;
         sum += div;
@@ -50,14 +49,14 @@ __global__ __launch_bounds__(TI *TJ) void k_continuity(Geo g, Ptrs p, double dt)
     const double dcolpdt = -sum;
     const double colp_new = p.COLP_OLD[c] + dt * dcolpdt;
     p.dCOLPdt[c] = dcolpdt;
-    put_c(p.COLP_NEW, g, i, j, 0, colp_new, 0);
+    p.COLP_NEW[at(g, i, j, 0)] = colp_new;
     // sigma-dot vanishes at the model top and at the surface (io_initial_conditions.py:45-46)
-    put_c(p.WWIND, g, i, j, 0, 0.0, 0);
-    put_c(p.WWIND, g, i, j, g.nz, 0.0, 0);
+    p.WWIND[at(g, i, j, 0)] = 0.0;
+    p.WWIND[at(g, i, j, g.nz)] = 0.0;
     double run = p.FLXDIV[c];
     for (int k = 1; k < g.nz; k++) {
         const double w = -run / colp_new - p.sigma_vb[k] * dcolpdt / colp_new;
-        put_c(p.WWIND, g, i, j, k, w, 0);
+        p.WWIND[at(g, i, j, k)] = w;
         run += p.FLXDIV[c + (size_t)k * g.plane];
     }
 }
@@ -107,8 +106,8 @@ __global__ __launch_bounds__(TI *TJ) void k_prepare(Geo g, Ptrs p)
     if (TURB) {
         // k = 0 and k = nz: never consumed (dyn_UFLX.py:158-167); the reference returns an
         // unassigned local there (dyn_functions.py:310/377) -> 0
-        if (u_ok) { put_c(p.KMOM_dUWINDdz, g, i, j, 0, 0.0, 1); put_c(p.KMOM_dUWINDdz, g, i, j, g.nz, 0.0, 1); }
-        if (v_ok) { put_s(p.KMOM_dVWINDdz, g, i, j, 0, 0.0); put_s(p.KMOM_dVWINDdz, g, i, j, g.nz, 0.0); }
+        if (u_ok) { p.KMOM_dUWINDdz[at(g, i, j, 0)] = 0.0; p.KMOM_dUWINDdz[at(g, i, j, g.nz)] = 0.0; }
+        if (v_ok) { p.KMOM_dVWINDdz[at(g, i, j, 0)] = 0.0; p.KMOM_dVWINDdz[at(g, i, j, g.nz)] = 0.0; }
     }
 
     double u_km1 = 0.0, v_km1 = 0.0;
@@ -157,13 +156,13 @@ __global__ __launch_bounds__(TI *TJ) void k_prepare(Geo g, Ptrs p)
                         alt_km1 = 0.125 * (PHM(0, 2) + PHM(1, 2) + 2.0 * PHM(0, 1) + 2.0 * PHM(1, 1) + PHM(0, 0) + PHM(1, 0)) / CON_G;
                         alt = 0.125 * (PH(0, 2) + PH(1, 2) + 2.0 * PH(0, 1) + 2.0 * PH(1, 1) + PH(0, 0) + PH(1, 0)) / CON_G;
                     }
-                    put_c(p.KMOM_dUWINDdz, g, i, j, k, k6 * ((u_km1 - u_k) / (alt_km1 - alt)), 1);
+                    p.KMOM_dUWINDdz[at(g, i, j, k)] = k6 * ((u_km1 - u_k) / (alt_km1 - alt));
                 }
                 if (v_ok) {
                     const double k6 = 0.125 * (KT(2, 0) + KT(2, 1) + KT2(1, 0) + KT2(1, 1) + KT(0, 0) + KT(0, 1));
                     const double alt_km1 = 0.125 * (PHM(2, 0) + PHM(2, 1) + 2.0 * PHM(1, 0) + 2.0 * PHM(1, 1) + PHM(0, 0) + PHM(0, 1)) / CON_G;
                     const double alt = 0.125 * (PH(2, 0) + PH(2, 1) + 2.0 * PH(1, 0) + 2.0 * PH(1, 1) + PH(0, 0) + PH(0, 1)) / CON_G;
-                    put_s(p.KMOM_dVWINDdz, g, i, j, k, k6 * ((v_km1 - v_k) / (alt_km1 - alt)));
+                    p.KMOM_dVWINDdz[at(g, i, j, k)] = k6 * ((v_km1 - v_k) / (alt_km1 - alt));
                 }
 #undef KT
 #undef KT2
@@ -437,8 +436,9 @@ __global__ __launch_bounds__(TI *TJ) void k_pott_tendency(Geo g, Ptrs p)
 }
 
 // ------------------------------------------------------------------------------------
-// Euler forward with pressure weighting: dyn_timestep.py:212-297 (+ exchange_BC of POTT,
-// VWIND, UWIND: dyn_org_discretizations.py:388-390).  Threads cover i in [1,nx],
+// Euler forward with pressure weighting: dyn_timestep.py:212-297 (the exchange_BC of POTT,
+// VWIND, UWIND, dyn_org_discretizations.py:388-390, follows as one k_halo_multi launch).
+// Threads cover i in [1,nx],
 // j in [1,ny+1]; U and POTT own rows 1..ny, V owns js rows not on a pole.
 // `cur` pointers are the fields being written (UWIND, VWIND, POTT); *_OLD and the
 // tendencies are read at the same cell only, so writing in place is race-free.
@@ -482,12 +482,12 @@ __global__ __launch_bounds__(TI *TJ) void k_euler_forward(Geo g, Ptrs p, double 
     for (int k = 0; k < g.nz; k++) {
         const size_t q = c + (size_t)k * g.plane;
         if (row_c) {
-            put_c(p.UWIND, g, i, j, k, p.UWIND_OLD[q] * cao_is / ca_is + dt * p.dUFLXdt[q] / ca_is, 1);
-            put_c(p.POTT, g, i, j, k, p.POTT_OLD[q] * co / cn + dt * p.dPOTTdt[q] / cn, 0);
+            p.UWIND[at(g, i, j, k)] = p.UWIND_OLD[q] * cao_is / ca_is + dt * p.dUFLXdt[q] / ca_is;
+            p.POTT[at(g, i, j, k)] = p.POTT_OLD[q] * co / cn + dt * p.dPOTTdt[q] / cn;
         }
         if (v_own) {
-            if (!v_pole) put_s(p.VWIND, g, i, j, k, p.VWIND_OLD[q] * cao_js / ca_js + dt * p.dVFLXdt[q] / ca_js);
-            else put_s(p.VWIND, g, i, j, k, 0.0);
+            if (!v_pole) p.VWIND[at(g, i, j, k)] = p.VWIND_OLD[q] * cao_js / ca_js + dt * p.dVFLXdt[q] / ca_js;
+            else p.VWIND[at(g, i, j, k)] = 0.0;
         }
     }
 }
@@ -496,10 +496,8 @@ __global__ __launch_bounds__(TI *TJ) void k_euler_forward(Geo g, Ptrs p, double 
 // primary diagnostics: dyn_diagnostics.py:139-195 (diag_PVTF, diag_PHI, diag_POTTVB) in one
 // bottom-up sweep over the whole array incl. halos (i in [0,nx+1], j in [0,ny+1]).
 // One pow() per interface instead of the reference's two per cell: PVTFVB[k+1] is carried.
-__global__ __launch_bounds__(TI *TJ) void k_primary_diag(Geo g, Ptrs p)
+__device__ __forceinline__ void diag_column(const Geo &g, const Ptrs &p, int i, int j)
 {
-    DYC_IJ(0, 0)
-    if (i > g.nx + 1 || j > g.ny + 1) return;
     const size_t c = at2(g, i, j);
     const int nz = g.nz;
     const double colp = p.COLP[c];
@@ -535,6 +533,22 @@ __global__ __launch_bounds__(TI *TJ) void k_primary_diag(Geo g, Ptrs p)
         pvtf_kp1 = pvtf;
     }
     if (nz >= 2) p.POTTVB[c] = pott_kp1 - (pottvb_first - pott_kp1);   // model top, :187-190
+}
+
+__global__ __launch_bounds__(TI *TJ) void k_primary_diag(Geo g, Ptrs p)
+{
+    DYC_IJ(0, 0)
+    if (i > g.nx + 1 || j > g.ny + 1) return;
+    diag_column(g, p, i, j);
+}
+
+// the same on two rows only: the halo rows a latitude band receives from its neighbours
+__global__ __launch_bounds__(TI) void k_primary_diag_rows(Geo g, Ptrs p, int row_a, int row_b)
+{
+    const int i = blockIdx.x * TI + threadIdx.x;
+    const int j = blockIdx.y == 0 ? row_a : row_b;
+    if (i > g.nx + 1 || j < 0) return;
+    diag_column(g, p, i, j);
 }
 
 // secondary diagnostics, RHO / RHOVB only: dyn_diagnostics.py:199-222
@@ -579,6 +593,50 @@ __global__ void k_exchange_bc(Geo g, double *F, int stgx, int stgy, int nk)
         else if (j == g.ny + 1 && g.pole_n) sj = g.ny;
         if (si != i || sj != j) pl[(size_t)j * g.P + i] = pl[(size_t)sj * g.P + si];
     }
+}
+
+// The same for up to 12 fields in ONE launch, touching halo cells only (the production
+// path: every kernel writes interior cells with plain coalesced stores, then one such launch
+// refreshes the lateral halo of everything it produced).  Part A = wall rows (all columns),
+// part B = the periodic columns of the interior rows.  Rows that belong to a neighbouring
+// latitude band are left alone: they arrive by message, periodic columns included.
+struct HaloList {
+    int n;
+    double *base[12];
+    int stgx[12], stgy[12], nk[12];
+};
+__global__ void k_halo_multi(Geo g, HaloList l)
+{
+    const int e = blockIdx.z, k = blockIdx.y;
+    if (e >= l.n || k >= l.nk[e]) return;
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int stgx = l.stgx[e], stgy = l.stgy[e];
+    const int fnx = g.nx + 2 + stgx;
+    double *pl = l.base[e] + (size_t)k * g.plane;
+    // ---- part A: wall rows ----
+    const int rows_s = g.pole_s ? (stgy ? 2 : 1) : 0, rows_n = g.pole_n ? (stgy ? 2 : 1) : 0;
+    const int nA = (rows_s + rows_n) * fnx;
+    if (t < nA) {
+        const int r = t / fnx, i = t - r * fnx;
+        const int j = r < rows_s ? r : g.ny + 1 + (r - rows_s);
+        if (stgy) { pl[(size_t)j * g.P + i] = 0.0; return; }
+        int si = i;
+        if (i == 0) si = g.nx;
+        else if (i == g.nx + 1) si = 1;
+        else if (stgx && i == g.nx + 2) si = 2;
+        const int sj = (j == 0) ? 1 : g.ny;
+        pl[(size_t)j * g.P + i] = pl[(size_t)sj * g.P + si];
+        return;
+    }
+    // ---- part B: periodic columns of the rows this band owns ----
+    t -= nA;
+    const int jlo = (stgy && g.pole_s) ? 2 : 1, jhi = g.ny;
+    const int nj = jhi - jlo + 1, ncol = 2 + stgx;
+    if (nj <= 0 || t >= ncol * nj) return;
+    const int cidx = t / nj, j = jlo + (t - cidx * nj);
+    const int i = cidx == 0 ? 0 : (cidx == 1 ? g.nx + 1 : g.nx + 2);
+    const int si = cidx == 0 ? g.nx : (cidx == 1 ? 1 : 2);
+    pl[(size_t)j * g.P + i] = pl[(size_t)j * g.P + si];
 }
 
 // ---- layout adaptor: host [i][j][k] (k contiguous) <-> device [k][j][i] ---------------

@@ -52,6 +52,10 @@ FIELD_TABLE = OrderedDict([
     ('POTT_OLD',      (0, 0, 'nz')),
     ('dPOTTdt',       (0, 0, 'nz')),
     ('POTTVB',        (0, 0, 'nzs')),
+    # predictor state of the fused library step (scratch)
+    ('UWIND_EST',     (1, 0, 'nz')),
+    ('VWIND_EST',     (0, 1, 'nz')),
+    ('POTT_EST',      (0, 0, 'nz')),
     # primary diagnostics
     ('PVTF',          (0, 0, 'nz')),
     ('PVTFVB',        (0, 0, 'nzs')),

@@ -33,7 +33,7 @@ ABI_SYMBOLS = [
     'dycore_vflx_tendency', 'dycore_pott_tendency', 'dycore_euler_forward', 'dycore_primary_diag',
     'dycore_secondary_diag_rho', 'dycore_step_matsuno', 'dycore_time_steps',
     'dycore_step_begin', 'dycore_substep_part', 'dycore_rows_size', 'dycore_pack_rows',
-    'dycore_unpack_rows',
+    'dycore_unpack_rows', 'dycore_substep_field',
     'dycore_profile', 'dycore_n_kernels', 'dycore_kernel_stats',
 ]
 
@@ -74,6 +74,8 @@ def load_library(path=None):
     lib.dycore_time_steps.argtypes = [hp, C.c_double, C.c_int32, C.c_int32, C.POINTER(C.c_double)]
     lib.dycore_step_begin.argtypes = [hp, C.c_int32]
     lib.dycore_substep_part.argtypes = [hp, C.c_double, C.c_int32, C.c_int32]
+    lib.dycore_substep_field.argtypes = [hp, C.c_int32, C.c_char_p]
+    lib.dycore_substep_field.restype = C.c_char_p
     cpp = C.POINTER(C.c_char_p)
     lib.dycore_rows_size.argtypes = [hp, C.c_int32, cpp, C.POINTER(C.c_int64)]
     lib.dycore_pack_rows.argtypes = [hp, C.c_int32, cpp, C.POINTER(C.c_int32), C.c_void_p]
@@ -211,6 +213,10 @@ class HipDycore:
 
     def substep_part(self, dt, substep, part):
         self._check(self.lib.dycore_substep_part(self._h, float(dt), int(substep), int(part)))
+
+    def substep_field(self, substep, name):
+        r = self.lib.dycore_substep_field(self._h, int(substep), name.encode())
+        return r.decode() if r else name
 
     @staticmethod
     def _names(names):

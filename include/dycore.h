@@ -130,6 +130,9 @@ int dycore_step_matsuno(dycore_t *h, double dt, int32_t nsteps, int32_t with_rho
  * levels) of the named fields between the field buffers and one contiguous device buffer,
  * entry e at offset sum_{e'<e} levels(e')*(nx+3) doubles. */
 int dycore_step_begin(dycore_t *h, int32_t with_rho);
+/* name of the registered field that holds `name` (UWIND, VWIND or POTT) right after part 1 of
+ * the given substep: the fused step writes the predictor state into *_EST scratch fields */
+const char *dycore_substep_field(dycore_t *h, int32_t substep, const char *name);
 int dycore_substep_part(dycore_t *h, double dt, int32_t substep, int32_t part);
 int dycore_rows_size(dycore_t *h, int32_t n, const char *const *names, int64_t *n_doubles);
 int dycore_pack_rows(dycore_t *h, int32_t n, const char *const *names, const int32_t *rows,

@@ -127,8 +127,9 @@ def test_layout_adaptor_roundtrip_and_exchange():
 
 
 def test_fused_momentum_equals_stage_kernels(monkeypatch):
-    """k_momentum_fused (prepare + dUFLXdt + dVFLXdt in one pass) against the three stage
-    kernels on the same state: same formulae, different instruction order -> 1e-12."""
+    """The fused production step (k_momentum_fused, k_pott_fused: tendencies + Euler step +
+    diagnostics without intermediate fields) against the stage kernels on the same state,
+    halos included: same formulae, different instruction order -> 1e-12."""
     from climate_model_amd import Namelist, Grid, ModelFields, HipDycore
     from climate_model_amd.synthetic import initialize_fields
     GR = Grid(Namelist(nz=8, dlat_deg=4, dlon_deg=4))
@@ -142,9 +143,11 @@ def test_fused_momentum_equals_stage_kernels(monkeypatch):
         F.copy_host_to_device()
         core.primary_diag()
         core.step_matsuno(GR.dt, 2)
-        out[fused] = {n: core.download(n) for n in ['dUFLXdt', 'dVFLXdt', 'UWIND', 'VWIND', 'POTT', 'COLP']}
+        out[fused] = {n: core.download(n) for n in ['UWIND', 'VWIND', 'POTT', 'COLP', 'PHI', 'PHIVB', 'PVTF', 'PVTFVB',
+                                                    'POTTVB', 'WWIND', 'UFLX', 'VFLX', 'COLP_NEW']}
         core.close()
     nx, ny = GR.nx, GR.ny
     for n in out['1']:
         err, ncmp, bad = rel_max_err(out['1'][n], out['0'][n], n, nx, ny)
         assert bad == 0 and ncmp > 0 and err <= 1e-12, '%s: %.3e' % (n, err)
+        assert np.array_equal(np.isfinite(out['1'][n]), np.isfinite(out['0'][n])), n

@@ -113,6 +113,7 @@ struct dycore {
     size_t stage_elems = 0;
     int grid_set = 0;
     bool fused = true;              // production kernels in dycore_step_matsuno (DYCORE_FUSED=0: stage kernels)
+    bool mom_dma = true;            // LDS-DMA momentum kernel (DYCORE_MOM_DMA=0: register-staged tiles)
     // profiler
     bool prof = false;
     std::vector<ProfRec> recs;
@@ -298,11 +299,16 @@ int do_momentum_fused(dycore *h, const Ptrs &p, const double *u_old, const doubl
                       double *u_out, double *v_out, double dt)
 {
     Scope s(h, K_MOM_FUSED);
-    const int gbx = (h->g.nx + TI - 1) / TI, gby = (h->g.ny + FTJ - 1) / FTJ;
+    const int gbx = (h->g.nx + FTI - 1) / FTI, gby = (h->g.ny + FTJ - 1) / FTJ;
     const int nblk = gbx * gby;
-    const dim3 gr(8 * ((nblk + 7) / 8)), bl(TI, FTJ);
+    const dim3 gr(8 * ((nblk + 7) / 8)), bl(FTI, FTJ);
     const int jv_lo = h->g.pole_s ? 2 : 1;
-    if (u_out)
+    if (u_out && h->mom_dma && h->g.nz <= DMAXZ) {
+        if (u_old == p.UWIND)
+            hipLaunchKernelGGL(k_momentum_dma<true>, gr, bl, DMA_LDS_BYTES, h->stream, h->g, p, gbx, gby, jv_lo, u_old, v_old, u_out, v_out, dt);
+        else
+            hipLaunchKernelGGL(k_momentum_dma<false>, gr, bl, DMA_LDS_BYTES, h->stream, h->g, p, gbx, gby, jv_lo, u_old, v_old, u_out, v_out, dt);
+    } else if (u_out)
         hipLaunchKernelGGL(k_momentum_fused<true>, gr, bl, 0, h->stream, h->g, p, gbx, gby, jv_lo, u_old, v_old, u_out, v_out, dt);
     else
         hipLaunchKernelGGL(k_momentum_fused<false>, gr, bl, 0, h->stream, h->g, p, gbx, gby, jv_lo, u_old, v_old, u_out, v_out, dt);
@@ -465,6 +471,12 @@ int dycore_create(const DycoreConfig *cfg, dycore_t **out)
     g.pair_top = cfg->pair_top;
     memset(&h->p, 0, sizeof h->p);
     if (const char *e = getenv("DYCORE_FUSED")) h->fused = atoi(e) != 0;
+    if (const char *e = getenv("DYCORE_MOM_DMA")) h->mom_dma = atoi(e) != 0;
+    {   // the LDS-DMA kernel double-buffers 122 KB of tiles: raise the dynamic-LDS limit once
+        hipError_t e1 = hipFuncSetAttribute((const void *)k_momentum_dma<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)DMA_LDS_BYTES);
+        hipError_t e2 = hipFuncSetAttribute((const void *)k_momentum_dma<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)DMA_LDS_BYTES);
+        if (e1 != hipSuccess || e2 != hipSuccess) { (void)hipGetLastError(); h->mom_dma = false; }
+    }
     if (cfg->stream) h->stream = (hipStream_t)cfg->stream;
     else {
         hipError_t e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);

@@ -19,11 +19,12 @@
 
 namespace dyc {
 
+constexpr int FTI = 64;                // lanes along i per workgroup (one wavefront per row)
 constexpr int FTJ = 8;                 // rows per workgroup
 constexpr int FTW = 68;                // tile width: i-1 .. i+2 for 64 lanes (67), padded
 constexpr int FTH = FTJ + 3;           // tile height: j-1 .. j+2
 constexpr int FTN = FTW * FTH;         // doubles per tile
-constexpr int FNT = TI * FTJ;          // threads per workgroup
+constexpr int FNT = FTI * FTJ;          // threads per workgroup
 constexpr int FNF = 9;                 // staged fields
 
 // XCD-aware workgroup order: hardware deals workgroup b to XCD b % 8; give every XCD a
@@ -55,8 +56,8 @@ __global__ __launch_bounds__(FNT) void k_momentum_fused(Geo g, Ptrs p, int gbx, 
     int bx, by;
     if (!xcd_tile(gbx, gby, bx, by)) return;
     const int tx = threadIdx.x, ty = threadIdx.y;
-    const int tid = ty * TI + tx;
-    const int i0 = bx * TI + 1, j0 = by * FTJ + 1;
+    const int tid = ty * FTI + tx;
+    const int i0 = bx * FTI + 1, j0 = by * FTJ + 1;
     const int i = i0 + tx, j = j0 + ty;
     const int P = g.P;
     const bool active = (i <= g.nx) && (j <= g.ny);
@@ -273,6 +274,290 @@ __global__ __launch_bounds__(FNT) void k_momentum_fused(Geo g, Ptrs p, int gbx, 
 #undef SM
 }
 
+
+// ------------------------------------------------------------------------------------
+// k_momentum_dma: the same computation as k_momentum_fused<true>, restructured around
+// LDS-DMA (global_load_lds_dwordx4: HBM/L2 -> LDS without passing through VGPRs):
+//   * every input of level k+1 is in flight, 16 B per lane / 1 KB per wave-instruction,
+//     into the second LDS buffer while level k is computed from the first: one barrier per
+//     level, no vector-memory load inside the loop whose result the loop waits for;
+//   * tiles start at an even column (i0-1 = 64*bx), so every 16-B chunk is aligned in HBM
+//     and the tile is a linear LDS image (the DMA writes wave-base + lane*16);
+//   * the vertical advection is evaluated one level late ("skewed"): iteration k forms
+//     WWIND*U at interface k from the six-point sum carried from iteration k-1 and the
+//     winds of levels k-1 and k, which closes the tendency of level k-1.
+// OLD_IS_CUR: predictor (u_old is the field the tendencies are evaluated on); otherwise the
+// step-start winds are staged as two more (interior-height) tiles.
+constexpr int DNCH = FTN / 2;                     // 16-byte chunks per full tile (374)
+constexpr int DOLD_H = FTJ;                       // rows of an "old" tile (j0 .. j0+FTJ-1)
+constexpr int DOLD_N = FTW * DOLD_H;              // 544 doubles
+constexpr int DOLD_NCH = DOLD_N / 2;              // 272 chunks
+constexpr int DBUF = FNF * FTN + 2 * DOLD_N;      // doubles per LDS buffer
+constexpr int DMAXZ = 160;                        // levels the LDS copy of the 1-D constants can hold
+constexpr size_t DMA_LDS_BYTES = (2 * (size_t)DBUF + 3 * DMAXZ + 2) * sizeof(double);
+
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef const __attribute__((address_space(1))) void gbl_void_t;
+
+template <bool OLD_IS_CUR>
+__global__ __launch_bounds__(FNT) void k_momentum_dma(Geo g, Ptrs p, int gbx, int gby, int jv_lo,
+                                                      const double *u_old, const double *v_old,
+                                                      double *u_out, double *v_out, double dt)
+{
+    extern __shared__ __attribute__((aligned(16))) double dsm[];
+    int bx, by;
+    if (!xcd_tile(gbx, gby, bx, by)) return;
+    const int tx = threadIdx.x, ty = threadIdx.y;
+    const int tid = ty * FTI + tx;
+    const int wave = tid >> 6, lane = tid & 63;
+    const int i0 = bx * FTI + 1, j0 = by * FTJ + 1;
+    const int i = i0 + tx, j = j0 + ty;
+    const int P = g.P, nz = g.nz;
+    const bool active = (i <= g.nx) && (j <= g.ny);
+
+    // ---- DMA assignment: waves 0..5 move slice `wave` (64 chunks) of each of the 9 full
+    // tiles; waves 6 and 7 move the UWIND / VWIND step-start tiles (5 slices each) ----
+    int goff = 0;                       // plane offset of this lane's chunk (full tiles)
+    bool dma_on = false;
+    if (wave < 6) {
+        const int ch = wave * 64 + lane;
+        dma_on = ch < DNCH;
+        const int e = 2 * (dma_on ? ch : 0), r = e / FTW, c2 = e - r * FTW;
+        goff = min(j0 - 1 + r, g.NJ - 1) * P + min(i0 - 1 + c2, P - 2);
+    }
+    int ooff[5] = {0, 0, 0, 0, 0};
+    bool oon[5] = {false, false, false, false, false};
+    if (!OLD_IS_CUR && wave >= 6) {
+#pragma unroll
+        for (int s5 = 0; s5 < 5; s5++) {
+            const int ch = s5 * 64 + lane;
+            oon[s5] = ch < DOLD_NCH;
+            const int e = 2 * (oon[s5] ? ch : 0), r = e / FTW, c2 = e - r * FTW;
+            ooff[s5] = min(j0 + r, g.NJ - 1) * P + min(i0 - 1 + c2, P - 2);
+        }
+    }
+    const double *src[FNF] = {p.UFLX, p.VFLX, p.UWIND, p.VWIND, p.WWIND, p.PHI, p.POTT, p.PVTF, p.PVTFVB};
+    const int kofs[FNF] = {0, 0, 0, 0, 1, 0, 0, 0, 1};
+    enum { S_UF = 0, S_VF, S_UW, S_VW, S_W, S_PHI, S_POTT, S_PVTF, S_PVB };
+    const double *osrc = (wave == 6) ? u_old : v_old;
+
+    auto issue = [&](int k, int b) {
+        double *buf = dsm + b * DBUF;
+        if (wave < 6) {
+            if (dma_on) {
+#pragma unroll
+                for (int f = 0; f < FNF; f++) {
+                    const double *gp = src[f] + (size_t)(k + kofs[f]) * g.plane + goff;
+                    __builtin_amdgcn_global_load_lds((gbl_void_t *)gp, (lds_void_t *)(buf + f * FTN + wave * 128), 16, 0, 0);
+                }
+            }
+        } else if (!OLD_IS_CUR) {
+            double *ob = buf + FNF * FTN + (wave - 6) * DOLD_N;
+#pragma unroll
+            for (int s5 = 0; s5 < 5; s5++)
+                if (oon[s5]) {
+                    const double *gp = osrc + (size_t)k * g.plane + ooff[s5];
+                    __builtin_amdgcn_global_load_lds((gbl_void_t *)gp, (lds_void_t *)(ob + s5 * 128), 16, 0, 0);
+                }
+        }
+    };
+
+    // ---- per-column (2-D) quantities ----
+    const size_t c = at2(g, active ? i : 1, active ? j : 1);
+    const int jg = j + g.joff;
+    const bool lo = (jg == 1), hi = (jg == g.ny_global);
+    const bool v_on = active && (j >= jv_lo);
+    double ca[3][3];
+#pragma unroll
+    for (int b = 0; b < 3; b++)
+#pragma unroll
+        for (int a = 0; a < 3; a++) {
+            const size_t q2 = c + (b - 1) * P + (a - 1);
+            ca[b][a] = p.COLP_NEW[q2] * p.A[q2];
+        }
+    const double colp = p.COLP[c], colp_im1 = p.COLP[c - 1], colp_jm1 = p.COLP[c - P];
+    const double lat_is = p.lat_is_rad[c];
+    const double kc_is = p.corf_is[c] * CON_RE * cos(lat_is), sin_is = sin(lat_is);
+    const double lat = p.lat_rad[c], lat_jm1 = p.lat_rad[c - P];
+    const double kc_c = p.corf[c] * CON_RE * cos(lat), sin_c = sin(lat);
+    const double kc_jm1 = p.corf[c - P] * CON_RE * cos(lat_jm1), sin_jm1 = sin(lat_jm1);
+    const double metric = CON_RE * p.dlon_rad[c] * p.dlat_rad[c] / 2.0;
+    const double dyis = p.dyis[c], dxjs = p.dxjs[c];
+    double ca_is, cao_is, ca_js, cao_js;
+    {
+        double co[3][3];
+#pragma unroll
+        for (int b = 0; b < 3; b++)
+#pragma unroll
+            for (int a = 0; a < 3; a++) {
+                const size_t q2 = c + (b - 1) * P + (a - 1);
+                co[b][a] = p.COLP_OLD[q2] * p.A[q2];
+            }
+#define CA(a, b) ca[(b) + 1][(a) + 1]
+#define CO(a, b) co[(b) + 1][(a) + 1]
+        if (lo) {
+            ca_is = 1.0 / 4.0 * (CA(-1, 1) + CA(0, 1) + CA(-1, 0) + CA(0, 0));
+            cao_is = 1.0 / 4.0 * (CO(-1, 1) + CO(0, 1) + CO(-1, 0) + CO(0, 0));
+        } else if (hi) {
+            ca_is = 1.0 / 4.0 * (CA(-1, -1) + CA(0, -1) + CA(-1, 0) + CA(0, 0));
+            cao_is = 1.0 / 4.0 * (CO(-1, -1) + CO(0, -1) + CO(-1, 0) + CO(0, 0));
+        } else {
+            ca_is = 1.0 / 8.0 * (CA(-1, 1) + CA(0, 1) + 2.0 * CA(-1, 0) + 2.0 * CA(0, 0) + CA(-1, -1) + CA(0, -1));
+            cao_is = 1.0 / 8.0 * (CO(-1, 1) + CO(0, 1) + 2.0 * CO(-1, 0) + 2.0 * CO(0, 0) + CO(-1, -1) + CO(0, -1));
+        }
+        ca_js = 1.0 / 8.0 * (CA(1, -1) + CA(1, 0) + 2.0 * CA(0, -1) + 2.0 * CA(0, 0) + CA(-1, -1) + CA(-1, 0));
+        cao_js = 1.0 / 8.0 * (CO(1, -1) + CO(1, 0) + 2.0 * CO(0, -1) + 2.0 * CO(0, 0) + CO(-1, -1) + CO(-1, 0));
+#undef CA
+#undef CO
+    }
+    double pvb_k = p.PVTFVB[c], pvb_im1_k = p.PVTFVB[c - 1], pvb_jm1_k = p.PVTFVB[c - P];
+
+    const int lx = tx + 1, ly = ty + 1;
+#define SM(f, a, b) buf[(f) * FTN + (ly + (b)) * FTW + (lx + (a))]
+
+    // carried across levels
+    double su_k = 0.0, sv_k = 0.0;          // six-point COLP_NEW*A*WWIND sums at interface k
+    double wu_km1 = 0.0, wv_km1 = 0.0;      // WWIND*U, WWIND*V at interface k-1
+    double u_km1 = 0.0, v_km1 = 0.0, uo_km1 = 0.0, vo_km1 = 0.0;
+    double tu_km1 = 0.0, tv_km1 = 0.0;      // tendencies of level k-1 without the vertical advection
+
+    // vertical 1-D constants -> LDS: a vector-memory load inside the loop would make the compiler
+    // wait vmcnt(0) at its first use and drain the DMA prefetch (cdna_hip_programming.md, section 5)
+    double *cst = dsm + 2 * DBUF;
+    double *c_ds = cst, *c_svb = cst + DMAXZ, *c_dif = cst + 2 * DMAXZ + 1;
+    for (int t = tid; t <= nz; t += FNT) {
+        c_svb[t] = p.sigma_vb[t];
+        if (t < nz) { c_ds[t] = p.dsigma[t]; c_dif[t] = p.UVFLX_dif_coef[t]; }
+    }
+    issue(0, 0);
+    __syncthreads();
+#pragma unroll 1
+    for (int k = 0; k < nz; k++) {
+        if (k + 1 < nz) issue(k + 1, (k + 1) & 1);
+        const double *buf = dsm + (k & 1) * DBUF;
+        if (active) {
+            const double ds = c_ds[k];
+            double uf[3][4], vf[4][3], uw[3][3], vw[3][3];
+#pragma unroll
+            for (int b = 0; b < 3; b++)
+#pragma unroll
+                for (int a = 0; a < 4; a++) uf[b][a] = SM(S_UF, a - 1, b - 1);
+#pragma unroll
+            for (int b = 0; b < 4; b++)
+#pragma unroll
+                for (int a = 0; a < 3; a++) vf[b][a] = SM(S_VF, a - 1, b - 1);
+#pragma unroll
+            for (int b = 0; b < 3; b++)
+#pragma unroll
+                for (int a = 0; a < 3; a++) { uw[b][a] = SM(S_UW, a - 1, b - 1); vw[b][a] = SM(S_VW, a - 1, b - 1); }
+#define UF(a, b) uf[(b) + 1][(a) + 1]
+#define VF(a, b) vf[(b) + 1][(a) + 1]
+#define U(a, b) uw[(b) + 1][(a) + 1]
+#define V(a, b) vw[(b) + 1][(a) + 1]
+            const double u = U(0, 0), v = V(0, 0);
+            double uo = u, vo = v;
+            if (!OLD_IS_CUR) {
+                uo = buf[FNF * FTN + ty * FTW + lx];
+                vo = buf[FNF * FTN + DOLD_N + ty * FTW + lx];
+            }
+            // ---- interface k closes level k-1 ----
+            if (k >= 1) {
+                const double ds_km1 = c_ds[k - 1];
+                const double wu_k = su_k * ((ds * u_km1 + ds_km1 * u) / (ds + ds_km1));
+                const double wv_k = sv_k * ((ds * v_km1 + ds_km1 * v) / (ds + ds_km1));
+                const size_t qm = c + (size_t)(k - 1) * g.plane;
+                const double tu = tu_km1 + (wu_km1 - wu_k) / ds_km1;
+                u_out[qm] = uo_km1 * cao_is / ca_is + dt * tu / ca_is;
+                if (v_on) {
+                    const double tv = tv_km1 + (wv_km1 - wv_k) / ds_km1;
+                    v_out[qm] = vo_km1 * cao_js / ca_js + dt * tv / ca_js;
+                }
+                wu_km1 = wu_k; wv_km1 = wv_k;
+            }
+            // ---- six-point sums at interface k+1 (dyn_functions.py:211-270) ----
+            if (k + 1 < nz) {
+#define WT(a, b) (ca[(b) + 1][(a) + 1] * SM(S_W, a, b))
+#define WT2(a, b) (2.0 * ca[(b) + 1][(a) + 1] * SM(S_W, a, b))
+                if (lo) su_k = 0.25 * (WT(-1, 1) + WT(0, 1) + WT(-1, 0) + WT(0, 0));
+                else if (hi) su_k = 0.25 * (WT(-1, 0) + WT(0, 0) + WT(-1, -1) + WT(0, -1));
+                else su_k = 0.125 * (WT(-1, 1) + WT(0, 1) + WT2(-1, 0) + WT2(0, 0) + WT(-1, -1) + WT(0, -1));
+                sv_k = 0.125 * (WT(1, -1) + WT(1, 0) + WT2(0, -1) + WT2(0, 0) + WT(-1, -1) + WT(-1, 0));
+#undef WT
+#undef WT2
+            }
+            const double svb = c_svb[k], svb1 = c_svb[k + 1];
+            const double dif = c_dif[k];
+            const double pvb_kp1 = SM(S_PVB, 0, 0), pvb_im1_kp1 = SM(S_PVB, -1, 0), pvb_jm1_kp1 = SM(S_PVB, 0, -1);
+            const double phi = SM(S_PHI, 0, 0), pott = SM(S_POTT, 0, 0), pvtf = SM(S_PVTF, 0, 0);
+            // =============================== dUFLXdt (level k, without vertical advection) ====
+            {
+                double bflx = 1.0 / 12.0 * (UF(0, -1) + UF(1, -1) + 2.0 * (UF(0, 0) + UF(1, 0)) + UF(0, 1) + UF(1, 1));
+                double bflx_im1 = 1.0 / 12.0 * (UF(-1, -1) + UF(0, -1) + 2.0 * (UF(-1, 0) + UF(0, 0)) + UF(-1, 1) + UF(0, 1));
+                double cflx = 1.0 / 12.0 * (VF(-1, -1) + VF(0, -1) + 2.0 * (VF(-1, 0) + VF(0, 0)) + VF(-1, 1) + VF(0, 1));
+                double cflx_jp1 = 1.0 / 12.0 * (VF(-1, 0) + VF(0, 0) + 2.0 * (VF(-1, 1) + VF(0, 1)) + VF(-1, 2) + VF(0, 2));
+                double dflx_im1 = 1.0 / 24.0 * (VF(-1, -1) + 2.0 * VF(-1, 0) + VF(-1, 1) + UF(-1, -1) + UF(-1, 0) + UF(0, -1) + UF(0, 0));
+                double dflx_jp1 = 1.0 / 24.0 * (VF(0, 0) + 2.0 * VF(0, 1) + VF(0, 2) + UF(0, 0) + UF(0, 1) + UF(1, 0) + UF(1, 1));
+                double eflx = 1.0 / 24.0 * (VF(0, -1) + 2.0 * VF(0, 0) + VF(0, 1) - UF(0, -1) - UF(0, 0) - UF(1, -1) - UF(1, 0));
+                double eflx_im1_jp1 = 1.0 / 24.0 * (VF(-1, 0) + 2.0 * VF(-1, 1) + VF(-1, 2) - UF(-1, 0) - UF(-1, 1) - UF(0, 0) - UF(0, 1));
+                if (lo) { dflx_im1 = 0.0; cflx = 0.0; eflx = 0.0; }
+                if (hi) { dflx_jp1 = 0.0; cflx_jp1 = 0.0; eflx_im1_jp1 = 0.0; }
+                const double u_im1 = U(-1, 0), u_ip1 = U(1, 0);
+                double t = 0.0;
+                t = t + (+bflx_im1 * (u_im1 + u) / 2.0 - bflx * (u + u_ip1) / 2.0
+                         + cflx * (U(0, -1) + u) / 2.0 - cflx_jp1 * (u + U(0, 1)) / 2.0
+                         + dflx_im1 * (U(-1, -1) + u) / 2.0 - dflx_jp1 * (u + U(1, 1)) / 2.0
+                         + 1.0 * (+eflx * (U(1, -1) + u) / 2.0 - eflx_im1_jp1 * (u + U(-1, 1)) / 2.0));
+                t = t + metric * (colp_im1 * (V(-1, 0) + V(-1, 1)) / 2.0 * (kc_is + (u_im1 + u) / 2.0 * sin_is) +
+                                  colp * (V(0, 0) + V(0, 1)) / 2.0 * (kc_is + (u + u_ip1) / 2.0 * sin_is));
+                t = t + pre_grad(phi, SM(S_PHI, -1, 0), colp, colp_im1, pott, SM(S_POTT, -1, 0),
+                                 pvtf, SM(S_PVTF, -1, 0), pvb_k, pvb_im1_k, pvb_im1_kp1, pvb_kp1,
+                                 ds, svb, svb1, dyis);
+                if (dif > 0.0)
+                    t = t + dif * (UF(-1, 0) + UF(1, 0) + UF(0, -1) + UF(0, 1) - 4.0 * UF(0, 0));
+                tu_km1 = t;
+            }
+            // =============================== dVFLXdt ===============================
+            if (v_on) {
+                const double rflx = 1.0 / 12.0 * (VF(-1, 0) + VF(-1, 1) + 2.0 * (VF(0, 0) + VF(0, 1)) + VF(1, 0) + VF(1, 1));
+                const double rflx_jm1 = 1.0 / 12.0 * (VF(-1, -1) + VF(-1, 0) + 2.0 * (VF(0, -1) + VF(0, 0)) + VF(1, -1) + VF(1, 0));
+                const double qflx = 1.0 / 12.0 * (UF(-1, -1) + UF(-1, 0) + 2.0 * (UF(0, -1) + UF(0, 0)) + UF(1, -1) + UF(1, 0));
+                const double qflx_ip1 = 1.0 / 12.0 * (UF(0, -1) + UF(0, 0) + 2.0 * (UF(1, -1) + UF(1, 0)) + UF(2, -1) + UF(2, 0));
+                const double sflx_jm1 = 1.0 / 24.0 * (VF(-1, -1) + VF(-1, 0) + VF(0, -1) + VF(0, 0) + UF(-1, -1) + 2.0 * UF(0, -1) + UF(1, -1));
+                const double sflx_ip1 = 1.0 / 24.0 * (VF(0, 0) + VF(0, 1) + VF(1, 0) + VF(1, 1) + UF(0, 0) + 2.0 * UF(1, 0) + UF(2, 0));
+                const double tflx = 1.0 / 24.0 * (VF(-1, 0) + VF(-1, 1) + VF(0, 0) + VF(0, 1) - UF(-1, 0) - 2.0 * UF(0, 0) - UF(1, 0));
+                const double tflx_ip1_jm1 = 1.0 / 24.0 * (VF(0, -1) + VF(0, 0) + VF(1, -1) + VF(1, 0) - UF(0, -1) - 2.0 * UF(1, -1) - UF(2, -1));
+                double t = 0.0;
+                t = t + (+rflx_jm1 * (V(0, -1) + v) / 2.0 - rflx * (v + V(0, 1)) / 2.0
+                         + qflx * (V(-1, 0) + v) / 2.0 - qflx_ip1 * (v + V(1, 0)) / 2.0
+                         + sflx_jm1 * (V(-1, -1) + v) / 2.0 - sflx_ip1 * (v + V(1, 1)) / 2.0
+                         + -1.0 * (+tflx * (V(-1, 1) + v) / 2.0 - tflx_ip1_jm1 * (v + V(1, -1)) / 2.0));
+                const double ub_jm1 = (U(0, -1) + U(1, -1)) / 2.0, ub = (U(0, 0) + U(1, 0)) / 2.0;
+                t = t + -metric * (colp_jm1 * ub_jm1 * (kc_jm1 + ub_jm1 * sin_jm1) + colp * ub * (kc_c + ub * sin_c));
+                t = t + pre_grad(phi, SM(S_PHI, 0, -1), colp, colp_jm1, pott, SM(S_POTT, 0, -1),
+                                 pvtf, SM(S_PVTF, 0, -1), pvb_k, pvb_jm1_k, pvb_jm1_kp1, pvb_kp1,
+                                 ds, svb, svb1, dxjs);
+                if (dif > 0.0)
+                    t = t + dif * (VF(-1, 0) + VF(1, 0) + VF(0, -1) + VF(0, 1) - 4.0 * VF(0, 0));
+                tv_km1 = t;
+            }
+#undef UF
+#undef VF
+#undef U
+#undef V
+            u_km1 = u; v_km1 = v; uo_km1 = uo; vo_km1 = vo;
+            pvb_k = pvb_kp1; pvb_im1_k = pvb_im1_kp1; pvb_jm1_k = pvb_jm1_kp1;
+        }
+        __syncthreads();       // level k+1 has landed for every wave; buffer k&1 is free again
+    }
+    // ---- the bottom level: WWIND*U vanishes at the surface interface ----
+    if (active) {
+        const double ds = c_ds[nz - 1];
+        const size_t qm = c + (size_t)(nz - 1) * g.plane;
+        u_out[qm] = uo_km1 * cao_is / ca_is + dt * (tu_km1 + (wu_km1 - 0.0) / ds) / ca_is;
+        if (v_on) v_out[qm] = vo_km1 * cao_js / ca_js + dt * (tv_km1 + (wv_km1 - 0.0) / ds) / ca_js;
+    }
+#undef SM
+}
 
 // ------------------------------------------------------------------------------------
 // k_pott_fused: dPOTTdt (dyn_POTT.py:180-216) + Euler step of POTT (dyn_timestep.py:70-79)

@@ -45,7 +45,7 @@ def load_library(path=None):
     global _lib
     if _lib is not None and path is None:
         return _lib
-    path = path or LIB_PATH
+    path = path or os.environ.get('DYCORE_LIB') or LIB_PATH   # DYCORE_LIB: A/B builds of the same ABI
     if not os.path.exists(path):
         raise DycoreError('HIP extension not built: %s is missing (run __graft_entry__.build() '
                           'or `make -C climate_model_amd/csrc`); there is no CPU fallback' % path)
@@ -85,8 +85,7 @@ def load_library(path=None):
                                         C.POINTER(C.c_double)]
     if lib.dycore_abi_version() != ABI_VERSION:
         raise DycoreError('libdycore_hip.so ABI %d != binding ABI %d' % (lib.dycore_abi_version(), ABI_VERSION))
-    if path == LIB_PATH:
-        _lib = lib
+    _lib = lib
     return lib
 
 

@@ -29,11 +29,16 @@ import numpy as np
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 PASSES_PER_STEP = 130          # compulsory 3-D field passes per Matsuno step
-# algorithmic 3-D field passes per launch of each kernel (SURVEY.md 8d stage table)
+# Compulsory 3-D field passes per launch of each kernel = distinct 3-D inputs read once +
+# outputs written once (2-D/1-D fields and halos neglected, <2 %).
+# Stage kernels: the stage table of SURVEY.md 8(d).  Fused kernels move fewer bytes than the
+# stages they replace, so they are priced by what THEY must move, not by the stages' sum;
+# corrector launches read the step-start state in addition, hence the .5 averages.
 KERNEL_PASSES = {
     'k_continuity': 5, 'k_prepare': 15, 'k_uflx_tendency': 13, 'k_vflx_tendency': 13,
     'k_pott_tendency': 6, 'k_euler_forward': 9, 'k_primary_diag': 5, 'k_diag_rho': 6,
-    'k_momentum_fused': 29, 'k_tendencies_fused': 35,
+    'k_momentum_fused': 12.0,    # R UFLX,VFLX,UWIND,VWIND,WWIND,PHI,POTT,PVTF,PVTFVB (+2 old) W UWIND,VWIND
+    'k_pott_fused': 11.5,        # R POTT,UFLX,VFLX,WWIND,POTTVB (+1 old) W POTT,PVTF,PVTFVB,PHI,PHIVB,POTTVB
 }
 
 

@@ -281,8 +281,9 @@ __global__ __launch_bounds__(FNT) void k_momentum_fused(Geo g, Ptrs p, int gbx, 
 //   * every input of level k+1 is in flight, 16 B per lane / 1 KB per wave-instruction,
 //     into the second LDS buffer while level k is computed from the first: one barrier per
 //     level, no vector-memory load inside the loop whose result the loop waits for;
-//   * tiles start at an even column (i0-1 = 64*bx), so every 16-B chunk is aligned in HBM
-//     and the tile is a linear LDS image (the DMA writes wave-base + lane*16);
+//   * arrays are allocated with longitude i = 1 on a 512-B boundary; tiles start at i0-2, an
+//     even element, so every 16-B chunk is aligned in HBM and the tile is a linear LDS image
+//     (the DMA writes wave-base + lane*16);
 //   * the vertical advection is evaluated one level late ("skewed"): iteration k forms
 //     WWIND*U at interface k from the six-point sum carried from iteration k-1 and the
 //     winds of levels k-1 and k, which closes the tendency of level k-1.
@@ -323,7 +324,7 @@ __global__ __launch_bounds__(FNT) void k_momentum_dma(Geo g, Ptrs p, int gbx, in
         const int ch = wave * 64 + lane;
         dma_on = ch < DNCH;
         const int e = 2 * (dma_on ? ch : 0), r = e / FTW, c2 = e - r * FTW;
-        goff = min(j0 - 1 + r, g.NJ - 1) * P + min(i0 - 1 + c2, P - 2);
+        goff = min(j0 - 1 + r, g.NJ - 1) * P + min(i0 - 2 + c2, P - 2);
     }
     int ooff[5] = {0, 0, 0, 0, 0};
     bool oon[5] = {false, false, false, false, false};
@@ -333,7 +334,7 @@ __global__ __launch_bounds__(FNT) void k_momentum_dma(Geo g, Ptrs p, int gbx, in
             const int ch = s5 * 64 + lane;
             oon[s5] = ch < DOLD_NCH;
             const int e = 2 * (oon[s5] ? ch : 0), r = e / FTW, c2 = e - r * FTW;
-            ooff[s5] = min(j0 + r, g.NJ - 1) * P + min(i0 - 1 + c2, P - 2);
+            ooff[s5] = min(j0 + r, g.NJ - 1) * P + min(i0 - 2 + c2, P - 2);
         }
     }
     const double *src[FNF] = {p.UFLX, p.VFLX, p.UWIND, p.VWIND, p.WWIND, p.PHI, p.POTT, p.PVTF, p.PVTFVB};
@@ -412,7 +413,7 @@ __global__ __launch_bounds__(FNT) void k_momentum_dma(Geo g, Ptrs p, int gbx, in
     }
     double pvb_k = p.PVTFVB[c], pvb_im1_k = p.PVTFVB[c - 1], pvb_jm1_k = p.PVTFVB[c - P];
 
-    const int lx = tx + 1, ly = ty + 1;
+    const int lx = tx + 2, ly = ty + 1;   // tile column 0 is longitude i0-2 (16-B aligned in HBM)
 #define SM(f, a, b) buf[(f) * FTN + (ly + (b)) * FTW + (lx + (a))]
 
     // carried across levels

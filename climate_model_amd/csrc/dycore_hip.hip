@@ -113,7 +113,7 @@ struct dycore {
     size_t stage_elems = 0;
     int grid_set = 0;
     bool fused = true;              // production kernels in dycore_step_matsuno (DYCORE_FUSED=0: stage kernels)
-    bool mom_dma = true;            // LDS-DMA momentum kernel (DYCORE_MOM_DMA=0: register-staged tiles)
+    int mom_dma = 2;                // momentum kernel: 2 = LDS-DMA, role-split; 1 = LDS-DMA; 0 = register-staged tiles (DYCORE_MOM_DMA)
     // profiler
     bool prof = false;
     std::vector<ProfRec> recs;
@@ -303,7 +303,13 @@ int do_momentum_fused(dycore *h, const Ptrs &p, const double *u_old, const doubl
     const int nblk = gbx * gby;
     const dim3 gr(8 * ((nblk + 7) / 8)), bl(FTI, FTJ);
     const int jv_lo = h->g.pole_s ? 2 : 1;
-    if (u_out && h->mom_dma && h->g.nz <= DMAXZ) {
+    if (u_out && h->mom_dma == 2 && h->g.nz <= DMAXZ) {
+        const dim3 bl2(FTI, FTJ, 2);
+        if (u_old == p.UWIND)
+            hipLaunchKernelGGL(k_momentum_split<true>, gr, bl2, DMA_LDS_BYTES, h->stream, h->g, p, gbx, gby, jv_lo, u_old, v_old, u_out, v_out, dt);
+        else
+            hipLaunchKernelGGL(k_momentum_split<false>, gr, bl2, DMA_LDS_BYTES, h->stream, h->g, p, gbx, gby, jv_lo, u_old, v_old, u_out, v_out, dt);
+    } else if (u_out && h->mom_dma && h->g.nz <= DMAXZ) {
         if (u_old == p.UWIND)
             hipLaunchKernelGGL(k_momentum_dma<true>, gr, bl, DMA_LDS_BYTES, h->stream, h->g, p, gbx, gby, jv_lo, u_old, v_old, u_out, v_out, dt);
         else
@@ -471,11 +477,13 @@ int dycore_create(const DycoreConfig *cfg, dycore_t **out)
     g.pair_top = cfg->pair_top;
     memset(&h->p, 0, sizeof h->p);
     if (const char *e = getenv("DYCORE_FUSED")) h->fused = atoi(e) != 0;
-    if (const char *e = getenv("DYCORE_MOM_DMA")) h->mom_dma = atoi(e) != 0;
+    if (const char *e = getenv("DYCORE_MOM_DMA")) h->mom_dma = atoi(e);
     {   // the LDS-DMA kernel double-buffers 122 KB of tiles: raise the dynamic-LDS limit once
         hipError_t e1 = hipFuncSetAttribute((const void *)k_momentum_dma<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)DMA_LDS_BYTES);
         hipError_t e2 = hipFuncSetAttribute((const void *)k_momentum_dma<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)DMA_LDS_BYTES);
-        if (e1 != hipSuccess || e2 != hipSuccess) { (void)hipGetLastError(); h->mom_dma = false; }
+        hipError_t e3 = hipFuncSetAttribute((const void *)k_momentum_split<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)DMA_LDS_BYTES);
+        hipError_t e4 = hipFuncSetAttribute((const void *)k_momentum_split<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)DMA_LDS_BYTES);
+        if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess || e4 != hipSuccess) { (void)hipGetLastError(); h->mom_dma = 0; }
     }
     if (cfg->stream) h->stream = (hipStream_t)cfg->stream;
     else {

@@ -297,42 +297,53 @@ constexpr int DBUF = FNF * FTN + 2 * DOLD_N;      // doubles per LDS buffer
 constexpr int DMAXZ = 160;                        // levels the LDS copy of the 1-D constants can hold
 constexpr size_t DMA_LDS_BYTES = (2 * (size_t)DBUF + 3 * DMAXZ + 2) * sizeof(double);
 
+constexpr size_t dma_lds_bytes(int tj) { return (2 * (size_t)(FNF * FTW * (tj + 3) + 2 * FTW * tj) + 3 * DMAXZ + 2) * sizeof(double); }
+
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef const __attribute__((address_space(1))) void gbl_void_t;
 
-template <bool OLD_IS_CUR>
-__global__ __launch_bounds__(FNT) void k_momentum_dma(Geo g, Ptrs p, int gbx, int gby, int jv_lo,
+template <bool OLD_IS_CUR, int TJ>
+__global__ __launch_bounds__(FTI *TJ) void k_momentum_dma(Geo g, Ptrs p, int gbx, int gby, int jv_lo,
                                                       const double *u_old, const double *v_old,
                                                       double *u_out, double *v_out, double dt)
 {
+    // tile geometry for TJ rows per workgroup (TJ is chosen per launch so that the number of
+    // workgroups fits the 256 CUs with the least idle tail: dma_pick_tj on the host)
+    constexpr int TH = TJ + 3, TN = FTW * TH, NT = FTI * TJ;          // tile rows, doubles, threads
+    constexpr int NCH = TN / 2, NSL = (NCH + 63) / 64;               // 16-B chunks, 64-chunk slices
+    constexpr int ON = FTW * TJ, ONCH = ON / 2, ONSL = (ONCH + 63) / 64;   // step-start ("old") tiles
+    constexpr int BUF = FNF * TN + 2 * ON;
+    static_assert(NSL + 2 <= TJ, "not enough wavefronts for the DMA slices");
     extern __shared__ __attribute__((aligned(16))) double dsm[];
     int bx, by;
     if (!xcd_tile(gbx, gby, bx, by)) return;
     const int tx = threadIdx.x, ty = threadIdx.y;
     const int tid = ty * FTI + tx;
     const int wave = tid >> 6, lane = tid & 63;
-    const int i0 = bx * FTI + 1, j0 = by * FTJ + 1;
+    const int i0 = bx * FTI + 1, j0 = by * TJ + 1;
     const int i = i0 + tx, j = j0 + ty;
     const int P = g.P, nz = g.nz;
     const bool active = (i <= g.nx) && (j <= g.ny);
 
-    // ---- DMA assignment: waves 0..5 move slice `wave` (64 chunks) of each of the 9 full
-    // tiles; waves 6 and 7 move the UWIND / VWIND step-start tiles (5 slices each) ----
+    // ---- DMA assignment: waves 0..NSL-1 move slice `wave` (64 chunks) of each of the 9 full
+    // tiles; the last two waves move the UWIND / VWIND step-start tiles (ONSL slices each) ----
     int goff = 0;                       // plane offset of this lane's chunk (full tiles)
     bool dma_on = false;
-    if (wave < 6) {
+    if (wave < NSL) {
         const int ch = wave * 64 + lane;
-        dma_on = ch < DNCH;
+        dma_on = ch < NCH;
         const int e = 2 * (dma_on ? ch : 0), r = e / FTW, c2 = e - r * FTW;
         goff = min(j0 - 1 + r, g.NJ - 1) * P + min(i0 - 2 + c2, P - 2);
     }
-    int ooff[5] = {0, 0, 0, 0, 0};
-    bool oon[5] = {false, false, false, false, false};
-    if (!OLD_IS_CUR && wave >= 6) {
+    int ooff[ONSL];
+    bool oon[ONSL];
 #pragma unroll
-        for (int s5 = 0; s5 < 5; s5++) {
+    for (int s5 = 0; s5 < ONSL; s5++) { ooff[s5] = 0; oon[s5] = false; }
+    if (!OLD_IS_CUR && wave >= TJ - 2) {
+#pragma unroll
+        for (int s5 = 0; s5 < ONSL; s5++) {
             const int ch = s5 * 64 + lane;
-            oon[s5] = ch < DOLD_NCH;
+            oon[s5] = ch < ONCH;
             const int e = 2 * (oon[s5] ? ch : 0), r = e / FTW, c2 = e - r * FTW;
             ooff[s5] = min(j0 + r, g.NJ - 1) * P + min(i0 - 2 + c2, P - 2);
         }
@@ -340,22 +351,22 @@ __global__ __launch_bounds__(FNT) void k_momentum_dma(Geo g, Ptrs p, int gbx, in
     const double *src[FNF] = {p.UFLX, p.VFLX, p.UWIND, p.VWIND, p.WWIND, p.PHI, p.POTT, p.PVTF, p.PVTFVB};
     const int kofs[FNF] = {0, 0, 0, 0, 1, 0, 0, 0, 1};
     enum { S_UF = 0, S_VF, S_UW, S_VW, S_W, S_PHI, S_POTT, S_PVTF, S_PVB };
-    const double *osrc = (wave == 6) ? u_old : v_old;
+    const double *osrc = (wave == TJ - 2) ? u_old : v_old;
 
     auto issue = [&](int k, int b) {
-        double *buf = dsm + b * DBUF;
-        if (wave < 6) {
+        double *buf = dsm + b * BUF;
+        if (wave < NSL) {
             if (dma_on) {
 #pragma unroll
                 for (int f = 0; f < FNF; f++) {
                     const double *gp = src[f] + (size_t)(k + kofs[f]) * g.plane + goff;
-                    __builtin_amdgcn_global_load_lds((gbl_void_t *)gp, (lds_void_t *)(buf + f * FTN + wave * 128), 16, 0, 0);
+                    __builtin_amdgcn_global_load_lds((gbl_void_t *)gp, (lds_void_t *)(buf + f * TN + wave * 128), 16, 0, 0);
                 }
             }
-        } else if (!OLD_IS_CUR) {
-            double *ob = buf + FNF * FTN + (wave - 6) * DOLD_N;
+        } else if (!OLD_IS_CUR && wave >= TJ - 2) {
+            double *ob = buf + FNF * TN + (wave - (TJ - 2)) * ON;
 #pragma unroll
-            for (int s5 = 0; s5 < 5; s5++)
+            for (int s5 = 0; s5 < ONSL; s5++)
                 if (oon[s5]) {
                     const double *gp = osrc + (size_t)k * g.plane + ooff[s5];
                     __builtin_amdgcn_global_load_lds((gbl_void_t *)gp, (lds_void_t *)(ob + s5 * 128), 16, 0, 0);
@@ -414,7 +425,7 @@ __global__ __launch_bounds__(FNT) void k_momentum_dma(Geo g, Ptrs p, int gbx, in
     double pvb_k = p.PVTFVB[c], pvb_im1_k = p.PVTFVB[c - 1], pvb_jm1_k = p.PVTFVB[c - P];
 
     const int lx = tx + 2, ly = ty + 1;   // tile column 0 is longitude i0-2 (16-B aligned in HBM)
-#define SM(f, a, b) buf[(f) * FTN + (ly + (b)) * FTW + (lx + (a))]
+#define SM(f, a, b) buf[(f) * TN + (ly + (b)) * FTW + (lx + (a))]
 
     // carried across levels
     double su_k = 0.0, sv_k = 0.0;          // six-point COLP_NEW*A*WWIND sums at interface k
@@ -424,9 +435,9 @@ __global__ __launch_bounds__(FNT) void k_momentum_dma(Geo g, Ptrs p, int gbx, in
 
     // vertical 1-D constants -> LDS: a vector-memory load inside the loop would make the compiler
     // wait vmcnt(0) at its first use and drain the DMA prefetch (cdna_hip_programming.md, section 5)
-    double *cst = dsm + 2 * DBUF;
+    double *cst = dsm + 2 * BUF;
     double *c_ds = cst, *c_svb = cst + DMAXZ, *c_dif = cst + 2 * DMAXZ + 1;
-    for (int t = tid; t <= nz; t += FNT) {
+    for (int t = tid; t <= nz; t += NT) {
         c_svb[t] = p.sigma_vb[t];
         if (t < nz) { c_ds[t] = p.dsigma[t]; c_dif[t] = p.UVFLX_dif_coef[t]; }
     }
@@ -435,7 +446,7 @@ __global__ __launch_bounds__(FNT) void k_momentum_dma(Geo g, Ptrs p, int gbx, in
 #pragma unroll 1
     for (int k = 0; k < nz; k++) {
         if (k + 1 < nz) issue(k + 1, (k + 1) & 1);
-        const double *buf = dsm + (k & 1) * DBUF;
+        const double *buf = dsm + (k & 1) * BUF;
         if (active) {
             const double ds = c_ds[k];
             double uf[3][4], vf[4][3], uw[3][3], vw[3][3];
@@ -458,8 +469,8 @@ __global__ __launch_bounds__(FNT) void k_momentum_dma(Geo g, Ptrs p, int gbx, in
             const double u = U(0, 0), v = V(0, 0);
             double uo = u, vo = v;
             if (!OLD_IS_CUR) {
-                uo = buf[FNF * FTN + ty * FTW + lx];
-                vo = buf[FNF * FTN + DOLD_N + ty * FTW + lx];
+                uo = buf[FNF * TN + ty * FTW + lx];
+                vo = buf[FNF * TN + ON + ty * FTW + lx];
             }
             // ---- interface k closes level k-1 ----
             if (k >= 1) {

@@ -124,12 +124,34 @@ class BandHalo:
 
 
 class _TorchBuffers:
+    """One send and one receive buffer per phase, laid out [south part | north part], so that a
+    band packs (and unpacks) both directions with ONE kernel launch."""
+
     def __init__(self, halo, device):
         import torch
-        self.buf = {}
+        self.send, self.recv, self.split_send, self.split_recv = {}, {}, {}, {}
         for ph in ('A', 'B'):
             sz = halo.sizes(ph)
-            self.buf[ph] = {k: torch.empty(n, dtype=torch.float64, device=device) for k, n in sz.items()}
+            ss = sz['send_south'] if halo.has_south else 0
+            sn = sz['send_north'] if halo.has_north else 0
+            rs = sz['recv_south'] if halo.has_south else 0
+            rn = sz['recv_north'] if halo.has_north else 0
+            self.send[ph] = torch.empty(max(ss + sn, 1), dtype=torch.float64, device=device)
+            self.recv[ph] = torch.empty(max(rs + rn, 1), dtype=torch.float64, device=device)
+            self.split_send[ph] = (ss, sn)
+            self.split_recv[ph] = (rs, rn)
+
+
+def _merged(halo, ph, sub, kind):
+    """Concatenated (names, rows) of the south and north parts of a pack ('send') or unpack
+    ('recv') list, matching the [south | north] buffer layout."""
+    p = halo.resolved(ph, sub)
+    names, rows = [], []
+    if halo.has_south:
+        names += p[kind + '_south'][0]; rows += p[kind + '_south'][1]
+    if halo.has_north:
+        names += p[kind + '_north'][0]; rows += p[kind + '_north'][1]
+    return names, rows
 
 
 class DistributedBands:
@@ -143,39 +165,32 @@ class DistributedBands:
         self.group = group
         self.south, self.north = layout.south(rank), layout.north(rank)
         self.halo = BandHalo(core, layout.ny(rank), self.south is not None, self.north is not None)
-        self.bufs = _TorchBuffers(self.halo, device).buf
+        self.bufs = _TorchBuffers(self.halo, device)
         self.staged = dist.get_backend(group) != 'nccl' and str(device) != 'cpu'
 
     def exchange(self, ph, sub=1):
         import torch
-        dist, p, b = self.dist, self.halo.resolved(ph, sub), self.bufs[ph]
-        core = self.core
-        if self.north is not None:
-            core.pack_rows(*p['send_north'], b['send_north'].data_ptr())
-        if self.south is not None:
-            core.pack_rows(*p['send_south'], b['send_south'].data_ptr())
+        if self.south is None and self.north is None:
+            return
+        dist, b, core = self.dist, self.bufs, self.core
+        core.pack_rows(*_merged(self.halo, ph, sub, 'send'), b.send[ph].data_ptr())
         if self.staged:     # gloo: through host memory
-            send = {k: b[k].cpu() for k in ('send_north', 'send_south')}
-            recv = {k: torch.empty(b[k].shape, dtype=b[k].dtype) for k in ('recv_north', 'recv_south')}
+            send, recv = b.send[ph].cpu(), torch.empty(b.recv[ph].shape, dtype=torch.float64)
         else:
-            send, recv = b, b
+            send, recv = b.send[ph], b.recv[ph]
+        (ss, sn), (rs, rn) = b.split_send[ph], b.split_recv[ph]
         ops = []
-        if self.north is not None:
-            ops.append(dist.P2POp(dist.isend, send['send_north'], self.north, self.group))
-            ops.append(dist.P2POp(dist.irecv, recv['recv_north'], self.north, self.group))
         if self.south is not None:
-            ops.append(dist.P2POp(dist.isend, send['send_south'], self.south, self.group))
-            ops.append(dist.P2POp(dist.irecv, recv['recv_south'], self.south, self.group))
-        if ops:
-            for w in dist.batch_isend_irecv(ops):
-                w.wait()
+            ops.append(dist.P2POp(dist.isend, send[:ss], self.south, self.group))
+            ops.append(dist.P2POp(dist.irecv, recv[:rs], self.south, self.group))
+        if self.north is not None:
+            ops.append(dist.P2POp(dist.isend, send[ss:ss + sn], self.north, self.group))
+            ops.append(dist.P2POp(dist.irecv, recv[rs:rs + rn], self.north, self.group))
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
         if self.staged:
-            for k in ('recv_north', 'recv_south'):
-                b[k].copy_(recv[k])
-        if self.north is not None:
-            core.unpack_rows(*p['recv_north'], b['recv_north'].data_ptr())
-        if self.south is not None:
-            core.unpack_rows(*p['recv_south'], b['recv_south'].data_ptr())
+            b.recv[ph].copy_(recv)
+        core.unpack_rows(*_merged(self.halo, ph, sub, 'recv'), b.recv[ph].data_ptr())
 
     def step_matsuno(self, dt, nsteps=1, with_rho=None):
         core = self.core
@@ -197,32 +212,29 @@ class LocalBands:
         self.cores, self.layout = cores, layout
         self.halos = [BandHalo(c, layout.ny(r), layout.south(r) is not None, layout.north(r) is not None)
                       for r, c in enumerate(cores)]
-        self.bufs = [_TorchBuffers(h, device).buf for h in self.halos]
+        self.bufs = [_TorchBuffers(h, device) for h in self.halos]
 
     def exchange(self, ph, sub=1):
+        import torch
         n = len(self.cores)
+        if n == 1:
+            return
         for r in range(n):
-            p, b = self.halos[r].resolved(ph, sub), self.bufs[r][ph]
-            if r < n - 1:
-                self.cores[r].pack_rows(*p['send_north'], b['send_north'].data_ptr())
-            if r > 0:
-                self.cores[r].pack_rows(*p['send_south'], b['send_south'].data_ptr())
+            self.cores[r].pack_rows(*_merged(self.halos[r], ph, sub, 'send'), self.bufs[r].send[ph].data_ptr())
         for c in self.cores:
             c.sync()
         for r in range(n):
-            p, b = self.halos[r].resolved(ph, sub), self.bufs[r][ph]
-            if r < n - 1:
-                b['recv_north'].copy_(self.bufs[r + 1][ph]['send_south'])
-            if r > 0:
-                b['recv_south'].copy_(self.bufs[r - 1][ph]['send_north'])
-        import torch
+            b = self.bufs[r]
+            (rs, rn) = b.split_recv[ph]
+            if r > 0:       # from the southern neighbour: its north part
+                ss2, sn2 = self.bufs[r - 1].split_send[ph]
+                b.recv[ph][:rs].copy_(self.bufs[r - 1].send[ph][ss2:ss2 + sn2])
+            if r < n - 1:   # from the northern neighbour: its south part
+                ss2, sn2 = self.bufs[r + 1].split_send[ph]
+                b.recv[ph][rs:rs + rn].copy_(self.bufs[r + 1].send[ph][:ss2])
         torch.cuda.synchronize()
         for r in range(n):
-            p, b = self.halos[r].resolved(ph, sub), self.bufs[r][ph]
-            if r < n - 1:
-                self.cores[r].unpack_rows(*p['recv_north'], b['recv_north'].data_ptr())
-            if r > 0:
-                self.cores[r].unpack_rows(*p['recv_south'], b['recv_south'].data_ptr())
+            self.cores[r].unpack_rows(*_merged(self.halos[r], ph, sub, 'recv'), self.bufs[r].recv[ph].data_ptr())
 
     def step_matsuno(self, dt, nsteps=1, with_rho=None):
         for _ in range(nsteps):

@@ -107,6 +107,9 @@ struct dycore {
     Ptrs p;
     hipStream_t stream = nullptr;
     bool own_stream = false;
+    hipStream_t side = nullptr;     // halo-row diagnostics of a band overlap the next continuity
+    hipEvent_t ev_main = nullptr, ev_side = nullptr;
+    bool side_pending = false;
     std::unordered_map<std::string, int> field_idx, grid_idx;
     std::vector<double *> allocs;
     double *stage = nullptr;        // staging buffer for the layout adaptor
@@ -178,6 +181,14 @@ int check_ready(dycore *h)
     if (h->grid_set != (1 << kNGrid) - 1)
         return fail(DYCORE_ESTATE, "grid constants missing: call dycore_set_grid for all %d arrays first", kNGrid);
     return 0;
+}
+
+int join_side(dycore *h);
+// stage entry points read what the side stream may still be writing
+int ready_join(dycore *h)
+{
+    int rc = check_ready(h);
+    return rc ? rc : join_side(h);
 }
 
 int launch_check(const char *what)
@@ -339,13 +350,35 @@ int do_pott_fused(dycore *h, const Ptrs &p, const double *pott_old, double *pott
     return launch_check("k_pott_fused");
 }
 // primary diagnostics on the halo rows a band received from its neighbours
+// The two rows are a 64-level serial recursion on ~3000 columns (latency-bound, ~60 us): they
+// run on a side stream behind the unpack of the received POTT rows and are joined again before
+// the next kernel that reads the diagnostics (join_side), i.e. they overlap the continuity
+// kernel and the first exchange of the next substep.
+int join_side(dycore *h)
+{
+    if (!h->side_pending) return 0;
+    HIP_TRY(hipStreamWaitEvent(h->stream, h->ev_side, 0));
+    h->side_pending = false;
+    return 0;
+}
 int do_diag_band_halo(dycore *h, const Ptrs &p)
 {
     if (h->g.pole_s && h->g.pole_n) return 0;
-    Scope s(h, K_DIAG_ROWS);
     const int row_a = h->g.pole_s ? -1 : 0, row_b = h->g.pole_n ? -1 : h->g.ny + 1;
-    hipLaunchKernelGGL(k_primary_diag_rows, dim3((h->g.nx + 2 + TI - 1) / TI, 2), dim3(TI), 0, h->stream, h->g, p, row_a, row_b);
-    return launch_check("k_primary_diag_rows");
+    const dim3 gr((h->g.nx + 2 + TI - 1) / TI, 2);
+    if (h->prof || !h->side) {      // profiling brackets launches on the main stream
+        Scope s(h, K_DIAG_ROWS);
+        hipLaunchKernelGGL(k_primary_diag_rows, gr, dim3(TI), 0, h->stream, h->g, p, row_a, row_b);
+        return launch_check("k_primary_diag_rows");
+    }
+    HIP_TRY(hipEventRecord(h->ev_main, h->stream));
+    HIP_TRY(hipStreamWaitEvent(h->side, h->ev_main, 0));
+    hipLaunchKernelGGL(k_primary_diag_rows, gr, dim3(TI), 0, h->side, h->g, p, row_a, row_b);
+    int rc = launch_check("k_primary_diag_rows");
+    if (rc) return rc;
+    HIP_TRY(hipEventRecord(h->ev_side, h->side));
+    h->side_pending = true;
+    return 0;
 }
 
 int do_momentum(dycore *h, const Ptrs &p)
@@ -413,6 +446,7 @@ int substep_part(dycore *h, double dt, int sub, int part)
         case 0:                     // -> UFLX, VFLX, WWIND, COLP_NEW halo rows
             return do_continuity(h, q, dt);
         case 1: {                   // momentum reads the old diagnostics, so it runs first
+            if ((rc = join_side(h))) return rc;
             if ((rc = do_momentum_fused(h, q, p.UWIND, p.VWIND, u_out, v_out, dt))) return rc;
             if ((rc = do_pott_fused(h, q, p.POTT, t_out, dt))) return rc;
             const int nz = h->g.nz;
@@ -512,6 +546,14 @@ int dycore_create(const DycoreConfig *cfg, dycore_t **out)
         if (e != hipSuccess) { delete h; return fail(DYCORE_EHIP, "hipStreamCreate: %s", hipGetErrorString(e)); }
         h->own_stream = true;
     }
+    if (!(g.pole_s && g.pole_n)) {      // a band of a decomposed grid
+        if (hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking) != hipSuccess ||
+            hipEventCreateWithFlags(&h->ev_main, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&h->ev_side, hipEventDisableTiming) != hipSuccess) {
+            (void)hipGetLastError();
+            h->side = nullptr;
+        }
+    }
     const double nan = std::numeric_limits<double>::quiet_NaN();
     // Every array is placed so that column i = 1 (the first owned longitude) of every row sits
     // on a 512-B boundary: a wavefront's 64 x 8 B row segment then covers exactly four 128-B
@@ -562,6 +604,9 @@ int dycore_destroy(dycore_t *h)
     for (auto &r : h->recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     for (auto e : h->ev_pool) (void)hipEventDestroy(e);
     for (double *d : h->allocs) (void)hipFree(d);
+    if (h->side) { (void)hipStreamSynchronize(h->side); (void)hipStreamDestroy(h->side); }
+    if (h->ev_main) (void)hipEventDestroy(h->ev_main);
+    if (h->ev_side) (void)hipEventDestroy(h->ev_side);
     if (h->own_stream) (void)hipStreamDestroy(h->stream);
     delete h;
     return 0;
@@ -570,6 +615,8 @@ int dycore_destroy(dycore_t *h)
 int dycore_sync(dycore_t *h)
 {
     if (!h) return fail(DYCORE_EINVAL, "null handle");
+    int rc = join_side(h);
+    if (rc) return rc;
     HIP_TRY(hipStreamSynchronize(h->stream));
     return 0;
 }
@@ -645,6 +692,7 @@ int dycore_download(dycore_t *h, const char *name, double *host)
     int rc = find_field(h, name, &d);
     if (rc) return rc;
     if (!host) return fail(DYCORE_EINVAL, "null host pointer");
+    if ((rc = join_side(h))) return rc;
     const Geo &g = h->g;
     const int n0 = g.nx + 2 + d->stgx, n1 = g.ny + 2 + d->stgy, n2 = h->nk_of(d->nk);
     const size_t n = (size_t)n0 * n1 * n2;
@@ -675,6 +723,7 @@ int dycore_copy_field(dycore_t *h, const char *dst, const char *src)
     if ((rc = find_field(h, dst, &a)) || (rc = find_field(h, src, &b))) return rc;
     if (a->stgx != b->stgx || a->stgy != b->stgy || a->nk != b->nk)
         return fail(DYCORE_EINVAL, "copy_field: '%s' and '%s' differ in shape", dst, src);
+    if ((rc = join_side(h))) return rc;
     return do_copy(h, h->p.*(a->member), h->p.*(b->member), h->field_elems(a->nk));
 }
 
@@ -686,15 +735,15 @@ int dycore_exchange_bc(dycore_t *h, const char *name)
     return do_exchange(h, h->p.*(d->member), d->stgx, d->stgy, h->nk_of(d->nk));
 }
 
-int dycore_continuity(dycore_t *h, double dt) { int rc = check_ready(h); return rc ? rc : do_continuity(h, h->p, dt); }
-int dycore_momentum(dycore_t *h) { int rc = check_ready(h); return rc ? rc : do_momentum(h, h->p); }
-int dycore_momentum_prepare(dycore_t *h) { int rc = check_ready(h); return rc ? rc : do_prepare(h, h->p); }
-int dycore_uflx_tendency(dycore_t *h) { int rc = check_ready(h); return rc ? rc : do_uflx(h, h->p); }
-int dycore_vflx_tendency(dycore_t *h) { int rc = check_ready(h); return rc ? rc : do_vflx(h, h->p); }
-int dycore_pott_tendency(dycore_t *h) { int rc = check_ready(h); return rc ? rc : do_pott(h, h->p); }
-int dycore_euler_forward(dycore_t *h, double dt) { int rc = check_ready(h); return rc ? rc : do_euler(h, h->p, dt); }
-int dycore_primary_diag(dycore_t *h) { int rc = check_ready(h); return rc ? rc : do_diag(h, h->p); }
-int dycore_secondary_diag_rho(dycore_t *h) { int rc = check_ready(h); return rc ? rc : do_rho(h, h->p); }
+int dycore_continuity(dycore_t *h, double dt) { int rc = ready_join(h); return rc ? rc : do_continuity(h, h->p, dt); }
+int dycore_momentum(dycore_t *h) { int rc = ready_join(h); return rc ? rc : do_momentum(h, h->p); }
+int dycore_momentum_prepare(dycore_t *h) { int rc = ready_join(h); return rc ? rc : do_prepare(h, h->p); }
+int dycore_uflx_tendency(dycore_t *h) { int rc = ready_join(h); return rc ? rc : do_uflx(h, h->p); }
+int dycore_vflx_tendency(dycore_t *h) { int rc = ready_join(h); return rc ? rc : do_vflx(h, h->p); }
+int dycore_pott_tendency(dycore_t *h) { int rc = ready_join(h); return rc ? rc : do_pott(h, h->p); }
+int dycore_euler_forward(dycore_t *h, double dt) { int rc = ready_join(h); return rc ? rc : do_euler(h, h->p, dt); }
+int dycore_primary_diag(dycore_t *h) { int rc = ready_join(h); return rc ? rc : do_diag(h, h->p); }
+int dycore_secondary_diag_rho(dycore_t *h) { int rc = ready_join(h); return rc ? rc : do_rho(h, h->p); }
 
 int dycore_step_matsuno(dycore_t *h, double dt, int32_t nsteps, int32_t with_rho)
 {
@@ -743,7 +792,7 @@ static int rows_op(dycore_t *h, int32_t n, const char *const *names, const int32
         RowList rl;
         rl.n = 0;
         int maxk = 1;
-        for (; done < n && rl.n < 8; done++) {
+        for (; done < n && rl.n < ROWLIST_MAX; done++) {
             const FieldDesc *d;
             int rc = find_field(h, names[done], &d);
             if (rc) return rc;

@@ -687,13 +687,14 @@ __global__ void k_to_host(Geo g, const double *__restrict__ src, double *__restr
     }
 }
 // ---- halo rows of a latitude band <-> contiguous message buffer (multi-GPU) -------------
-// One launch moves up to 8 (field,row) pairs: entry e copies the nk[e] levels of row
+// One launch moves up to 12 (field,row) pairs: entry e copies the nk[e] levels of row
 // row[e], columns 0..nx+2, to/from buf + off[e].
+constexpr int ROWLIST_MAX = 12;
 struct RowList {
     int n;
-    double *base[8];
-    int row[8], nk[8];
-    long long off[8];
+    double *base[ROWLIST_MAX];
+    int row[ROWLIST_MAX], nk[ROWLIST_MAX];
+    long long off[ROWLIST_MAX];
 };
 __global__ void k_rows(Geo g, RowList rl, double *buf, int unpack)
 {

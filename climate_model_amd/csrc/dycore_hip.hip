@@ -118,6 +118,7 @@ struct dycore {
     bool fused = true;              // production kernels in dycore_step_matsuno (DYCORE_FUSED=0: stage kernels)
     int n_cu = 256;                 // compute units of the device
     int mom_tj = 0;                 // DYCORE_MOM_TJ: force the rows per momentum workgroup (8, 9, 10)
+    int mom_ks = 0;                 // DYCORE_MOM_KS: force the level chunks per momentum tile (1, 2, 4)
     int mom_dma = 1;                // momentum kernel: 1 = LDS-DMA (default); 2 = LDS-DMA, role-split; 0 = register-staged tiles (DYCORE_MOM_DMA)
     // profiler
     bool prof = false;
@@ -330,11 +331,25 @@ int do_momentum_fused(dycore *h, const Ptrs &p, const double *u_old, const doubl
         int tj = 8;
         if (h->mom_tj) tj = h->mom_tj;
         const int gby2 = (h->g.ny + tj - 1) / tj;
-        const dim3 gr2(8 * ((gbx * gby2 + 7) / 8)), blk(FTI, tj);
+        // level chunks per tile: with one workgroup per CU, `tiles` workgroups of 64 levels take
+        // ceil(tiles / CUs) rounds; ks chunks take ceil(tiles*ks / CUs) rounds of (64/ks + 1)
+        // levels (one extra level of prologue per chunk).  Pick the cheapest of 1, 2, 4.
+        int ks = 1;
+        {
+            const long tiles = (long)gbx * gby2;
+            double best = -1.0;
+            for (int cand : {1, 2, 4}) {
+                if (h->g.nz / cand < 4) break;
+                const double cost = (double)((tiles * cand + h->n_cu - 1) / h->n_cu) * ((double)h->g.nz / cand + (cand > 1 ? 1.0 : 0.0));
+                if (best < 0 || cost < best - 1e-9) { best = cost; ks = cand; }
+            }
+            if (h->mom_ks) ks = h->mom_ks;
+        }
+        const dim3 gr2(8 * ((gbx * gby2 * ks + 7) / 8)), blk(FTI, tj);
         const bool cur = (u_old == p.UWIND);
 #define DMA_LAUNCH(TJ_)                                                                                        \
-        if (cur) hipLaunchKernelGGL((k_momentum_dma<true, TJ_>), gr2, blk, dma_lds_bytes(TJ_), h->stream, h->g, p, gbx, gby2, jv_lo, u_old, v_old, u_out, v_out, dt); \
-        else hipLaunchKernelGGL((k_momentum_dma<false, TJ_>), gr2, blk, dma_lds_bytes(TJ_), h->stream, h->g, p, gbx, gby2, jv_lo, u_old, v_old, u_out, v_out, dt);
+        if (cur) hipLaunchKernelGGL((k_momentum_dma<true, TJ_>), gr2, blk, dma_lds_bytes(TJ_), h->stream, h->g, p, gbx, gby2, ks, jv_lo, u_old, v_old, u_out, v_out, dt); \
+        else hipLaunchKernelGGL((k_momentum_dma<false, TJ_>), gr2, blk, dma_lds_bytes(TJ_), h->stream, h->g, p, gbx, gby2, ks, jv_lo, u_old, v_old, u_out, v_out, dt);
         if (tj == 8) { DMA_LAUNCH(8) } else if (tj == 9) { DMA_LAUNCH(9) } else { DMA_LAUNCH(10) }
 #undef DMA_LAUNCH
     } else if (u_out)
@@ -525,6 +540,7 @@ int dycore_create(const DycoreConfig *cfg, dycore_t **out)
     if (const char *e = getenv("DYCORE_FUSED")) h->fused = atoi(e) != 0;
     if (const char *e = getenv("DYCORE_MOM_DMA")) h->mom_dma = atoi(e);
     if (const char *e = getenv("DYCORE_MOM_TJ")) h->mom_tj = atoi(e);
+    if (const char *e = getenv("DYCORE_MOM_KS")) h->mom_ks = atoi(e);
     {
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, cfg->device) == hipSuccess && prop.multiProcessorCount > 0) h->n_cu = prop.multiProcessorCount;

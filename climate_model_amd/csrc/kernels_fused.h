@@ -303,7 +303,7 @@ typedef __attribute__((address_space(3))) void lds_void_t;
 typedef const __attribute__((address_space(1))) void gbl_void_t;
 
 template <bool OLD_IS_CUR, int TJ>
-__global__ __launch_bounds__(FTI *TJ) void k_momentum_dma(Geo g, Ptrs p, int gbx, int gby, int jv_lo,
+__global__ __launch_bounds__(FTI *TJ) void k_momentum_dma(Geo g, Ptrs p, int gbx, int gby, int ksplit, int jv_lo,
                                                       const double *u_old, const double *v_old,
                                                       double *u_out, double *v_out, double dt)
 {
@@ -315,8 +315,13 @@ __global__ __launch_bounds__(FTI *TJ) void k_momentum_dma(Geo g, Ptrs p, int gbx
     constexpr int BUF = FNF * TN + 2 * ON;
     static_assert(NSL + 2 <= TJ, "not enough wavefronts for the DMA slices");
     extern __shared__ __attribute__((aligned(16))) double dsm[];
+    // workgroup -> (tile, level chunk): `ksplit` chunks of the k range per tile give a small
+    // latitude band enough workgroups to balance over the CUs (one tile per CU otherwise)
     int bx, by;
-    if (!xcd_tile(gbx, gby, bx, by)) return;
+    if (!xcd_tile(gbx, gby * ksplit, bx, by)) return;
+    const int kc = by / gby;
+    by -= kc * gby;
+    const int k0 = (int)((long long)kc * g.nz / ksplit), k1 = (int)((long long)(kc + 1) * g.nz / ksplit);
     const int tx = threadIdx.x, ty = threadIdx.y;
     const int tid = ty * FTI + tx;
     const int wave = tid >> 6, lane = tid & 63;
@@ -422,7 +427,8 @@ __global__ __launch_bounds__(FTI *TJ) void k_momentum_dma(Geo g, Ptrs p, int gbx
 #undef CA
 #undef CO
     }
-    double pvb_k = p.PVTFVB[c], pvb_im1_k = p.PVTFVB[c - 1], pvb_jm1_k = p.PVTFVB[c - P];
+    const size_t c0 = c + (size_t)k0 * g.plane;
+    double pvb_k = p.PVTFVB[c0], pvb_im1_k = p.PVTFVB[c0 - 1], pvb_jm1_k = p.PVTFVB[c0 - P];
 
     const int lx = tx + 2, ly = ty + 1;   // tile column 0 is longitude i0-2 (16-B aligned in HBM)
 #define SM(f, a, b) buf[(f) * TN + (ly + (b)) * FTW + (lx + (a))]
@@ -432,6 +438,18 @@ __global__ __launch_bounds__(FTI *TJ) void k_momentum_dma(Geo g, Ptrs p, int gbx
     double wu_km1 = 0.0, wv_km1 = 0.0;      // WWIND*U, WWIND*V at interface k-1
     double u_km1 = 0.0, v_km1 = 0.0, uo_km1 = 0.0, vo_km1 = 0.0;
     double tu_km1 = 0.0, tv_km1 = 0.0;      // tendencies of level k-1 without the vertical advection
+    if (k0 > 0) {       // a chunk that starts inside the column: interface k0 and the winds above it
+#define WG(a, b) (ca[(b) + 1][(a) + 1] * p.WWIND[c0 + (b) * P + (a)])
+#define WG2(a, b) (2.0 * ca[(b) + 1][(a) + 1] * p.WWIND[c0 + (b) * P + (a)])
+        if (lo) su_k = 0.25 * (WG(-1, 1) + WG(0, 1) + WG(-1, 0) + WG(0, 0));
+        else if (hi) su_k = 0.25 * (WG(-1, 0) + WG(0, 0) + WG(-1, -1) + WG(0, -1));
+        else su_k = 0.125 * (WG(-1, 1) + WG(0, 1) + WG2(-1, 0) + WG2(0, 0) + WG(-1, -1) + WG(0, -1));
+        sv_k = 0.125 * (WG(1, -1) + WG(1, 0) + WG2(0, -1) + WG2(0, 0) + WG(-1, -1) + WG(-1, 0));
+#undef WG
+#undef WG2
+        u_km1 = p.UWIND[c0 - g.plane];
+        v_km1 = p.VWIND[c0 - g.plane];
+    }
 
     // vertical 1-D constants -> LDS: a vector-memory load inside the loop would make the compiler
     // wait vmcnt(0) at its first use and drain the DMA prefetch (cdna_hip_programming.md, section 5)
@@ -441,11 +459,11 @@ __global__ __launch_bounds__(FTI *TJ) void k_momentum_dma(Geo g, Ptrs p, int gbx
         c_svb[t] = p.sigma_vb[t];
         if (t < nz) { c_ds[t] = p.dsigma[t]; c_dif[t] = p.UVFLX_dif_coef[t]; }
     }
-    issue(0, 0);
+    issue(k0, k0 & 1);
     __syncthreads();
 #pragma unroll 1
-    for (int k = 0; k < nz; k++) {
-        if (k + 1 < nz) issue(k + 1, (k + 1) & 1);
+    for (int k = k0; k < k1; k++) {
+        if (k + 1 < k1) issue(k + 1, (k + 1) & 1);
         const double *buf = dsm + (k & 1) * BUF;
         if (active) {
             const double ds = c_ds[k];
@@ -477,12 +495,14 @@ __global__ __launch_bounds__(FTI *TJ) void k_momentum_dma(Geo g, Ptrs p, int gbx
                 const double ds_km1 = c_ds[k - 1];
                 const double wu_k = su_k * ((ds * u_km1 + ds_km1 * u) / (ds + ds_km1));
                 const double wv_k = sv_k * ((ds * v_km1 + ds_km1 * v) / (ds + ds_km1));
-                const size_t qm = c + (size_t)(k - 1) * g.plane;
-                const double tu = tu_km1 + (wu_km1 - wu_k) / ds_km1;
-                u_out[qm] = uo_km1 * cao_is / ca_is + dt * tu / ca_is;
-                if (v_on) {
-                    const double tv = tv_km1 + (wv_km1 - wv_k) / ds_km1;
-                    v_out[qm] = vo_km1 * cao_js / ca_js + dt * tv / ca_js;
+                if (k > k0) {
+                    const size_t qm = c + (size_t)(k - 1) * g.plane;
+                    const double tu = tu_km1 + (wu_km1 - wu_k) / ds_km1;
+                    u_out[qm] = uo_km1 * cao_is / ca_is + dt * tu / ca_is;
+                    if (v_on) {
+                        const double tv = tv_km1 + (wv_km1 - wv_k) / ds_km1;
+                        v_out[qm] = vo_km1 * cao_js / ca_js + dt * tv / ca_js;
+                    }
                 }
                 wu_km1 = wu_k; wv_km1 = wv_k;
             }
@@ -561,12 +581,18 @@ __global__ __launch_bounds__(FTI *TJ) void k_momentum_dma(Geo g, Ptrs p, int gbx
         }
         __syncthreads();       // level k+1 has landed for every wave; buffer k&1 is free again
     }
-    // ---- the bottom level: WWIND*U vanishes at the surface interface ----
+    // ---- the last level of the chunk: its lower interface is k1 (WWIND*U = 0 at the surface) ----
     if (active) {
-        const double ds = c_ds[nz - 1];
-        const size_t qm = c + (size_t)(nz - 1) * g.plane;
-        u_out[qm] = uo_km1 * cao_is / ca_is + dt * (tu_km1 + (wu_km1 - 0.0) / ds) / ca_is;
-        if (v_on) v_out[qm] = vo_km1 * cao_js / ca_js + dt * (tv_km1 + (wv_km1 - 0.0) / ds) / ca_js;
+        const double ds = c_ds[k1 - 1];
+        const size_t qm = c + (size_t)(k1 - 1) * g.plane;
+        double wu_k = 0.0, wv_k = 0.0;
+        if (k1 < nz) {
+            const double ds1 = c_ds[k1];
+            wu_k = su_k * ((ds1 * u_km1 + ds * p.UWIND[qm + g.plane]) / (ds1 + ds));
+            wv_k = sv_k * ((ds1 * v_km1 + ds * p.VWIND[qm + g.plane]) / (ds1 + ds));
+        }
+        u_out[qm] = uo_km1 * cao_is / ca_is + dt * (tu_km1 + (wu_km1 - wu_k) / ds) / ca_is;
+        if (v_on) v_out[qm] = vo_km1 * cao_js / ca_js + dt * (tv_km1 + (wv_km1 - wv_k) / ds) / ca_js;
     }
 #undef SM
 }

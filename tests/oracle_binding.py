@@ -89,6 +89,8 @@ class Oracle:
                  i_radiation=0, nthreads=0, fill_nan=True):
         self.lib = load_oracle()
         self.nx, self.ny, self.nz = int(nx), int(ny), int(nz)
+        if not nthreads:        # a GPU box shows every core of its host; its share is 16
+            nthreads = min(16, len(os.sched_getaffinity(0)))
         self.cfg = OracleCfg(self.nx, self.ny, self.nz, int(i_turb), int(i_radiation),
                              int(nthreads), float(pair_top))
         self.G = {}

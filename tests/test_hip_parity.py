@@ -151,3 +151,58 @@ def test_fused_momentum_equals_stage_kernels(monkeypatch):
         err, ncmp, bad = rel_max_err(out['1'][n], out['0'][n], n, nx, ny)
         assert bad == 0 and ncmp > 0 and err <= 1e-12, '%s: %.3e' % (n, err)
         assert np.array_equal(np.isfinite(out['1'][n]), np.isfinite(out['0'][n])), n
+
+
+@pytest.mark.parametrize('nx,ny,nz', [(36, 18, 4), (37, 19, 5), (130, 33, 3), (64, 16, 2), (65, 17, 9), (200, 9, 7)])
+@pytest.mark.parametrize('i_turb', [0, 1])
+def test_odd_grid_sizes_vs_oracle(nx, ny, nz, i_turb):
+    """Ragged extents (partial tiles and wavefronts, nz = 2, nz not a power of two, fewer rows
+    than a tile) on a synthetic state: fused/staged HIP step against the CPU oracle."""
+    from climate_model_amd import Namelist, Grid, ModelFields, HipDycore
+    from climate_model_amd.synthetic import initialize_fields
+    from oracle_binding import Oracle
+    GR = Grid(Namelist(nz=nz, dlat_deg=180. / ny, dlon_deg=360. / nx, UVFLX_dif_coef=4.0,
+                       i_UVFLX_vert_turb=i_turb, i_POTT_vert_turb=i_turb, dt=20.))
+    assert (GR.nx, GR.ny, GR.nz) == (nx, ny, nz)
+    F = ModelFields(GR)
+    initialize_fields(GR, F)
+    if i_turb:
+        rng = np.random.default_rng(4)
+        for n, lo, hi in [('KMOM', 0.5, 20.), ('KHEAT', 0.5, 20.), ('SSHFLX', -50., 150.),
+                          ('SMOMXFLX', -0.2, 0.2), ('SMOMYFLX', -0.2, 0.2)]:
+            F.host[n][...] = rng.uniform(lo, hi, F.host[n].shape)
+    names = ['HSURF', 'COLP', 'UWIND', 'VWIND', 'POTT', 'WWIND', 'POTTVB', 'KMOM', 'KHEAT',
+             'SSHFLX', 'SMOMXFLX', 'SMOMYFLX', 'dPOTTdt_RAD']
+    state = {n: F.host[n].copy() for n in names}
+    o = Oracle(nx, ny, nz, GR.GRF['CPU'], state, pair_top=GR.nl.pair_top, i_turb=i_turb)
+    o.primary_diag()
+    o.step_matsuno(GR.dt, 3, with_rho=bool(i_turb))
+    core = HipDycore(nx, ny, nz, pair_top=GR.nl.pair_top, i_turb=i_turb)
+    core.set_grid(GR.GRF['HIP'])
+    for n, a in state.items():
+        core.upload(n, a)
+    core.primary_diag()
+    core.step_matsuno(GR.dt, 3)
+    for name in PROGNOSTIC + ['PHI', 'PVTF', 'PVTFVB', 'POTTVB', 'WWIND', 'UFLX', 'VFLX']:
+        got = core.download(name)
+        err, ncmp, bad = rel_max_err(got, o.F[name], name, nx, ny)
+        assert bad == 0 and ncmp > 0 and err <= STEP_TOL, '%s (%dx%dx%d): rel err %.3e, %d bad' % (name, nx, ny, nz, err, bad)
+    core.close()
+
+
+def test_config_errors_are_reported():
+    from climate_model_amd import HipDycore, DycoreError
+    with pytest.raises(DycoreError):
+        HipDycore(2, 18, 4)                 # nx too small
+    with pytest.raises(DycoreError):
+        HipDycore(36, 18, 1)                # nz too small
+    with pytest.raises(DycoreError):
+        HipDycore(36, 10, 4, ny_global=18, j_offset=12)   # band outside the grid
+    core = HipDycore(36, 18, 4)
+    with pytest.raises(DycoreError):
+        core.step_matsuno(1.0, 1)           # grid constants not set
+    with pytest.raises(DycoreError):
+        core.upload('NOFIELD', np.zeros((1, 1, 1)))
+    with pytest.raises(DycoreError):
+        core.upload('UWIND', np.zeros((3, 3, 3)))
+    core.close()

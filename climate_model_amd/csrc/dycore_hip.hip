@@ -89,12 +89,12 @@ constexpr int kNGrid = sizeof(kGrid) / sizeof(kGrid[0]);
 
 // kernels tracked by the profiler
 enum KernelId {
-    K_CONTINUITY = 0, K_PREPARE, K_UFLX, K_VFLX, K_POTT, K_EULER, K_DIAG, K_RHO, K_EXCHANGE, K_COPY, K_HALO, K_MOM_FUSED, K_POTT_FUSED, K_DIAG_ROWS, K_HALO_MULTI,
+    K_CONTINUITY = 0, K_PREPARE, K_UFLX, K_VFLX, K_POTT, K_EULER, K_DIAG, K_RHO, K_EXCHANGE, K_COPY, K_HALO, K_MOM_FUSED, K_POTT_FUSED, K_DIAG_ROWS, K_HALO_MULTI, K_CONT_REG, K_DERIVE,
     K_COUNT
 };
 const char *kKernelNames[K_COUNT] = {
     "k_continuity", "k_prepare", "k_uflx_tendency", "k_vflx_tendency", "k_pott_tendency",
-    "k_euler_forward", "k_primary_diag", "k_diag_rho", "k_exchange_bc", "copy_field", "k_rows", "k_momentum_fused", "k_pott_fused", "k_primary_diag_rows", "k_halo_multi",
+    "k_euler_forward", "k_primary_diag", "k_diag_rho", "k_exchange_bc", "copy_field", "k_rows", "k_momentum_fused", "k_pott_fused", "k_primary_diag_rows", "k_halo_multi", "k_continuity_reg", "k_derive",
 };
 
 struct ProfRec { int kid; hipEvent_t a, b; };
@@ -116,6 +116,8 @@ struct dycore {
     size_t stage_elems = 0;
     int grid_set = 0;
     bool fused = true;              // production kernels in dycore_step_matsuno (DYCORE_FUSED=0: stage kernels)
+    bool lazy = true;               // fused step leaves FLXDIV / PHIVB to be derived on demand (DYCORE_LAZY=0: store them)
+    bool stale_flxdiv = false, stale_phivb = false;
     int n_cu = 256;                 // compute units of the device
     int mom_tj = 0;                 // DYCORE_MOM_TJ: force the rows per momentum workgroup (8, 9, 10)
     int mom_ks = 0;                 // DYCORE_MOM_KS: force the level chunks per momentum tile (1, 2, 4)
@@ -185,11 +187,15 @@ int check_ready(dycore *h)
 }
 
 int join_side(dycore *h);
-// stage entry points read what the side stream may still be writing
+int refresh_lazy(dycore *h);
+// stage entry points read what the side stream may still be writing and what the fused step
+// left to be derived
 int ready_join(dycore *h)
 {
     int rc = check_ready(h);
-    return rc ? rc : join_side(h);
+    if (rc) return rc;
+    if ((rc = join_side(h))) return rc;
+    return refresh_lazy(h);
 }
 
 int launch_check(const char *what)
@@ -308,6 +314,46 @@ int do_copy(dycore *h, double *dst, const double *src, size_t elems)
     return 0;
 }
 
+// continuity of the fused step: running sums in registers, FLXDIV not stored
+int do_continuity_fused(dycore *h, const Ptrs &p, double dt)
+{
+    const int nz = h->g.nz;
+    if (!h->lazy || !(nz == 8 || nz == 16 || nz == 32 || nz == 64)) return do_continuity(h, p, dt);
+    {
+        Scope s(h, K_CONT_REG);
+        const dim3 gr = grid_for(h->g, h->g.nx, h->g.ny), bl(TI, TJ);
+        switch (nz) {
+        case 8: hipLaunchKernelGGL(k_continuity_reg<8>, gr, bl, 0, h->stream, h->g, p, dt); break;
+        case 16: hipLaunchKernelGGL(k_continuity_reg<16>, gr, bl, 0, h->stream, h->g, p, dt); break;
+        case 32: hipLaunchKernelGGL(k_continuity_reg<32>, gr, bl, 0, h->stream, h->g, p, dt); break;
+        default: hipLaunchKernelGGL(k_continuity_reg<64>, gr, bl, 0, h->stream, h->g, p, dt); break;
+        }
+        int rc = launch_check("k_continuity_reg");
+        if (rc) return rc;
+    }
+    h->stale_flxdiv = true;
+    return do_halo(h, {{p.UFLX, 1, 0, nz}, {p.VFLX, 0, 1, nz}, {p.WWIND, 0, 0, nz + 1}, {p.COLP_NEW, 0, 0, 1}});
+}
+// bring the on-demand fields up to date (called wherever they can be observed)
+int refresh_lazy(dycore *h)
+{
+    if (!h->stale_flxdiv && !h->stale_phivb) return 0;
+    int rc = join_side(h);
+    if (rc) return rc;
+    Scope s(h, K_DERIVE);
+    if (h->stale_flxdiv) {
+        hipLaunchKernelGGL(k_derive_flxdiv, grid_for(h->g, h->g.nx, h->g.ny), dim3(TI, TJ), 0, h->stream, h->g, h->p);
+        if ((rc = launch_check("k_derive_flxdiv"))) return rc;
+        h->stale_flxdiv = false;
+    }
+    if (h->stale_phivb) {
+        hipLaunchKernelGGL(k_derive_phivb, grid_for(h->g, h->g.nx + 2, h->g.ny + 2), dim3(TI, TJ), 0, h->stream, h->g, h->p);
+        if ((rc = launch_check("k_derive_phivb"))) return rc;
+        h->stale_phivb = false;
+    }
+    return 0;
+}
+
 // prepare + dUFLXdt + dVFLXdt (+ Euler step of the winds when u_out != nullptr)
 int do_momentum_fused(dycore *h, const Ptrs &p, const double *u_old, const double *v_old,
                       double *u_out, double *v_out, double dt)
@@ -361,7 +407,11 @@ int do_momentum_fused(dycore *h, const Ptrs &p, const double *u_old, const doubl
 int do_pott_fused(dycore *h, const Ptrs &p, const double *pott_old, double *pott_out, double dt)
 {
     Scope s(h, K_POTT_FUSED);
-    hipLaunchKernelGGL(k_pott_fused, grid_for(h->g, h->g.nx, h->g.ny), dim3(TI, TJ), 0, h->stream, h->g, p, pott_old, pott_out, dt);
+    if (h->lazy) {
+        hipLaunchKernelGGL(k_pott_fused<false>, grid_for(h->g, h->g.nx, h->g.ny), dim3(TI, TJ), 0, h->stream, h->g, p, pott_old, pott_out, dt);
+        h->stale_phivb = true;
+    } else
+        hipLaunchKernelGGL(k_pott_fused<true>, grid_for(h->g, h->g.nx, h->g.ny), dim3(TI, TJ), 0, h->stream, h->g, p, pott_old, pott_out, dt);
     return launch_check("k_pott_fused");
 }
 // primary diagnostics on the halo rows a band received from its neighbours
@@ -459,15 +509,20 @@ int substep_part(dycore *h, double dt, int sub, int part)
         double *t_out = sub == 0 ? p.POTT_EST : p.POTT;
         switch (part) {
         case 0:                     // -> UFLX, VFLX, WWIND, COLP_NEW halo rows
-            return do_continuity(h, q, dt);
+            return do_continuity_fused(h, q, dt);
         case 1: {                   // momentum reads the old diagnostics, so it runs first
             if ((rc = join_side(h))) return rc;
             if ((rc = do_momentum_fused(h, q, p.UWIND, p.VWIND, u_out, v_out, dt))) return rc;
             if ((rc = do_pott_fused(h, q, p.POTT, t_out, dt))) return rc;
             const int nz = h->g.nz;
-            if ((rc = do_halo(h, {{u_out, 1, 0, nz}, {v_out, 0, 1, nz}, {t_out, 0, 0, nz}, {p.PVTF, 0, 0, nz},
-                                  {p.PVTFVB, 0, 0, nz + 1}, {p.PHI, 0, 0, nz}, {p.PHIVB, 0, 0, nz + 1},
-                                  {p.POTTVB, 0, 0, nz + 1}}))) return rc;
+            if (h->lazy)
+                rc = do_halo(h, {{u_out, 1, 0, nz}, {v_out, 0, 1, nz}, {t_out, 0, 0, nz}, {p.PVTF, 0, 0, nz},
+                                 {p.PVTFVB, 0, 0, nz + 1}, {p.PHI, 0, 0, nz}, {p.POTTVB, 0, 0, nz + 1}});
+            else
+                rc = do_halo(h, {{u_out, 1, 0, nz}, {v_out, 0, 1, nz}, {t_out, 0, 0, nz}, {p.PVTF, 0, 0, nz},
+                                 {p.PVTFVB, 0, 0, nz + 1}, {p.PHI, 0, 0, nz}, {p.PHIVB, 0, 0, nz + 1},
+                                 {p.POTTVB, 0, 0, nz + 1}});
+            if (rc) return rc;
             return do_copy(h, p.COLP, p.COLP_NEW, (size_t)h->g.plane);   // -> winds, POTT halo rows
         }
         case 2: {
@@ -539,6 +594,7 @@ int dycore_create(const DycoreConfig *cfg, dycore_t **out)
     memset(&h->p, 0, sizeof h->p);
     if (const char *e = getenv("DYCORE_FUSED")) h->fused = atoi(e) != 0;
     if (const char *e = getenv("DYCORE_MOM_DMA")) h->mom_dma = atoi(e);
+    if (const char *e = getenv("DYCORE_LAZY")) h->lazy = atoi(e) != 0;
     if (const char *e = getenv("DYCORE_MOM_TJ")) h->mom_tj = atoi(e);
     if (const char *e = getenv("DYCORE_MOM_KS")) h->mom_ks = atoi(e);
     {
@@ -709,6 +765,7 @@ int dycore_download(dycore_t *h, const char *name, double *host)
     if (rc) return rc;
     if (!host) return fail(DYCORE_EINVAL, "null host pointer");
     if ((rc = join_side(h))) return rc;
+    if ((rc = refresh_lazy(h))) return rc;
     const Geo &g = h->g;
     const int n0 = g.nx + 2 + d->stgx, n1 = g.ny + 2 + d->stgy, n2 = h->nk_of(d->nk);
     const size_t n = (size_t)n0 * n1 * n2;
@@ -725,6 +782,7 @@ int dycore_field_ptr(dycore_t *h, const char *name, void **dev, int64_t *pitch, 
     const FieldDesc *d;
     int rc = find_field(h, name, &d);
     if (rc) return rc;
+    if ((rc = refresh_lazy(h))) return rc;
     if (dev) *dev = h->p.*(d->member);
     if (pitch) *pitch = h->g.P;
     if (rows) *rows = h->g.NJ;
@@ -740,6 +798,7 @@ int dycore_copy_field(dycore_t *h, const char *dst, const char *src)
     if (a->stgx != b->stgx || a->stgy != b->stgy || a->nk != b->nk)
         return fail(DYCORE_EINVAL, "copy_field: '%s' and '%s' differ in shape", dst, src);
     if ((rc = join_side(h))) return rc;
+    if ((rc = refresh_lazy(h))) return rc;
     return do_copy(h, h->p.*(a->member), h->p.*(b->member), h->field_elems(a->nk));
 }
 

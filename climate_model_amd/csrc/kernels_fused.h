@@ -19,6 +19,21 @@
 
 namespace dyc {
 
+// (p / 1e5) ** kappa of dyn_diagnostics.py:146-153.  DYC_POW_VARIANT 0: pow() as written in the
+// reference; 1: exp(kappa * (log(p) - log(1e5))), the same value to ~2 ulp at less than half
+// the instruction count (k_pott_fused is bound by fp64 instruction issue, not by HBM).
+#ifndef DYC_POW_VARIANT
+#define DYC_POW_VARIANT 0
+#endif
+__device__ __forceinline__ double exner_vb(double p)
+{
+#if DYC_POW_VARIANT == 1
+    return exp(CON_KAPPA * (log(p) - 11.512925464970229));   // log(100000)
+#else
+    return pow(p / 100000.0, CON_KAPPA);
+#endif
+}
+
 constexpr int FTI = 64;                // lanes along i per workgroup (one wavefront per row)
 constexpr int FTJ = 8;                 // rows per workgroup
 constexpr int FTW = 68;                // tile width: i-1 .. i+2 for 64 lanes (67), padded
@@ -829,6 +844,81 @@ __global__ __launch_bounds__(2 * FNT) void k_momentum_split(Geo g, Ptrs p, int g
 }
 
 // ------------------------------------------------------------------------------------
+// k_continuity_reg: dyn_continuity.py:170-232 with the running sums of the flux divergence kept
+// in registers (NZ is a compile-time constant, both level loops fully unrolled), so FLXDIV
+// makes no round trip through HBM: 2 reads + 3 writes per cell, the compulsory minimum of
+// this stage.  FLXDIV itself is not stored (k_derive_flxdiv re-derives it on demand).
+template <int NZ>
+__global__ __launch_bounds__(TI *TJ) void k_continuity_reg(Geo g, Ptrs p, double dt)
+{
+    DYC_IJ(1, 1)
+    if (i > g.nx || j > g.ny) return;
+    const size_t c = at2(g, i, j);
+    const double colp = p.COLP[c];
+    const double c_im1 = p.COLP[c - 1], c_ip1 = p.COLP[c + 1];
+    const double c_jm1 = p.COLP[c - g.P], c_jp1 = p.COLP[c + g.P];
+    const double dy_i = p.dyis[c], dy_ip1 = p.dyis[c + 1];
+    const double dx_j = p.dxjs[c], dx_jp1 = p.dxjs[c + g.P];
+    const double area = p.A[c];
+    // inputs and outputs never alias: lets the compiler issue the loads of later levels ahead
+    // of the stores of earlier ones in the unrolled loop
+    const double *__restrict__ uw = p.UWIND;
+    const double *__restrict__ vw = p.VWIND;
+    double *__restrict__ uflx = p.UFLX;
+    double *__restrict__ vflx = p.VFLX;
+    double pre[NZ];                     // pre[k] = sum of FLXDIV over the levels above k
+    double run = 0.0;
+#pragma unroll
+    for (int k = 0; k < NZ; k++) {
+        const size_t q = c + (size_t)k * g.plane;
+        const double uflx_i = (c_im1 + colp) / 2.0 * uw[q] * dy_i;
+        const double uflx_ip1 = (colp + c_ip1) / 2.0 * uw[q + 1] * dy_ip1;
+        const double vflx_j = (c_jm1 + colp) / 2.0 * vw[q] * dx_j;
+        const double vflx_jp1 = (colp + c_jp1) / 2.0 * vw[q + g.P] * dx_jp1;
+        uflx[q] = uflx_i;
+        vflx[q] = vflx_j;
+        const double div = (uflx_ip1 - uflx_i + vflx_jp1 - vflx_j) * p.dsigma[k] / area;
+        pre[k] = run;
+        run += div;
+    }
+    const double dcolpdt = -run;
+    const double colp_new = p.COLP_OLD[c] + dt * dcolpdt;
+    p.dCOLPdt[c] = dcolpdt;
+    p.COLP_NEW[c] = colp_new;
+    p.WWIND[c] = 0.0;
+    p.WWIND[c + (size_t)NZ * g.plane] = 0.0;
+#pragma unroll
+    for (int k = 1; k < NZ; k++)
+        p.WWIND[c + (size_t)k * g.plane] = -pre[k] / colp_new - p.sigma_vb[k] * dcolpdt / colp_new;
+}
+
+// Fields the fused step does not store, re-derived when somebody asks for them:
+// FLXDIV (dyn_continuity.py:46-47) from UFLX, VFLX;  PHIVB (dyn_diagnostics.py:160-174) from
+// PHI, POTT, PVTF, PVTFVB, HSURF -- whole array including halos, like diag_PHI.
+__global__ __launch_bounds__(TI *TJ) void k_derive_flxdiv(Geo g, Ptrs p)
+{
+    DYC_IJ(1, 1)
+    if (i > g.nx || j > g.ny) return;
+    const size_t c = at2(g, i, j);
+    const double area = p.A[c];
+    for (int k = 0; k < g.nz; k++) {
+        const size_t q = c + (size_t)k * g.plane;
+        p.FLXDIV[q] = (p.UFLX[q + 1] - p.UFLX[q] + p.VFLX[q + g.P] - p.VFLX[q]) * p.dsigma[k] / area;
+    }
+}
+__global__ __launch_bounds__(TI *TJ) void k_derive_phivb(Geo g, Ptrs p)
+{
+    DYC_IJ(0, 0)
+    if (i > g.nx + 1 || j > g.ny + 1) return;
+    const size_t c = at2(g, i, j);
+    p.PHIVB[c + (size_t)g.nz * g.plane] = p.HSURF[c] * CON_G;
+    for (int k = 0; k < g.nz; k++) {
+        const size_t q = c + (size_t)k * g.plane;
+        p.PHIVB[q] = p.PHI[q] - CON_CP * (p.POTT[q] * (p.PVTFVB[q] - p.PVTF[q]));
+    }
+}
+
+// ------------------------------------------------------------------------------------
 // k_pott_fused: dPOTTdt (dyn_POTT.py:180-216) + Euler step of POTT (dyn_timestep.py:70-79)
 // + primary diagnostics PVTF, PVTFVB, PHI, PHIVB, POTTVB of the NEW state
 // (dyn_diagnostics.py:139-195) in one bottom-up sweep per column.  dPOTTdt never reaches
@@ -837,6 +927,7 @@ __global__ __launch_bounds__(2 * FNT) void k_momentum_split(Geo g, Ptrs p, int g
 // cells; halos of every output by k_halo_multi afterwards).  POTTVB is updated in place: interface k+1 is rewritten only after its old
 // value has been consumed by the vertical advection of levels k+1 and k.
 // Dry dycore only (the turbulence-coupled path uses the stage kernels).
+template <bool WRITE_PHIVB>
 __global__ __launch_bounds__(TI *TJ) void k_pott_fused(Geo g, Ptrs p, const double *pott_old, double *pott_out, double dt)
 {
     DYC_IJ(1, 1)
@@ -846,30 +937,53 @@ __global__ __launch_bounds__(TI *TJ) void k_pott_fused(Geo g, Ptrs p, const doub
     const double colp = p.COLP[c], cnew = p.COLP_NEW[c], cold = p.COLP_OLD[c];
     const double c_im1 = p.COLP[c - 1], c_ip1 = p.COLP[c + 1], c_jm1 = p.COLP[c - P], c_jp1 = p.COLP[c + P];
     const double area = p.A[c];
+#ifdef DYC_RCP
+    const double r_area = 1.0 / area, r_cnew = 1.0 / cnew;
+#endif
     // surface interface of the new column
     double p_kp12 = g.pair_top + p.sigma_vb[nz] * cnew;
-    double pvb_kp1 = pow(p_kp12 / 100000.0, CON_KAPPA);
+    double pvb_kp1 = exner_vb(p_kp12);
     double phivb_kp1 = p.HSURF[c] * CON_G;
     p.PVTFVB[at(g, i, j, nz)] = pvb_kp1;
-    p.PHIVB[at(g, i, j, nz)] = phivb_kp1;
+    if (WRITE_PHIVB) p.PHIVB[at(g, i, j, nz)] = phivb_kp1;
     double w_kp1 = p.WWIND[c + (size_t)nz * g.plane];
     double pvbo_kp1 = p.POTTVB[c + (size_t)nz * g.plane];        // old interface values
     double pottn_kp1 = 0.0, pvtf_kp1 = 0.0, pottvb_first = 0.0;
+    // software pipeline: the inputs of level k-1 are requested before level k is computed, so the
+    // HBM latency overlaps the pow/division chain instead of preceding it (the kernel is
+    // latency-bound: 3 waves per SIMD, one dependent chain per level)
+    struct In { double pt, im1, ip1, jm1, jp1, uf, uf1, vf, vf1, w, pvb, po; };
+    auto load = [&](int k) {
+        In r;
+        const size_t q = c + (size_t)k * g.plane;
+        r.pt = p.POTT[q]; r.im1 = p.POTT[q - 1]; r.ip1 = p.POTT[q + 1]; r.jm1 = p.POTT[q - P]; r.jp1 = p.POTT[q + P];
+        r.uf = p.UFLX[q]; r.uf1 = p.UFLX[q + 1]; r.vf = p.VFLX[q]; r.vf1 = p.VFLX[q + P];
+        r.w = p.WWIND[q]; r.pvb = p.POTTVB[q]; r.po = pott_old[q];
+        return r;
+    };
+    In nx_ = load(nz - 1);
 #pragma unroll 1
     for (int k = nz - 1; k >= 0; k--) {
         const size_t q = c + (size_t)k * g.plane;
-        const double pt = p.POTT[q];
-        const double p_im1 = p.POTT[q - 1], p_ip1 = p.POTT[q + 1], p_jm1 = p.POTT[q - P], p_jp1 = p.POTT[q + P];
+        const In cur = nx_;
+        if (k > 0) nx_ = load(k - 1);
+        const double pt = cur.pt;
+        const double p_im1 = cur.im1, p_ip1 = cur.ip1, p_jm1 = cur.jm1, p_jp1 = cur.jp1;
         const double ds = p.dsigma[k];
         double t = 0.0;
-        t = t + (+p.UFLX[q] * (p_im1 + pt) / 2.0 - p.UFLX[q + 1] * (pt + p_ip1) / 2.0
-                 + p.VFLX[q] * (p_jm1 + pt) / 2.0 - p.VFLX[q + P] * (pt + p_jp1) / 2.0) / area;
+        t = t + (+cur.uf * (p_im1 + pt) / 2.0 - cur.uf1 * (pt + p_ip1) / 2.0
+                 + cur.vf * (p_jm1 + pt) / 2.0 - cur.vf1 * (pt + p_jp1) / 2.0)
+#ifdef DYC_RCP
+                * r_area;
+#else
+                / area;
+#endif
         double w_k = 0.0, pvbo_k = 0.0;
         if (k == 0) {
             t = t + cnew * (-w_kp1 * pvbo_kp1) / ds;
         } else {
-            w_k = p.WWIND[q];
-            pvbo_k = p.POTTVB[q];
+            w_k = cur.w;
+            pvbo_k = cur.pvb;
             t = t + cnew * (+w_k * pvbo_k - w_kp1 * pvbo_kp1) / ds;
         }
         const double dif = p.POTT_dif_coef[k];
@@ -877,18 +991,22 @@ __global__ __launch_bounds__(TI *TJ) void k_pott_fused(Geo g, Ptrs p, const doub
             t = t + dif * (c_im1 * p_im1 + c_ip1 * p_ip1 + c_jm1 * p_jm1 + c_jp1 * p_jp1 - 4.0 * colp * pt);
         if (g.i_rad) t = t + p.dPOTTdt_RAD[q] * colp;
         // Euler forward, pressure weighted
-        const double pott = pott_old[q] * cold / cnew + dt * t / cnew;
+#ifdef DYC_RCP
+        const double pott = cur.po * cold * r_cnew + dt * t * r_cnew;
+#else
+        const double pott = cur.po * cold / cnew + dt * t / cnew;
+#endif
         pott_out[at(g, i, j, k)] = pott;
         // diagnostics of the new column, level k
         const double p_km12 = g.pair_top + p.sigma_vb[k] * cnew;
-        const double pvb_k = pow(p_km12 / 100000.0, CON_KAPPA);
+        const double pvb_k = exner_vb(p_km12);
         const double pvtf = 1.0 / (1.0 + CON_KAPPA) * (pvb_kp1 * p_kp12 - pvb_k * p_km12) / (p_kp12 - p_km12);
         const double phi = phivb_kp1 - CON_CP * (pott * (pvtf - pvb_kp1));
         const double phivb = phi - CON_CP * (pott * (pvb_k - pvtf));
         p.PVTF[at(g, i, j, k)] = pvtf;
         p.PVTFVB[at(g, i, j, k)] = pvb_k;
         p.PHI[at(g, i, j, k)] = phi;
-        p.PHIVB[at(g, i, j, k)] = phivb;
+        if (WRITE_PHIVB) p.PHIVB[at(g, i, j, k)] = phivb;
         if (k < nz - 1) {
             const double vb = ((pvb_kp1 - pvtf) * pott + (pvtf_kp1 - pvb_kp1) * pottn_kp1) / (pvtf_kp1 - pvtf);
             p.POTTVB[at(g, i, j, k + 1)] = vb;

@@ -144,7 +144,7 @@ def test_fused_momentum_equals_stage_kernels(monkeypatch):
         core.primary_diag()
         core.step_matsuno(GR.dt, 2)
         out[fused] = {n: core.download(n) for n in ['UWIND', 'VWIND', 'POTT', 'COLP', 'PHI', 'PHIVB', 'PVTF', 'PVTFVB',
-                                                    'POTTVB', 'WWIND', 'UFLX', 'VFLX', 'COLP_NEW']}
+                                                    'POTTVB', 'WWIND', 'UFLX', 'VFLX', 'COLP_NEW', 'FLXDIV', 'dCOLPdt']}
         core.close()
     nx, ny = GR.nx, GR.ny
     for n in out['1']:

@@ -377,10 +377,16 @@ __global__ __launch_bounds__(FTI *TJ) void k_momentum_dma(Geo g, Ptrs p, int gbx
         double *buf = dsm + b * BUF;
         if (wave < NSL) {
             if (dma_on) {
+                // rows a field really needs below j-1: UFLX, winds, WWIND j+1 (TJ+2 rows), VFLX j+2
+                // (all TJ+3), PHI/POTT/PVTF/PVTFVB only j-1 and j (TJ+1): skip the chunks beyond
+                constexpr int rows_f[FNF] = {TJ + 2, TJ + 3, TJ + 2, TJ + 2, TJ + 2, TJ + 1, TJ + 1, TJ + 1, TJ + 1};
+                const int ch = wave * 64 + lane;
 #pragma unroll
                 for (int f = 0; f < FNF; f++) {
-                    const double *gp = src[f] + (size_t)(k + kofs[f]) * g.plane + goff;
-                    __builtin_amdgcn_global_load_lds((gbl_void_t *)gp, (lds_void_t *)(buf + f * TN + wave * 128), 16, 0, 0);
+                    if (ch < rows_f[f] * (FTW / 2)) {
+                        const double *gp = src[f] + (size_t)(k + kofs[f]) * g.plane + goff;
+                        __builtin_amdgcn_global_load_lds((gbl_void_t *)gp, (lds_void_t *)(buf + f * TN + wave * 128), 16, 0, 0);
+                    }
                 }
             }
         } else if (!OLD_IS_CUR && wave >= TJ - 2) {

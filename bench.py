@@ -125,9 +125,16 @@ def main():
     from climate_model_amd.fields import FIELD_TABLE
     from climate_model_amd.synthetic import initialize_fields
 
+    # rehearsal switches (tests only): all ranks on one GPU, gloo instead of RCCL
+    backend = os.environ.get('DYCORE_BANDS_BACKEND', 'nccl')
+    if os.environ.get('DYCORE_BANDS_ONE_GPU'):
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        else:
+            dist.init_process_group(backend)
     stream = torch.cuda.Stream()
     torch.cuda.set_stream(stream)
 
@@ -170,9 +177,27 @@ def main():
     stats = core.kernel_stats()
     core.profile(False)
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
+        t = torch.tensor([elapsed], dtype=torch.float64, device='cuda' if backend == 'nccl' else 'cpu')
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+
+    # measured device-to-device copy ceiling of this GPU (reported next to the 8 TB/s spec peak)
+    copy_gbs = None
+    try:
+        nbytes = min(core.field_shape('UWIND')[0] * core.field_shape('UWIND')[1] * core.field_shape('UWIND')[2] * 8, 1 << 30)
+        a = torch.empty(nbytes // 8, dtype=torch.float64, device='cuda')
+        b = torch.empty_like(a)
+        b.copy_(a)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            b.copy_(a)
+        e1.record()
+        e1.synchronize()
+        copy_gbs = 2 * nbytes * 10 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+        del a, b
+    except Exception:
+        copy_gbs = None
 
     # sanity: the state must still be finite (a diverged run is not a measurement)
     u = core.download('UWIND')
@@ -208,6 +233,7 @@ def main():
                 'algorithmic_bytes_per_launch': per_launch_bytes, 'avg_launch_ms': dom_ms / dom_n,
                 'launches': dom_n,
                 'step_achieved': step_ach, 'step_frac': step_ach / HBM_PEAK_GBS,
+                'measured_copy_GBs': copy_gbs,
                 'kernels_ms_per_step': {k: tot / args.steps for k, (n, tot) in stats.items() if n}}
 
     line = {

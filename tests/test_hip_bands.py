@@ -87,3 +87,20 @@ def test_two_process_gloo_bands_equal_single(tmp_path):
     z = np.load(out)
     for n in ('COLP', 'UWIND', 'VWIND', 'POTT'):
         np.testing.assert_array_equal(z[n], ref[n], err_msg=n)
+
+
+def test_bench_two_ranks_rehearsal():
+    """bench.py's N > 1 path (band set-up, exchange, barrier, max-over-ranks, JSON line) with two
+    ranks on the one GPU and gloo instead of RCCL, on a small grid."""
+    import json
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0', DYCORE_BANDS_BACKEND='gloo', DYCORE_BANDS_ONE_GPU='1')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
+           '--master-addr', '127.0.0.1', '--master-port', str(port),
+           os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1', '--dlat', '2', '--nz', '16']
+    r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith('{')][-1]
+    j = json.loads(line)
+    assert j['n_gpus'] == 2 and j['steps'] == 3 and j['value'] > 0 and j['scaling'] == 'strong'
+    assert j['roofline'] and j['roofline']['frac'] > 0

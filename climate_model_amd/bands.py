@@ -96,14 +96,16 @@ class BandHalo:
         self.has_south, self.has_north = has_south, has_north
         self._resolved = {}
         self.plan = {}
+        moist = bool(getattr(core, 'i_moist', False))       # QV, QC travel with the state (phase B)
         for ph in ('A', 'B'):
-            sn = [f for f, _ in SEND_NORTH[ph]]
-            ss = [f for f, _ in SEND_SOUTH[ph]]
+            extra = [('QV', None), ('QC', None)] if (moist and ph == 'B') else []
+            sn = [f for f, _ in SEND_NORTH[ph]] + [f for f, _ in extra]
+            ss = [f for f, _ in SEND_SOUTH[ph]] + [f for f, _ in extra]
             self.plan[ph] = dict(
-                send_north=(sn, _resolve([r for _, r in SEND_NORTH[ph]], ny)),
-                send_south=(ss, _resolve([r for _, r in SEND_SOUTH[ph]], ny)),
-                recv_south=(sn, _resolve(RECV_FROM_SOUTH[ph], ny)),      # neighbour's send_north list
-                recv_north=(ss, _resolve(RECV_FROM_NORTH[ph], ny)),      # neighbour's send_south list
+                send_north=(sn, _resolve([r for _, r in SEND_NORTH[ph]] + ['N'] * len(extra), ny)),
+                send_south=(ss, _resolve([r for _, r in SEND_SOUTH[ph]] + [1] * len(extra), ny)),
+                recv_south=(sn, _resolve(RECV_FROM_SOUTH[ph] + [0] * len(extra), ny)),      # neighbour's send_north list
+                recv_north=(ss, _resolve(RECV_FROM_NORTH[ph] + ['N+1'] * len(extra), ny)),  # neighbour's send_south list
             )
 
     def sizes(self, ph):

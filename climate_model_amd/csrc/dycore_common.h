@@ -20,6 +20,7 @@ constexpr double CON_RE = 6371000.0;
 constexpr double CON_RD = 287.058;
 constexpr double CON_CP = 1005.0;
 constexpr double CON_KAPPA = CON_RD / CON_CP;
+constexpr double CON_LH = 2264E3;       // io_constants.py:24
 
 struct Geo {
     int nx, ny, nz;        // local extents (ny = band height)
@@ -28,7 +29,7 @@ struct Geo {
     long long plane;       // P * NJ
     int ny_global, joff;   // global row = local row + joff
     int pole_s, pole_n;    // this band touches the south / north wall
-    int i_turb, i_rad;
+    int i_turb, i_rad, i_moist;
     double pair_top;
 };
 
@@ -49,10 +50,12 @@ struct Ptrs {
     double *PVTF, *PVTFVB, *PHI, *PHIVB;
     double *RHO, *RHOVB, *KMOM, *KHEAT;
     double *SSHFLX, *SMOMXFLX, *SMOMYFLX, *dPOTTdt_RAD;
+    // moisture (dyn_moist.py)
+    double *QV, *QV_OLD, *QC, *QC_OLD, *dQVdt, *dQCdt, *dQVdt_TURB, *SLHFLX, *QV_EST, *QC_EST;
     // grid constants, 2-D
     const double *A, *dxjs, *dyis, *corf, *corf_is, *lat_rad, *lat_is_rad, *dlon_rad, *dlat_rad;
     // grid constants, vertical 1-D
-    const double *sigma_vb, *dsigma, *UVFLX_dif_coef, *POTT_dif_coef;
+    const double *sigma_vb, *dsigma, *UVFLX_dif_coef, *POTT_dif_coef, *moist_dif_coef;
 };
 
 __device__ __forceinline__ size_t at(const Geo &g, int i, int j, int k)

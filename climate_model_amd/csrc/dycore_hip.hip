@@ -68,6 +68,8 @@ const FieldDesc kFields[] = {
     F_(PVTF, 0, 0, 0), F_(PVTFVB, 0, 0, -1), F_(PHI, 0, 0, 0), F_(PHIVB, 0, 0, -1),
     F_(RHO, 0, 0, 0), F_(RHOVB, 0, 0, -1), F_(KMOM, 0, 0, -1), F_(KHEAT, 0, 0, -1),
     F_(SSHFLX, 0, 0, 1), F_(SMOMXFLX, 0, 0, 1), F_(SMOMYFLX, 0, 0, 1), F_(dPOTTdt_RAD, 0, 0, 0),
+    F_(QV, 0, 0, 0), F_(QV_OLD, 0, 0, 0), F_(QC, 0, 0, 0), F_(QC_OLD, 0, 0, 0), F_(dQVdt, 0, 0, 0), F_(dQCdt, 0, 0, 0),
+    F_(dQVdt_TURB, 0, 0, 0), F_(SLHFLX, 0, 0, 1), F_(QV_EST, 0, 0, 0), F_(QC_EST, 0, 0, 0),
 };
 #undef F_
 constexpr int kNFields = sizeof(kFields) / sizeof(kFields[0]);
@@ -83,18 +85,19 @@ const GridDesc kGrid[] = {
     G_(A, 0, 0, 1), G_(dxjs, 0, 1, 1), G_(dyis, 1, 0, 1), G_(corf, 0, 0, 1), G_(corf_is, 1, 0, 1),
     G_(lat_rad, 0, 0, 1), G_(lat_is_rad, 1, 0, 1), G_(dlon_rad, 0, 1, 1), G_(dlat_rad, 1, 0, 1),
     G_(sigma_vb, -1, 0, -1), G_(dsigma, -1, 0, 0), G_(UVFLX_dif_coef, -1, 0, 0), G_(POTT_dif_coef, -1, 0, 0),
+    G_(moist_dif_coef, -1, 0, 0),       // must stay last: optional unless i_moist
 };
 #undef G_
 constexpr int kNGrid = sizeof(kGrid) / sizeof(kGrid[0]);
 
 // kernels tracked by the profiler
 enum KernelId {
-    K_CONTINUITY = 0, K_PREPARE, K_UFLX, K_VFLX, K_POTT, K_EULER, K_DIAG, K_RHO, K_EXCHANGE, K_COPY, K_HALO, K_MOM_FUSED, K_POTT_FUSED, K_DIAG_ROWS, K_HALO_MULTI, K_CONT_REG, K_DERIVE,
+    K_CONTINUITY = 0, K_PREPARE, K_UFLX, K_VFLX, K_POTT, K_EULER, K_DIAG, K_RHO, K_EXCHANGE, K_COPY, K_HALO, K_MOM_FUSED, K_POTT_FUSED, K_DIAG_ROWS, K_HALO_MULTI, K_CONT_REG, K_DERIVE, K_MOIST,
     K_COUNT
 };
 const char *kKernelNames[K_COUNT] = {
     "k_continuity", "k_prepare", "k_uflx_tendency", "k_vflx_tendency", "k_pott_tendency",
-    "k_euler_forward", "k_primary_diag", "k_diag_rho", "k_exchange_bc", "copy_field", "k_rows", "k_momentum_fused", "k_pott_fused", "k_primary_diag_rows", "k_halo_multi", "k_continuity_reg", "k_derive",
+    "k_euler_forward", "k_primary_diag", "k_diag_rho", "k_exchange_bc", "copy_field", "k_rows", "k_momentum_fused", "k_pott_fused", "k_primary_diag_rows", "k_halo_multi", "k_continuity_reg", "k_derive", "k_moist",
 };
 
 struct ProfRec { int kid; hipEvent_t a, b; };
@@ -181,7 +184,9 @@ dim3 grid_for(const Geo &g, int ni, int nj) { return dim3((ni + TI - 1) / TI, (n
 int check_ready(dycore *h)
 {
     if (!h) return fail(DYCORE_EINVAL, "null handle");
-    if (h->grid_set != (1 << kNGrid) - 1)
+    int need = (1 << kNGrid) - 1;
+    if (!h->g.i_moist) need &= ~(1 << (kNGrid - 1));      // moist_dif_coef only with moisture
+    if ((h->grid_set & need) != need)
         return fail(DYCORE_ESTATE, "grid constants missing: call dycore_set_grid for all %d arrays first", kNGrid);
     return 0;
 }
@@ -286,6 +291,8 @@ int do_euler(dycore *h, const Ptrs &p, double dt)
         if (rc) return rc;
     }
     const int nz = h->g.nz;
+    if (h->g.i_moist)
+        return do_halo(h, {{p.POTT, 0, 0, nz}, {p.VWIND, 0, 1, nz}, {p.UWIND, 1, 0, nz}, {p.QV, 0, 0, nz}, {p.QC, 0, 0, nz}});
     return do_halo(h, {{p.POTT, 0, 0, nz}, {p.VWIND, 0, 1, nz}, {p.UWIND, 1, 0, nz}});
 }
 int do_diag(dycore *h, const Ptrs &p)
@@ -414,6 +421,21 @@ int do_pott_fused(dycore *h, const Ptrs &p, const double *pott_old, double *pott
         hipLaunchKernelGGL(k_pott_fused<true>, grid_for(h->g, h->g.nx, h->g.ny), dim3(TI, TJ), 0, h->stream, h->g, p, pott_old, pott_out, dt);
     return launch_check("k_pott_fused");
 }
+// dQVdt, dQCdt (stage) or the new QV, QC directly (fused): dyn_moist.py
+int do_moist(dycore *h, const Ptrs &p, const double *qv_old, const double *qc_old, double *qv_out, double *qc_out, double dt)
+{
+    Scope s(h, K_MOIST);
+    const dim3 gr = grid_for(h->g, h->g.nx, h->g.ny), bl(TI, TJ);
+    if (qv_out) {
+        if (h->g.i_turb) hipLaunchKernelGGL((k_moist<true, true>), gr, bl, 0, h->stream, h->g, p, qv_old, qc_old, qv_out, qc_out, dt);
+        else hipLaunchKernelGGL((k_moist<false, true>), gr, bl, 0, h->stream, h->g, p, qv_old, qc_old, qv_out, qc_out, dt);
+    } else {
+        if (h->g.i_turb) hipLaunchKernelGGL((k_moist<true, false>), gr, bl, 0, h->stream, h->g, p, qv_old, qc_old, qv_out, qc_out, dt);
+        else hipLaunchKernelGGL((k_moist<false, false>), gr, bl, 0, h->stream, h->g, p, qv_old, qc_old, qv_out, qc_out, dt);
+    }
+    return launch_check("k_moist");
+}
+
 // primary diagnostics on the halo rows a band received from its neighbours
 // The two rows are a 64-level serial recursion on ~3000 columns (latency-bound, ~60 us): they
 // run on a side stream behind the unpack of the received POTT rows and are joined again before
@@ -485,6 +507,7 @@ int step_begin(dycore *h, int with_rho)
     std::swap(p.VWIND, p.VWIND_OLD);
     std::swap(p.POTT, p.POTT_OLD);
     std::swap(p.COLP, p.COLP_OLD);
+    if (h->g.i_moist) { std::swap(p.QV, p.QV_OLD); std::swap(p.QC, p.QC_OLD); }
     return 0;
 }
 // the fields the tendencies of a substep are evaluated on
@@ -492,9 +515,10 @@ Ptrs substep_view(dycore *h, int sub)
 {
     Ptrs q = h->p;
     if (fused_path(h)) {
-        if (sub == 1) { q.UWIND = h->p.UWIND_EST; q.VWIND = h->p.VWIND_EST; q.POTT = h->p.POTT_EST; }
+        if (sub == 1) { q.UWIND = h->p.UWIND_EST; q.VWIND = h->p.VWIND_EST; q.POTT = h->p.POTT_EST; q.QV = h->p.QV_EST; q.QC = h->p.QC_EST; }
     } else if (sub == 0) {         // predictor: the current state IS the *_OLD buffers
         q.UWIND = h->p.UWIND_OLD; q.VWIND = h->p.VWIND_OLD; q.POTT = h->p.POTT_OLD; q.COLP = h->p.COLP_OLD;
+        q.QV = h->p.QV_OLD; q.QC = h->p.QC_OLD;
     }
     return q;
 }
@@ -514,7 +538,10 @@ int substep_part(dycore *h, double dt, int sub, int part)
             if ((rc = join_side(h))) return rc;
             if ((rc = do_momentum_fused(h, q, p.UWIND, p.VWIND, u_out, v_out, dt))) return rc;
             if ((rc = do_pott_fused(h, q, p.POTT, t_out, dt))) return rc;
+            double *qv_out = sub == 0 ? p.QV_EST : p.QV, *qc_out = sub == 0 ? p.QC_EST : p.QC;
+            if (h->g.i_moist && (rc = do_moist(h, q, p.QV, p.QC, qv_out, qc_out, dt))) return rc;
             const int nz = h->g.nz;
+            if (h->g.i_moist && (rc = do_halo(h, {{qv_out, 0, 0, nz}, {qc_out, 0, 0, nz}}))) return rc;
             if (h->lazy)
                 rc = do_halo(h, {{u_out, 1, 0, nz}, {v_out, 0, 1, nz}, {t_out, 0, 0, nz}, {p.PVTF, 0, 0, nz},
                                  {p.PVTFVB, 0, 0, nz + 1}, {p.PHI, 0, 0, nz}, {p.POTTVB, 0, 0, nz + 1}});
@@ -539,6 +566,7 @@ int substep_part(dycore *h, double dt, int sub, int part)
     case 1:
         if ((rc = do_momentum(h, q))) return rc;
         if ((rc = do_pott(h, q))) return rc;
+        if (h->g.i_moist && (rc = do_moist(h, q, nullptr, nullptr, nullptr, nullptr, dt))) return rc;
         // COLP <- COLP_NEW (dyn_matsuno.py:64-67), then the Euler step writes p.UWIND/VWIND/POTT
         if ((rc = do_copy(h, p.COLP, p.COLP_NEW, (size_t)h->g.plane))) return rc;
         return do_euler(h, p, dt);  // -> needs UWIND, VWIND, POTT halo rows afterwards
@@ -589,7 +617,7 @@ int dycore_create(const DycoreConfig *cfg, dycore_t **out)
     g.ny_global = cfg->ny_global; g.joff = cfg->j_offset;
     g.pole_s = (cfg->j_offset == 0);
     g.pole_n = (cfg->j_offset + cfg->ny == cfg->ny_global);
-    g.i_turb = cfg->i_turb != 0; g.i_rad = cfg->i_radiation != 0;
+    g.i_turb = cfg->i_turb != 0; g.i_rad = cfg->i_radiation != 0; g.i_moist = cfg->i_moist != 0;
     g.pair_top = cfg->pair_top;
     memset(&h->p, 0, sizeof h->p);
     if (const char *e = getenv("DYCORE_FUSED")) h->fused = atoi(e) != 0;
@@ -816,6 +844,13 @@ int dycore_momentum_prepare(dycore_t *h) { int rc = ready_join(h); return rc ? r
 int dycore_uflx_tendency(dycore_t *h) { int rc = ready_join(h); return rc ? rc : do_uflx(h, h->p); }
 int dycore_vflx_tendency(dycore_t *h) { int rc = ready_join(h); return rc ? rc : do_vflx(h, h->p); }
 int dycore_pott_tendency(dycore_t *h) { int rc = ready_join(h); return rc ? rc : do_pott(h, h->p); }
+int dycore_moist_tendency(dycore_t *h)
+{
+    int rc = ready_join(h);
+    if (rc) return rc;
+    if (!h->g.i_moist) return fail(DYCORE_ESTATE, "handle created without i_moist");
+    return do_moist(h, h->p, nullptr, nullptr, nullptr, nullptr, 0.0);
+}
 int dycore_euler_forward(dycore_t *h, double dt) { int rc = ready_join(h); return rc ? rc : do_euler(h, h->p, dt); }
 int dycore_primary_diag(dycore_t *h) { int rc = ready_join(h); return rc ? rc : do_diag(h, h->p); }
 int dycore_secondary_diag_rho(dycore_t *h) { int rc = ready_join(h); return rc ? rc : do_rho(h, h->p); }
@@ -852,6 +887,8 @@ const char *dycore_substep_field(dycore_t *h, int32_t substep, const char *name)
         if (!strcmp(name, "UWIND")) return "UWIND_EST";
         if (!strcmp(name, "VWIND")) return "VWIND_EST";
         if (!strcmp(name, "POTT")) return "POTT_EST";
+        if (!strcmp(name, "QV")) return "QV_EST";
+        if (!strcmp(name, "QC")) return "QC_EST";
     }
     return name;
 }

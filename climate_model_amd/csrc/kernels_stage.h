@@ -448,6 +448,105 @@ __global__ __launch_bounds__(TI *TJ) void k_pott_tendency(Geo g, Ptrs p)
 }
 
 // ------------------------------------------------------------------------------------
+// dyn_functions.py:70-95: interface value by logarithmic interpolation (Python's max(VAR,
+// min_val): the first argument unless the second is greater)
+__device__ __forceinline__ double varvb_log(double var, double var_km1)
+{
+    const double min_val = 0.0000001;
+    if (min_val > var) var = min_val;
+    if (min_val > var_km1) var_km1 = min_val;
+    if (var_km1 == var) return var;
+    return (log(var_km1) - log(var)) / (1.0 / var - 1.0 / var_km1);
+}
+
+// dyn_functions.py:26-67
+__device__ __forceinline__ double turb_flux(double phi, double phi_kp1, double phi_km1, double phivb,
+                                            double phivb_kp1, double var, double var_kp1, double var_km1,
+                                            double kvar, double kvar_kp1, double rho, double rhovb,
+                                            double rhovb_kp1, double colp, double surf, int k, int nz)
+{
+    const double alt = phi / CON_G, alt_kp1 = phi_kp1 / CON_G, alt_km1 = phi_km1 / CON_G;
+    const double altvb = phivb / CON_G, altvb_kp1 = phivb_kp1 / CON_G;
+    if (k == 0)
+        return colp * ((0.0 - ((var - var_kp1) / (alt - alt_kp1) * rhovb_kp1 * kvar_kp1)) / ((altvb - altvb_kp1) * rho));
+    if (k == nz - 1)
+        return colp * ((((var_km1 - var) / (alt_km1 - alt) * rhovb * kvar) + surf) / ((altvb - altvb_kp1) * rho));
+    return colp * ((((var_km1 - var) / (alt_km1 - alt) * rhovb * kvar)
+                    - ((var - var_kp1) / (alt - alt_kp1) * rhovb_kp1 * kvar_kp1)) / ((altvb - altvb_kp1) * rho));
+}
+
+// dQVdt, dQCdt: dyn_moist.py:201-243 and :49-129.  Owned i in [1,nx], j in [1,ny].
+// EULER: apply the pressure-weighted Euler step (dyn_timestep.py:291-296) in the same thread and
+// write the new QV/QC to q?_out instead of storing the tendencies (fused production path).
+// The interface value below the bottom level is an unchecked out-of-range read in the
+// reference, multiplied by WWIND[nz] = 0: taken as 0 here.
+template <bool TURB, bool EULER>
+__global__ __launch_bounds__(TI *TJ) void k_moist(Geo g, Ptrs p, const double *qv_old, const double *qc_old,
+                                                  double *qv_out, double *qc_out, double dt)
+{
+    DYC_IJ(1, 1)
+    if (i > g.nx || j > g.ny) return;
+    const int P = g.P, nz = g.nz;
+    const size_t c = at2(g, i, j);
+    const double colp = p.COLP[c], colp_new = p.COLP_NEW[c], colp_old = p.COLP_OLD[c];
+    const double c_im1 = p.COLP[c - 1], c_ip1 = p.COLP[c + 1], c_jm1 = p.COLP[c - P], c_jp1 = p.COLP[c + P];
+    const double area = p.A[c];
+    double surf = 0.0;
+    if (TURB) surf = p.SLHFLX[c] / CON_LH;
+    double qv_km1 = 0.0, qc_km1 = 0.0, phi_km1 = 0.0;
+    double fv_k = 0.0, fc_k = 0.0;                 // W * interface value at interface k (0 at the top)
+    double qv_k = p.QV[c], qc_k = p.QC[c];
+    for (int k = 0; k < nz; k++) {
+        const size_t q = c + (size_t)k * g.plane;
+        const double ds = p.dsigma[k], dif = p.moist_dif_coef[k];
+        const double uflx = p.UFLX[q], uflx_ip1 = p.UFLX[q + 1], vflx = p.VFLX[q], vflx_jp1 = p.VFLX[q + P];
+        const bool last = (k == nz - 1);
+        const double qv_kp1 = last ? 0.0 : p.QV[q + g.plane], qc_kp1 = last ? 0.0 : p.QC[q + g.plane];
+        double fv_kp1 = 0.0, fc_kp1 = 0.0;
+        if (!last) {
+            const double w_kp1 = p.WWIND[q + g.plane];
+            fv_kp1 = w_kp1 * varvb_log(qv_kp1, qv_k);
+            fc_kp1 = w_kp1 * varvb_log(qc_kp1, qc_k);
+        }
+        double tq[2];
+#pragma unroll
+        for (int s = 0; s < 2; s++) {
+            const double *Q = s == 0 ? p.QV : p.QC;
+            const double x = s == 0 ? qv_k : qc_k;
+            const double x_im1 = Q[q - 1], x_ip1 = Q[q + 1], x_jm1 = Q[q - P], x_jp1 = Q[q + P];
+            const double f_k = s == 0 ? fv_k : fc_k, f_kp1 = s == 0 ? fv_kp1 : fc_kp1;
+            double d = 0.0;
+            d = d + (+uflx * (x_im1 + x) / 2.0 - uflx_ip1 * (x + x_ip1) / 2.0
+                     + vflx * (x_jm1 + x) / 2.0 - vflx_jp1 * (x + x_jp1) / 2.0) / area;
+            if (k == 0) d = d + colp_new * (-f_kp1) / ds;
+            else d = d + colp_new * (+f_k - f_kp1) / ds;
+            if (TURB) {
+                const double tb = turb_flux(p.PHI[q], last ? 0.0 : p.PHI[q + g.plane], phi_km1, p.PHIVB[q], p.PHIVB[q + g.plane],
+                                            x, s == 0 ? qv_kp1 : qc_kp1, s == 0 ? qv_km1 : qc_km1,
+                                            p.KHEAT[q], p.KHEAT[q + g.plane], p.RHO[q], p.RHOVB[q], p.RHOVB[q + g.plane],
+                                            colp, s == 0 ? surf : 0.0, k, nz);
+                d = d + tb;
+                if (s == 0 && !EULER) p.dQVdt_TURB[q] = tb;
+            }
+            if (dif > 0.0)
+                d = d + dif * (c_im1 * x_im1 + c_ip1 * x_ip1 + c_jm1 * x_jm1 + c_jp1 * x_jp1 - 4.0 * colp * x);
+            tq[s] = d;
+        }
+        if (EULER) {
+            qv_out[q] = qv_old[q] * colp_old / colp_new + dt * tq[0] / colp_new;
+            qc_out[q] = qc_old[q] * colp_old / colp_new + dt * tq[1] / colp_new;
+        } else {
+            p.dQVdt[q] = tq[0];
+            p.dQCdt[q] = tq[1];
+        }
+        if (TURB) phi_km1 = p.PHI[q];
+        qv_km1 = qv_k; qc_km1 = qc_k;
+        qv_k = qv_kp1; qc_k = qc_kp1;
+        fv_k = fv_kp1; fc_k = fc_kp1;
+    }
+}
+
+// ------------------------------------------------------------------------------------
 // Euler forward with pressure weighting: dyn_timestep.py:212-297 (the exchange_BC of POTT,
 // VWIND, UWIND, dyn_org_discretizations.py:388-390, follows as one k_halo_multi launch).
 // Threads cover i in [1,nx],
@@ -496,6 +595,10 @@ __global__ __launch_bounds__(TI *TJ) void k_euler_forward(Geo g, Ptrs p, double 
         if (row_c) {
             p.UWIND[at(g, i, j, k)] = p.UWIND_OLD[q] * cao_is / ca_is + dt * p.dUFLXdt[q] / ca_is;
             p.POTT[at(g, i, j, k)] = p.POTT_OLD[q] * co / cn + dt * p.dPOTTdt[q] / cn;
+            if (g.i_moist) {   // no clipping of QV/QC on the reference's CPU path (dyn_timestep.py:291-296)
+                p.QV[q] = p.QV_OLD[q] * co / cn + dt * p.dQVdt[q] / cn;
+                p.QC[q] = p.QC_OLD[q] * co / cn + dt * p.dQCdt[q] / cn;
+            }
         }
         if (v_own) {
             if (!v_pole) p.VWIND[at(g, i, j, k)] = p.VWIND_OLD[q] * cao_js / ca_js + dt * p.dVFLXdt[q] / ca_js;

@@ -93,11 +93,13 @@ class TendencyFactory(_Factory):
                  dQVdt, dQVdt_TURB, QV, dQCdt, QC, UFLX, VFLX,
                  COLP, WWIND, COLP_NEW,
                  PHI, PHIVB, KHEAT, RHO, RHOVB, SLHFLX):
-        """dyn_moist (QV/QC advection) is not part of the dry dycore: QV/QC do not feed
-        COLP/UWIND/VWIND/POTT (SURVEY.md 8f, rank 1 of the next rows).  Kept so that the
-        reference's compute_tendencies sequence (dyn_tendencies.py:62-70) runs unchanged."""
-        return None
-
+        """dQVdt, dQCdt (dyn_moist.py) on handles created with i_moist; a no-op otherwise, so that
+        the reference's compute_tendencies sequence (dyn_tendencies.py:62-70) runs unchanged on
+        the dry dycore (QV/QC do not feed COLP/UWIND/VWIND/POTT)."""
+        core = _core_of(QV, QC, UFLX)
+        if getattr(core, 'i_moist', False):
+            _expect(dQVdt=dQVdt, dQVdt_TURB=dQVdt_TURB, QV=QV, dQCdt=dQCdt, QC=QC)
+            core.moist_tendency()
 
 
 class DiagnosticsFactory(_Factory):

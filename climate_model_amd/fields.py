@@ -73,11 +73,21 @@ FIELD_TABLE = OrderedDict([
     ('dUFLXdt_TURB',  (1, 0, 'nz')),
     ('dVFLXdt_TURB',  (0, 1, 'nz')),
     ('dPOTTdt_TURB',  (0, 0, 'nz')),
+    # moisture (dyn_moist.py)
+    ('QV',            (0, 0, 'nz')),
+    ('QV_OLD',        (0, 0, 'nz')),
+    ('QC',            (0, 0, 'nz')),
+    ('QC_OLD',        (0, 0, 'nz')),
+    ('dQVdt',         (0, 0, 'nz')),
+    ('dQCdt',         (0, 0, 'nz')),
+    ('dQVdt_TURB',    (0, 0, 'nz')),
+    ('SLHFLX',        (0, 0, 1)),
+    ('QV_EST',        (0, 0, 'nz')),
+    ('QC_EST',        (0, 0, 'nz')),
 ])
 
-# fields the reference also passes through the factory signatures but that the
-# dry/turbulence-coupled dycore does not own (moisture = SURVEY.md 8f "next" row)
-PASS_THROUGH_FIELDS = ('QV', 'QV_OLD', 'QC', 'QC_OLD', 'dQVdt', 'dQCdt')
+# fields the reference passes through a factory signature that the dycore does not own
+PASS_THROUGH_FIELDS = ()
 
 
 def field_shape(name, nx, ny, nz, nb=1):
@@ -147,7 +157,7 @@ class ModelFields:
         self.host['POTTVB'][:] = 0.
         self.host['WWIND'][:] = 0.
         # physics-produced inputs: zero in the dry dycore
-        for n in ('KMOM', 'KHEAT', 'SSHFLX', 'SMOMXFLX', 'SMOMYFLX', 'dPOTTdt_RAD'):
+        for n in ('KMOM', 'KHEAT', 'SSHFLX', 'SLHFLX', 'SMOMXFLX', 'SMOMYFLX', 'dPOTTdt_RAD'):
             self.host[n][:] = 0.
         if core is not None:
             self.attach(core)

@@ -126,11 +126,13 @@ class Grid:
         self.POTT_dif_coef = np.zeros((1, 1, nz), dtype=wp)
         self.UVFLX_dif_coef[0, 0, k] = nl.UVFLX_dif_coef * np.exp(-0.0 * (nz - k - 1) / nz)
         self.POTT_dif_coef[0, 0, k] = nl.POTT_dif_coef * np.exp(-1.5 * (nz - k - 1) / nz)
+        self.moist_dif_coef = np.zeros((1, 1, nz), dtype=wp)
+        self.moist_dif_coef[0, 0, k] = nl.moist_dif_coef * np.exp(-1.5 * (nz - k - 1) / nz)
         self._build_GRF()
 
     GRID_FIELD_NAMES = ['corf', 'corf_is', 'A', 'sigma_vb', 'dsigma', 'dxjs', 'dyis',
                         'lat_rad', 'lat_is_rad', 'dlat_rad', 'dlon_rad',
-                        'POTT_dif_coef', 'UVFLX_dif_coef']
+                        'POTT_dif_coef', 'UVFLX_dif_coef', 'moist_dif_coef']
 
     def _build_GRF(self):
         """main_grid.py:299-314.  The device copy lives inside the HIP handle
@@ -139,16 +141,17 @@ class Grid:
         self.GRF = {CPU: grf, HIP: grf}
 
     @classmethod
-    def from_arrays(cls, nx, ny, nz, grf, dt, pair_top=10000., i_turb=0):
+    def from_arrays(cls, nx, ny, nz, grf, dt, pair_top=10000., i_turb=0, i_moist=0):
         """A Grid around externally supplied grid constants (golden fixtures, restarts)."""
         self = cls.__new__(cls)
         self.nl = Namelist(nz=nz, dlat_deg=180. / ny, dlon_deg=360. / nx, pair_top=pair_top,
-                           i_UVFLX_vert_turb=i_turb, i_POTT_vert_turb=i_turb, dt=dt)
+                           i_UVFLX_vert_turb=i_turb, i_POTT_vert_turb=i_turb, i_moist_main_switch=i_moist, dt=dt)
         self.nb = 1
         self.nx, self.ny, self.nz = int(nx), int(ny), int(nz)
         self.nxs, self.nys, self.nzs = self.nx + 1, self.ny + 1, self.nz + 1
         for name in cls.GRID_FIELD_NAMES:
-            setattr(self, name, np.array(grf[name], dtype=np.float64))
+            src = name if name in grf else 'POTT_dif_coef'       # moist_dif_coef defaults to POTT's
+            setattr(self, name, np.array(grf[src], dtype=np.float64))
         self.dt = dt
         self.ts = 0
         self.timer = Timer()

@@ -20,7 +20,8 @@ class DycoreError(RuntimeError):
 class DycoreConfig(C.Structure):
     _fields_ = [('abi_version', C.c_int32), ('nx', C.c_int32), ('ny', C.c_int32), ('nz', C.c_int32),
                 ('ny_global', C.c_int32), ('j_offset', C.c_int32), ('device', C.c_int32),
-                ('i_turb', C.c_int32), ('i_radiation', C.c_int32), ('reserved', C.c_int32 * 7),
+                ('i_turb', C.c_int32), ('i_radiation', C.c_int32), ('i_moist', C.c_int32),
+                ('reserved', C.c_int32 * 6),
                 ('pair_top', C.c_double), ('stream', C.c_void_p)]
 
 
@@ -30,7 +31,8 @@ ABI_SYMBOLS = [
     'dycore_set_grid', 'dycore_field_shape', 'dycore_upload', 'dycore_download', 'dycore_field_ptr',
     'dycore_copy_field', 'dycore_exchange_bc',
     'dycore_continuity', 'dycore_momentum', 'dycore_momentum_prepare', 'dycore_uflx_tendency',
-    'dycore_vflx_tendency', 'dycore_pott_tendency', 'dycore_euler_forward', 'dycore_primary_diag',
+    'dycore_vflx_tendency', 'dycore_pott_tendency', 'dycore_moist_tendency', 'dycore_euler_forward',
+    'dycore_primary_diag',
     'dycore_secondary_diag_rho', 'dycore_step_matsuno', 'dycore_time_steps',
     'dycore_step_begin', 'dycore_substep_part', 'dycore_rows_size', 'dycore_pack_rows',
     'dycore_unpack_rows', 'dycore_substep_field',
@@ -67,7 +69,7 @@ def load_library(path=None):
     for n in ('dycore_continuity', 'dycore_euler_forward'):
         getattr(lib, n).argtypes = [hp, C.c_double]
     for n in ('dycore_momentum', 'dycore_momentum_prepare', 'dycore_uflx_tendency',
-              'dycore_vflx_tendency', 'dycore_pott_tendency', 'dycore_primary_diag',
+              'dycore_vflx_tendency', 'dycore_pott_tendency', 'dycore_moist_tendency', 'dycore_primary_diag',
               'dycore_secondary_diag_rho'):
         getattr(lib, n).argtypes = [hp]
     lib.dycore_step_matsuno.argtypes = [hp, C.c_double, C.c_int32, C.c_int32]
@@ -97,7 +99,7 @@ class HipDycore:
     """One dycore handle = one GPU (or one latitude band of a decomposed grid)."""
 
     def __init__(self, nx, ny, nz, pair_top=10000., i_turb=0, i_radiation=0, device=0,
-                 ny_global=None, j_offset=0, stream=None):
+                 ny_global=None, j_offset=0, stream=None, i_moist=0):
         self.lib = load_library()
         self.nx, self.ny, self.nz = int(nx), int(ny), int(nz)
         cfg = DycoreConfig()
@@ -108,11 +110,13 @@ class HipDycore:
         cfg.device = int(device)
         cfg.i_turb = int(bool(i_turb))
         cfg.i_radiation = int(bool(i_radiation))
+        cfg.i_moist = int(bool(i_moist))
         cfg.pair_top = float(pair_top)
         cfg.stream = C.c_void_p(stream) if stream else None
         self._h = C.c_void_p()
         self._check(self.lib.dycore_create(C.byref(cfg), C.byref(self._h)))
         self.i_turb = bool(i_turb)
+        self.i_moist = bool(i_moist)
 
     # ---- plumbing ----
     def _check(self, rc):
@@ -135,7 +139,8 @@ class HipDycore:
 
     # ---- grid constants / fields ----
     def set_grid(self, GRF):
-        for name in GRID_ARRAYS:
+        names = GRID_ARRAYS + (['moist_dif_coef'] if self.i_moist else [])
+        for name in names:
             a = np.ascontiguousarray(np.asarray(GRF[name], dtype=np.float64))
             shp = a.shape if a.ndim == 3 else (a.size, 1, 1)
             self._check(self.lib.dycore_set_grid(self._h, name.encode(), a.ctypes.data_as(C.POINTER(C.c_double)),
@@ -191,6 +196,9 @@ class HipDycore:
 
     def pott_tendency(self):
         self._check(self.lib.dycore_pott_tendency(self._h))
+
+    def moist_tendency(self):
+        self._check(self.lib.dycore_moist_tendency(self._h))
 
     def euler_forward(self, dt):
         self._check(self.lib.dycore_euler_forward(self._h, float(dt)))

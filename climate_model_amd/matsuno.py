@@ -46,6 +46,9 @@ def step_matsuno(GR, F):
     GR.timer.start('step')
     for old, cur in _OLD_PAIRS:                      # :34-49 (set_equal)
         core.copy_field(old, cur)
+    if getattr(core, 'i_moist', False):
+        core.copy_field('QV_OLD', 'QV')
+        core.copy_field('QC_OLD', 'QC')
     GR.timer.stop('step')
 
     for _substep in ('estimate', 'final'):

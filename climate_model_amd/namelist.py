@@ -40,9 +40,11 @@ class Namelist:
     i_UVFLX_vert_turb: int = 0
     i_POTT_vert_turb: int = 0
     i_POTT_radiation: int = 0
+    i_moist_main_switch: int = 0        # dyn_moist: QV/QC advection (namelist.py:80)
     # diffusion (namelist.py:281-316); None = table value for dlat_deg
     UVFLX_dif_coef: float = None
     POTT_dif_coef: float = 1E-5
+    moist_dif_coef: float = None        # None = POTT_dif_coef (namelist.py:284)
     # time stepping (namelist.py:219-221)
     CFL: float = 0.7
     dt: float = None            # None = reference rule int(CFL*min(dx)/400)
@@ -57,6 +59,8 @@ class Namelist:
             raise NotImplementedError('the HIP dycore computes in float64')
         if bool(self.i_UVFLX_vert_turb) != bool(self.i_POTT_vert_turb):
             raise NotImplementedError('i_UVFLX_vert_turb and i_POTT_vert_turb must agree')
+        if self.moist_dif_coef is None:
+            self.moist_dif_coef = self.POTT_dif_coef
         if self.UVFLX_dif_coef is None:
             self.UVFLX_dif_coef = uvflx_dif_coef_for(self.dlat_deg)
 

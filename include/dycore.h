@@ -58,7 +58,8 @@ typedef struct DycoreConfig {
     int32_t device;        /* HIP device ordinal                                        */
     int32_t i_turb;        /* i_UVFLX_vert_turb & i_POTT_vert_turb (namelist.py:66,77)  */
     int32_t i_radiation;   /* i_POTT_radiation (io_read_namelist.py:66-67)              */
-    int32_t reserved[7];
+    int32_t i_moist;       /* i_moist_main_switch (namelist.py:80): QV/QC advection, dyn_moist */
+    int32_t reserved[6];
     double  pair_top;      /* model-top pressure [Pa] (namelist.py:37)                  */
     void   *stream;        /* hipStream_t to issue work on; NULL = handle creates one   */
 } DycoreConfig;
@@ -73,8 +74,8 @@ int dycore_sync(dycore_t *h);
 
 /* ---- grid constants: main_grid.py:299-314 (GRF dict) ------------------------------ */
 /* name in {A,dxjs,dyis,corf,corf_is,lat_rad,lat_is_rad,dlon_rad,dlat_rad} with host
- * shape (n0,n1,1), or {sigma_vb,dsigma,UVFLX_dif_coef,POTT_dif_coef} with n0*n1*n2
- * = nz+1 / nz elements. */
+ * shape (n0,n1,1), or {sigma_vb,dsigma,UVFLX_dif_coef,POTT_dif_coef,moist_dif_coef} with
+ * n0*n1*n2 = nz+1 / nz elements (moist_dif_coef is required only with i_moist). */
 int dycore_set_grid(dycore_t *h, const char *name, const double *host,
                     int32_t n0, int32_t n1, int32_t n2);
 
@@ -104,6 +105,8 @@ int dycore_uflx_tendency(dycore_t *h);
 int dycore_vflx_tendency(dycore_t *h);
 /* TendencyFactory.temperature (:253-273) */
 int dycore_pott_tendency(dycore_t *h);
+/* TendencyFactory.moisture (:277-294): dQVdt, dQCdt, dQVdt_TURB (handles created with i_moist) */
+int dycore_moist_tendency(dycore_t *h);
 /* PrognosticsFactory.euler_forward (:359-393) incl. exchange of POTT,VWIND,UWIND      */
 int dycore_euler_forward(dycore_t *h, double dt);
 /* DiagnosticsFactory.primary_diag (:310-326): PVTF, PVTFVB, PHI, PHIVB, POTTVB         */

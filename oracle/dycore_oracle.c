@@ -31,6 +31,7 @@
 #define CON_RD 287.058
 #define CON_CP 1005.0
 #define CON_KAPPA (CON_RD / CON_CP)
+#define CON_LH 2264E3   /* io_constants.py:24 */
 
 #define AT(F, i, j, k, stgy, nk) \
     (F)[((size_t)(i) * (size_t)(ny + 2 + (stgy)) + (size_t)(j)) * (size_t)(nk) + (size_t)(k)]
@@ -513,6 +514,105 @@ void oracle_pott_tendency(const oracle_cfg *c, const oracle_grid *g, oracle_fiel
 #undef P
 }
 
+
+/* ------------------------------------------------------------------------- */
+/* dyn_functions.py:70-95: interface value by logarithmic interpolation.  max(VAR, min_val)
+ * is Python's: the first argument unless the second is greater. */
+static inline double varvb_log(double var, double var_km1)
+{
+    const double min_val = 0.0000001;
+    if (min_val > var) var = min_val;
+    if (min_val > var_km1) var_km1 = min_val;
+    if (var_km1 == var) return var;
+    return (log(var_km1) - log(var)) / (1.0 / var - 1.0 / var_km1);
+}
+
+/* dyn_functions.py:26-67 */
+static inline double turb_flux_tendency(double phi, double phi_kp1, double phi_km1, double phivb,
+                                        double phivb_kp1, double var, double var_kp1, double var_km1,
+                                        double kvar, double kvar_kp1, double rho, double rhovb,
+                                        double rhovb_kp1, double colp, double surf_flux, int k, int nz)
+{
+    const double alt = phi / CON_G, alt_kp1 = phi_kp1 / CON_G, alt_km1 = phi_km1 / CON_G;
+    const double altvb = phivb / CON_G, altvb_kp1 = phivb_kp1 / CON_G;
+    if (k == 0)
+        return colp * ((+0.0 - ((var - var_kp1) / (alt - alt_kp1) * rhovb_kp1 * kvar_kp1)) / ((altvb - altvb_kp1) * rho));
+    if (k == nz - 1)
+        return colp * ((+((var_km1 - var) / (alt_km1 - alt) * rhovb * kvar) + surf_flux) / ((altvb - altvb_kp1) * rho));
+    return colp * ((+((var_km1 - var) / (alt_km1 - alt) * rhovb * kvar)
+                    - ((var - var_kp1) / (alt - alt_kp1) * rhovb_kp1 * kvar_kp1)) / ((altvb - altvb_kp1) * rho));
+}
+
+/* dyn_moist.py:201-243 (loop) and :49-129 (terms).  QV[i,j,k+1] at k = nz-1 is an unchecked
+ * out-of-range read in the reference whose interface value is multiplied by WWIND[nz] = 0;
+ * the product is taken as 0 here.  The k-1 neighbour at k = 0 wraps to nz-1 in the reference
+ * and is not used by any term. */
+void oracle_moist_tendency(const oracle_cfg *c, const oracle_grid *g, oracle_fields *f)
+{
+    const int nx = c->nx, ny = c->ny, nz = c->nz, nzs = nz + 1;
+    const int nthr = nthreads_of(c);
+    (void)nthr;
+#define QVA(ii, jj, kk) AT(f->QV, ii, jj, kk, 0, nz)
+#define QCA(ii, jj, kk) AT(f->QC, ii, jj, kk, 0, nz)
+    PAR_FOR
+    for (int i = 1; i < nx + 1; i++)
+        for (int j = 1; j < ny + 1; j++) {
+            const double colp = A2(f->COLP, i, j), colp_new = A2(f->COLP_NEW, i, j);
+            const double c_im1 = A2(f->COLP, i - 1, j), c_ip1 = A2(f->COLP, i + 1, j);
+            const double c_jm1 = A2(f->COLP, i, j - 1), c_jp1 = A2(f->COLP, i, j + 1);
+            const double area = A2(g->A, i, j);
+            for (int k = 0; k < nz; k++) {
+                const double uflx = AT(f->UFLX, i, j, k, 0, nz), uflx_ip1 = AT(f->UFLX, i + 1, j, k, 0, nz);
+                const double vflx = AT(f->VFLX, i, j, k, 1, nz), vflx_jp1 = AT(f->VFLX, i, j + 1, k, 1, nz);
+                const double w = AT(f->WWIND, i, j, k, 0, nzs), w_kp1 = AT(f->WWIND, i, j, k + 1, 0, nzs);
+                const double ds = g->dsigma[k], dif = g->moist_dif_coef[k];
+                double t[2];
+                double turb_qv = 0.0;
+                for (int s = 0; s < 2; s++) {
+                    double *Q = s == 0 ? f->QV : f->QC;
+#define QA(ii, jj, kk) AT(Q, ii, jj, kk, 0, nz)
+                    const double q = QA(i, j, k);
+                    const double q_im1 = QA(i - 1, j, k), q_ip1 = QA(i + 1, j, k), q_jm1 = QA(i, j - 1, k), q_jp1 = QA(i, j + 1, k);
+                    double d = 0.0;
+                    /* hor_adv_py */
+                    d = d + (+uflx * (q_im1 + q) / 2.0 - uflx_ip1 * (q + q_ip1) / 2.0
+                             + vflx * (q_jm1 + q) / 2.0 - vflx_jp1 * (q + q_jp1) / 2.0) / area;
+                    /* vertical advection with log-interpolated interface values */
+                    {
+                        double flux_kp1 = 0.0;                           /* W[nz] * (unchecked read) = 0 */
+                        if (k < nz - 1) flux_kp1 = w_kp1 * varvb_log(QA(i, j, k + 1), q);
+                        if (k == 0)
+                            d = d + colp_new * (-flux_kp1) / ds;
+                        else
+                            d = d + colp_new * (+w * varvb_log(q, QA(i, j, k - 1)) - flux_kp1) / ds;
+                    }
+                    if (c->i_turb) {
+                        const double surf = s == 0 ? A2(f->SLHFLX, i, j) / CON_LH : 0.0;
+                        const double tb = turb_flux_tendency(
+                            AT(f->PHI, i, j, k, 0, nz), k < nz - 1 ? AT(f->PHI, i, j, k + 1, 0, nz) : 0.0,
+                            k > 0 ? AT(f->PHI, i, j, k - 1, 0, nz) : 0.0,
+                            AT(f->PHIVB, i, j, k, 0, nzs), AT(f->PHIVB, i, j, k + 1, 0, nzs),
+                            q, k < nz - 1 ? QA(i, j, k + 1) : 0.0, k > 0 ? QA(i, j, k - 1) : 0.0,
+                            AT(f->KHEAT, i, j, k, 0, nzs), AT(f->KHEAT, i, j, k + 1, 0, nzs),
+                            AT(f->RHO, i, j, k, 0, nz), AT(f->RHOVB, i, j, k, 0, nzs), AT(f->RHOVB, i, j, k + 1, 0, nzs),
+                            colp, surf, k, nz);
+                        d = d + tb;
+                        if (s == 0) turb_qv = tb;
+                    }
+                    if (dif > 0.0)
+                        d = d + dif * (+c_im1 * q_im1 + c_ip1 * q_ip1 + c_jm1 * q_jm1 + c_jp1 * q_jp1 - 4.0 * colp * q);
+                    t[s] = d;
+#undef QA
+                }
+                AT(f->dQVdt, i, j, k, 0, nz) = t[0];
+                AT(f->dQCdt, i, j, k, 0, nz) = t[1];
+                if (c->i_turb) AT(f->dQVdt_TURB, i, j, k, 0, nz) = turb_qv;
+            }
+        }
+#undef QVA
+#undef QCA
+}
+
 /* ------------------------------------------------------------------------- */
 /* dyn_timestep.py:212-297 (serial in the reference: plain njit) */
 void oracle_make_timestep(const oracle_cfg *c, const oracle_grid *g, oracle_fields *f, double dt)
@@ -549,6 +649,11 @@ void oracle_make_timestep(const oracle_cfg *c, const oracle_grid *g, oracle_fiel
                 const double cn = CN(i, j), co = CO(i, j);
                 for (int k = 0; k < nz; k++)
                     AT(f->POTT, i, j, k, 0, nz) = AT(f->POTT_OLD, i, j, k, 0, nz) * co / cn + dt * AT(f->dPOTTdt, i, j, k, 0, nz) / cn;
+                if (c->i_moist)   /* no clipping of QV/QC on the CPU path (dyn_timestep.py:291-296) */
+                    for (int k = 0; k < nz; k++) {
+                        AT(f->QV, i, j, k, 0, nz) = AT(f->QV_OLD, i, j, k, 0, nz) * co / cn + dt * AT(f->dQVdt, i, j, k, 0, nz) / cn;
+                        AT(f->QC, i, j, k, 0, nz) = AT(f->QC_OLD, i, j, k, 0, nz) * co / cn + dt * AT(f->dQCdt, i, j, k, 0, nz) / cn;
+                    }
             }
         }
 #undef CN
@@ -674,6 +779,12 @@ void oracle_stage_temperature(const oracle_cfg *c, const oracle_grid *g, oracle_
     oracle_pott_tendency(c, g, f);
 }
 
+/* dyn_org_discretizations.py:277-294 */
+void oracle_stage_moisture(const oracle_cfg *c, const oracle_grid *g, oracle_fields *f)
+{
+    if (c->i_moist) oracle_moist_tendency(c, g, f);
+}
+
 /* dyn_org_discretizations.py:359-393 */
 void oracle_stage_euler_forward(const oracle_cfg *c, const oracle_grid *g, oracle_fields *f, double dt)
 {
@@ -681,6 +792,10 @@ void oracle_stage_euler_forward(const oracle_cfg *c, const oracle_grid *g, oracl
     oracle_exchange_bc(c, f->POTT, 0, 0, c->nz);
     oracle_exchange_bc(c, f->VWIND, 0, 1, c->nz);
     oracle_exchange_bc(c, f->UWIND, 1, 0, c->nz);
+    if (c->i_moist) {
+        oracle_exchange_bc(c, f->QV, 0, 0, c->nz);
+        oracle_exchange_bc(c, f->QC, 0, 0, c->nz);
+    }
 }
 
 /* dyn_org_discretizations.py:310-326 */
@@ -703,10 +818,15 @@ void oracle_step_matsuno(const oracle_cfg *c, const oracle_grid *g, oracle_field
         memcpy(f->UWIND_OLD, f->UWIND, (size_t)(nx + 3) * (ny + 2) * nz * sizeof(double));
         memcpy(f->VWIND_OLD, f->VWIND, (size_t)(nx + 2) * (ny + 3) * nz * sizeof(double));
         memcpy(f->POTT_OLD, f->POTT, n2 * nz * sizeof(double));
+        if (c->i_moist) {
+            memcpy(f->QV_OLD, f->QV, n2 * nz * sizeof(double));
+            memcpy(f->QC_OLD, f->QC, n2 * nz * sizeof(double));
+        }
         for (int sub = 0; sub < 2; sub++) {
             oracle_stage_continuity(c, g, f, dt);                   /* dyn_tendencies.py:25-70 */
             oracle_stage_momentum(c, g, f);
             oracle_stage_temperature(c, g, f);
+            oracle_stage_moisture(c, g, f);
             memcpy(f->COLP, f->COLP_NEW, n2 * sizeof(double));      /* :64-67 */
             oracle_stage_euler_forward(c, g, f, dt);                /* :75-77 */
             oracle_stage_primary_diag(c, g, f);                     /* :86-88 */

@@ -31,6 +31,7 @@ typedef struct {
     int i_radiation;   /* i_POTT_radiation after io_read_namelist.py:66-67         */
     int nthreads;      /* OpenMP threads, 0 = runtime default                      */
     double pair_top;   /* namelist.py pair_top                                     */
+    int i_moist;       /* i_moist_main_switch (namelist.py:80): QV/QC advection     */
 } oracle_cfg;
 
 /* grid constants: main_grid.py:299-314 (GRF dict) */
@@ -38,6 +39,7 @@ typedef struct {
     const double *A, *dxjs, *dyis, *corf, *corf_is, *lat_rad, *lat_is_rad,
                  *dlon_rad, *dlat_rad;                 /* 2-D (.., .., 1) */
     const double *sigma_vb, *dsigma, *UVFLX_dif_coef, *POTT_dif_coef; /* 1-D */
+    const double *moist_dif_coef;                                     /* 1-D */
 } oracle_grid;
 
 /* model fields touched by the hot path: main_fields.py:234-475 */
@@ -53,6 +55,8 @@ typedef struct {
     double *PVTF, *PVTFVB, *PHI, *PHIVB;
     double *RHO, *RHOVB, *KMOM, *KHEAT;
     double *SSHFLX, *SMOMXFLX, *SMOMYFLX, *dPOTTdt_RAD;
+    /* moisture (dyn_moist.py) */
+    double *QV, *QV_OLD, *QC, *QC_OLD, *dQVdt, *dQCdt, *dQVdt_TURB, *SLHFLX;
 } oracle_fields;
 
 /* misc_boundaries.py:22-42 ; stgx/stgy = 1 if staggered in that direction */
@@ -68,7 +72,9 @@ void oracle_uflx_tendency(const oracle_cfg *c, const oracle_grid *g, oracle_fiel
 void oracle_vflx_tendency(const oracle_cfg *c, const oracle_grid *g, oracle_fields *f);
 /* dyn_POTT.py:180-216 */
 void oracle_pott_tendency(const oracle_cfg *c, const oracle_grid *g, oracle_fields *f);
-/* dyn_timestep.py:212-297 (UWIND, VWIND, POTT only) */
+/* dyn_moist.py:201-243 (loop), :49-129 (terms) */
+void oracle_moist_tendency(const oracle_cfg *c, const oracle_grid *g, oracle_fields *f);
+/* dyn_timestep.py:212-297 (UWIND, VWIND, POTT; QV, QC when i_moist) */
 void oracle_make_timestep(const oracle_cfg *c, const oracle_grid *g, oracle_fields *f, double dt);
 /* dyn_diagnostics.py:139-195 */
 void oracle_diag_pvtf(const oracle_cfg *c, const oracle_grid *g, oracle_fields *f);
@@ -81,6 +87,7 @@ void oracle_diag_rho(const oracle_cfg *c, oracle_fields *f);
 void oracle_stage_continuity(const oracle_cfg *c, const oracle_grid *g, oracle_fields *f, double dt);
 void oracle_stage_momentum(const oracle_cfg *c, const oracle_grid *g, oracle_fields *f);
 void oracle_stage_temperature(const oracle_cfg *c, const oracle_grid *g, oracle_fields *f);
+void oracle_stage_moisture(const oracle_cfg *c, const oracle_grid *g, oracle_fields *f);
 void oracle_stage_euler_forward(const oracle_cfg *c, const oracle_grid *g, oracle_fields *f, double dt);
 void oracle_stage_primary_diag(const oracle_cfg *c, const oracle_grid *g, oracle_fields *f);
 

@@ -15,11 +15,13 @@ this image.  The stand-ins written below (to a temp dir, at run time) are
   * `numba`      : njit/jit = identity decorator, prange = range (the decorated
                    functions are unchanged reference code, executed by CPython);
                    ndarray arguments are viewed through a subclass whose scalar
-                   __getitem__ yields NaN for an out-of-range index (numba does
-                   no bounds check; the reference issues a few such loads whose
-                   values are never used), and a function that returns a
-                   never-assigned local yields 0 (dyn_functions.py:310/377,
-                   levels never consumed).
+                   __getitem__ reproduces numba's unchecked indexing: an
+                   out-of-range index reads the element at that flat offset of the
+                   C-contiguous allocation (NaN beyond it).  The dry path never
+                   uses such a value; dyn_moist multiplies one by WWIND[nz] = 0
+                   (dyn_moist.py:216, QV[i,j,k+1] at k = nz-1).  A function that
+                   returns a never-assigned local yields 0
+                   (dyn_functions.py:310/377, levels never consumed).
   * `netCDF4`    : Dataset reader over scipy.io.netcdf_file (topography input).
   * `scipy.interpolate.interp2d` : bilinear interpolation (removed from SciPy).
   * `bin.rad_longwave_cython`    : empty (radiation is off).
@@ -59,11 +61,23 @@ CASES = {
 NUMBA_SHIM = r'''
 import numpy as _np
 class _OOB(_np.ndarray):
-    """ndarray view: scalar out-of-range read -> NaN (numba has no bounds check)."""
+    """ndarray view with numba's unchecked indexing: an out-of-range scalar read returns
+    whatever lies at that flat offset of the (C-contiguous) allocation -- e.g. QV[i,j,nz] is
+    QV[i,j+1,0] -- and NaN if the offset leaves the allocation (genuinely undefined)."""
     def __getitem__(self, idx):
         try:
             return _np.ndarray.__getitem__(self, idx)
         except IndexError:
+            try:
+                base = self.base if self.base is not None else self
+                flat = 0
+                for n, st in zip(idx, self.strides):
+                    flat += int(n) * (st // self.itemsize)
+                fb = _np.asarray(base).reshape(-1)
+                if 0 <= flat < fb.size and self.flags.c_contiguous:
+                    return fb[flat]
+            except Exception:
+                pass
             return _np.float64('nan')
 def _wrap(f):
     def g(*args):

@@ -7,15 +7,15 @@ from climate_model_amd.fields import FIELD_TABLE
 from oracle_binding import GRID_2D, GRID_1D
 
 
-def grid_from_golden(z, i_turb=0):
+def grid_from_golden(z, i_turb=0, i_moist=0):
     nx, ny, nz = int(z['meta/nx']), int(z['meta/ny']), int(z['meta/nz'])
     grf = {n: z['grid/' + n] for n in GRID_2D + GRID_1D}
     return Grid.from_arrays(nx, ny, nz, grf, dt=float(z['meta/dt']),
-                            pair_top=float(z['meta/pair_top']), i_turb=i_turb)
+                            pair_top=float(z['meta/pair_top']), i_turb=i_turb, i_moist=i_moist)
 
 
-def make_core(GR, i_turb=0):
-    core = HipDycore(GR.nx, GR.ny, GR.nz, pair_top=GR.nl.pair_top, i_turb=i_turb)
+def make_core(GR, i_turb=0, i_moist=0):
+    core = HipDycore(GR.nx, GR.ny, GR.nz, pair_top=GR.nl.pair_top, i_turb=i_turb, i_moist=i_moist)
     core.set_grid(GR.GRF['HIP'])
     return core
 

@@ -21,11 +21,11 @@ _dp = C.POINTER(C.c_double)
 class OracleCfg(C.Structure):
     _fields_ = [('nx', C.c_int), ('ny', C.c_int), ('nz', C.c_int),
                 ('i_turb', C.c_int), ('i_radiation', C.c_int), ('nthreads', C.c_int),
-                ('pair_top', C.c_double)]
+                ('pair_top', C.c_double), ('i_moist', C.c_int)]
 
 
 GRID_2D = ['A', 'dxjs', 'dyis', 'corf', 'corf_is', 'lat_rad', 'lat_is_rad', 'dlon_rad', 'dlat_rad']
-GRID_1D = ['sigma_vb', 'dsigma', 'UVFLX_dif_coef', 'POTT_dif_coef']
+GRID_1D = ['sigma_vb', 'dsigma', 'UVFLX_dif_coef', 'POTT_dif_coef', 'moist_dif_coef']
 
 
 class OracleGrid(C.Structure):
@@ -42,7 +42,8 @@ ORACLE_FIELDS = ['COLP', 'COLP_OLD', 'COLP_NEW', 'dCOLPdt', 'HSURF',
                  'dUFLXdt_TURB', 'dVFLXdt_TURB', 'dPOTTdt_TURB',
                  'PVTF', 'PVTFVB', 'PHI', 'PHIVB',
                  'RHO', 'RHOVB', 'KMOM', 'KHEAT',
-                 'SSHFLX', 'SMOMXFLX', 'SMOMYFLX', 'dPOTTdt_RAD']
+                 'SSHFLX', 'SMOMXFLX', 'SMOMYFLX', 'dPOTTdt_RAD',
+                 'QV', 'QV_OLD', 'QC', 'QC_OLD', 'dQVdt', 'dQCdt', 'dQVdt_TURB', 'SLHFLX']
 
 
 class OracleFields(C.Structure):
@@ -73,7 +74,8 @@ def load_oracle():
             getattr(lib, n).argtypes = [cp, gp, fp, C.c_double]
         for n in ('oracle_uvflx_prepare', 'oracle_uflx_tendency', 'oracle_vflx_tendency',
                   'oracle_pott_tendency', 'oracle_diag_pvtf', 'oracle_stage_momentum',
-                  'oracle_stage_temperature', 'oracle_stage_primary_diag'):
+                  'oracle_stage_temperature', 'oracle_stage_primary_diag', 'oracle_stage_moisture',
+                  'oracle_moist_tendency'):
             getattr(lib, n).argtypes = [cp, gp, fp]
         for n in ('oracle_diag_phi', 'oracle_diag_pottvb', 'oracle_diag_rho'):
             getattr(lib, n).argtypes = [cp, fp]
@@ -86,16 +88,18 @@ class Oracle:
     """The CPU restatement bound to one set of numpy arrays (reference layout)."""
 
     def __init__(self, nx, ny, nz, grid, fields=None, pair_top=10000., i_turb=1,
-                 i_radiation=0, nthreads=0, fill_nan=True):
+                 i_radiation=0, nthreads=0, fill_nan=True, i_moist=0):
         self.lib = load_oracle()
         self.nx, self.ny, self.nz = int(nx), int(ny), int(nz)
         if not nthreads:        # a GPU box shows every core of its host; its share is 16
             nthreads = min(16, len(os.sched_getaffinity(0)))
         self.cfg = OracleCfg(self.nx, self.ny, self.nz, int(i_turb), int(i_radiation),
-                             int(nthreads), float(pair_top))
+                             int(nthreads), float(pair_top), int(i_moist))
         self.G = {}
         self.grid = OracleGrid()
         for n in GRID_2D + GRID_1D:
+            if n == 'moist_dif_coef' and n not in grid:      # dry callers: same vertical profile as POTT
+                grid = dict(grid, moist_dif_coef=grid['POTT_dif_coef'])
             a = np.ascontiguousarray(np.asarray(grid[n], dtype=np.float64))
             self.G[n] = a
             setattr(self.grid, n, a.ctypes.data_as(_dp))
@@ -133,6 +137,9 @@ class Oracle:
     def temperature(self):
         c, g, f = self._c(); self.lib.oracle_stage_temperature(c, g, f)
 
+    def moisture(self):
+        c, g, f = self._c(); self.lib.oracle_stage_moisture(c, g, f)
+
     def euler_forward(self, dt):
         c, g, f = self._c(); self.lib.oracle_stage_euler_forward(c, g, f, float(dt))
 
@@ -147,7 +154,7 @@ class Oracle:
         self.lib.oracle_step_matsuno(c, g, f, float(dt), int(nsteps), int(bool(with_rho)))
 
 
-def oracle_from_golden(z, tag=None, i_turb=1):
+def oracle_from_golden(z, tag=None, i_turb=1, i_moist=0):
     """Build an Oracle from a golden .npz: grid constants + either the initial
     conditions (tag None) or the full captured state `tag` (e.g. 'st00_pre')."""
     nx, ny, nz = int(z['meta/nx']), int(z['meta/ny']), int(z['meta/nz'])
@@ -157,5 +164,5 @@ def oracle_from_golden(z, tag=None, i_turb=1):
     for n in ORACLE_FIELDS:
         if prefix + n in z:
             fields[n] = z[prefix + n]
-    o = Oracle(nx, ny, nz, grid, fields, pair_top=float(z['meta/pair_top']), i_turb=i_turb)
+    o = Oracle(nx, ny, nz, grid, fields, pair_top=float(z['meta/pair_top']), i_turb=i_turb, i_moist=i_moist)
     return o

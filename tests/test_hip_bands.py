@@ -22,8 +22,9 @@ CHECK = ['COLP', 'UWIND', 'VWIND', 'POTT', 'PHI', 'PHIVB', 'PVTF', 'PVTFVB', 'PO
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _initial_state(d, nz, i_turb):
-    GR = Grid(Namelist(nz=nz, dlat_deg=d, dlon_deg=d, i_UVFLX_vert_turb=i_turb, i_POTT_vert_turb=i_turb))
+def _initial_state(d, nz, i_turb, i_moist=0):
+    GR = Grid(Namelist(nz=nz, dlat_deg=d, dlon_deg=d, i_UVFLX_vert_turb=i_turb, i_POTT_vert_turb=i_turb,
+                       i_moist_main_switch=i_moist))
     F = ModelFields(GR)
     initialize_fields(GR, F)
     if i_turb:
@@ -33,31 +34,42 @@ def _initial_state(d, nz, i_turb):
             F.host[n][...] = rng.uniform(lo, hi, F.host[n].shape)
     names = ['HSURF', 'COLP', 'UWIND', 'VWIND', 'POTT', 'WWIND', 'POTTVB', 'KMOM', 'KHEAT',
              'SSHFLX', 'SMOMXFLX', 'SMOMYFLX', 'dPOTTdt_RAD']
+    if i_moist:       # a smooth humidity field with structure in every direction
+        ii, jj = np.meshgrid(np.arange(GR.nx + 2), np.arange(GR.ny + 2), indexing='ij')
+        for k in range(GR.nz):
+            F.host['QV'][:, :, k] = 0.004 * (k + 1) / GR.nz * (1.2 + np.sin(2 * np.pi * ii / GR.nx) * np.cos(np.pi * jj / GR.ny))
+            F.host['QC'][:, :, k] = 1e-5 * (1.1 + np.cos(4 * np.pi * ii / GR.nx)) * (k + 1) / GR.nz
+        from climate_model_amd.grid import exchange_BC_host
+        exchange_BC_host(F.host['QV'], GR.nx, GR.ny)
+        exchange_BC_host(F.host['QC'], GR.nx, GR.ny)
+        F.host['SLHFLX'][...] = 30.
+        names += ['QV', 'QC', 'SLHFLX']
     return GR, {n: F.host[n] for n in names}
 
 
-def _single(GR, state, i_turb, nsteps):
-    core = HipDycore(GR.nx, GR.ny, GR.nz, i_turb=i_turb)
+def _single(GR, state, i_turb, nsteps, i_moist=0, check=None):
+    core = HipDycore(GR.nx, GR.ny, GR.nz, i_turb=i_turb, i_moist=i_moist)
     core.set_grid(GR.GRF['HIP'])
     for n, a in state.items():
         core.upload(n, a)
     core.primary_diag()
     core.step_matsuno(GR.dt, nsteps)
-    out = {n: core.download(n) for n in CHECK}
+    out = {n: core.download(n) for n in (check or CHECK)}
     core.close()
     return out
 
 
 @pytest.mark.parametrize('nbands', [2, 3, 5])
-@pytest.mark.parametrize('i_turb', [0, 1])
-def test_local_bands_bitwise_equal_single(nbands, i_turb):
+@pytest.mark.parametrize('i_turb,i_moist', [(0, 0), (1, 0), (0, 1), (1, 1)])
+def test_local_bands_bitwise_equal_single(nbands, i_turb, i_moist):
     import torch
-    GR, state = _initial_state(4, 8, i_turb)
-    ref = _single(GR, state, i_turb, 3)
+    GR, state = _initial_state(4, 8, i_turb, i_moist)
+    check = CHECK + (['QV', 'QC'] if i_moist else [])
+    ref = _single(GR, state, i_turb, 3, i_moist, check)
     L = BandLayout(GR.ny, nbands)
     cores = []
     for r in range(nbands):
-        c = HipDycore(GR.nx, L.ny(r), GR.nz, i_turb=i_turb, ny_global=GR.ny, j_offset=L.j_offset(r))
+        c = HipDycore(GR.nx, L.ny(r), GR.nz, i_turb=i_turb, ny_global=GR.ny, j_offset=L.j_offset(r), i_moist=i_moist)
         c.set_grid(band_grid_arrays(GR.GRF['HIP'], L, r))
         for n, a in state.items():
             c.upload(n, L.slice_rows(a, r, FIELD_TABLE[n][1]))
@@ -65,7 +77,7 @@ def test_local_bands_bitwise_equal_single(nbands, i_turb):
         cores.append(c)
     lb = LocalBands(cores, L, torch.device('cuda:0'))
     lb.step_matsuno(GR.dt, 3)
-    for n in CHECK:
+    for n in check:
         got = gather_global(L, [c.download(n) for c in cores], n)
         np.testing.assert_array_equal(got, ref[n], err_msg='%s incl. halos (%d bands)' % (n, nbands))
     for c in cores:

@@ -10,6 +10,7 @@ from oracle_binding import oracle_from_golden, ORACLE_FIELDS
 # reference's operation order, so only libm-vs-libm and summation order differ.
 STAGE_TOL = 1e-12
 PROGNOSTIC = ['COLP', 'UWIND', 'VWIND', 'POTT']
+MOIST = ['QV', 'QC']
 
 
 @pytest.mark.parametrize('case', ['g10x4_dry', 'g10x4_turb'])
@@ -17,7 +18,7 @@ def test_stage_by_stage(case):
     z = load_golden(case)
     nx, ny = int(z['meta/nx']), int(z['meta/ny'])
     dt = float(z['meta/dt'])
-    o = oracle_from_golden(z, 'st00_pre', i_turb=1)
+    o = oracle_from_golden(z, 'st00_pre', i_turb=1, i_moist=1)
     tags = stage_tags(z)
     assert tags[0] == 'st00_pre'
     worst = {}
@@ -25,7 +26,7 @@ def test_stage_by_stage(case):
         stage = tag.split('_', 1)[1]
         ref_out = fields_of(z, tag)
         if n == 1:   # dyn_matsuno.py:34-41
-            for a in ('COLP', 'UWIND', 'VWIND', 'POTT'):
+            for a in ('COLP', 'UWIND', 'VWIND', 'POTT', 'QV', 'QC'):
                 o.F[a + '_OLD'][...] = o.F[a]
         if stage == 'continuity':
             o.continuity(dt)
@@ -34,7 +35,7 @@ def test_stage_by_stage(case):
         elif stage == 'temperature':
             o.temperature()
         elif stage == 'moisture':
-            pass                                # SURVEY.md 8f "next" row
+            o.moisture()                        # dyn_moist: SURVEY.md 8f, rank 1
         elif stage == 'euler_forward':
             o.F['COLP'][...] = o.F['COLP_NEW']   # dyn_matsuno.py:64-67
             o.euler_forward(dt)
@@ -61,16 +62,23 @@ def test_whole_steps(case, steps, tol):
     z = load_golden(case)
     nx, ny = int(z['meta/nx']), int(z['meta/ny'])
     dt = float(z['meta/dt'])
-    o = oracle_from_golden(z, None, i_turb=1)
+    o = oracle_from_golden(z, None, i_turb=1, i_moist=1)
     o.primary_diag()                 # solver.py:70-73
     done = 0
     for s in steps:
         o.step_matsuno(dt, s - done, with_rho=True)
         done = s
-        for name in PROGNOSTIC:
-            err, ncmp, bad = rel_max_err(o.F[name], z['step%03d/%s' % (s, name)], name, nx, ny)
+        for name in PROGNOSTIC + MOIST:
+            ref = z['step%03d/%s' % (s, name)]
+            err, ncmp, bad = rel_max_err(o.F[name], ref, name, nx, ny)
             assert bad == 0 and ncmp > 0
-            assert err <= tol, '%s step %d %s: rel err %.3e' % (case, s, name, err)
+            if name == 'QC' and np.nanmax(np.abs(ref)) < 1e-300:
+                assert np.nanmax(np.abs(o.F[name][1:-1, 1:-1])) < 1e-300
+                continue
+            # QC stays at the 1e-10 level (it only exists through the 1e-7 clamp of the log
+            # interpolation) and amplifies last-bit differences of log(): looser bound
+            lim = 1e-9 if name == 'QC' else tol
+            assert err <= lim, '%s step %d %s: rel err %.3e' % (case, s, name, err)
 
 
 def test_dry_switch_equals_zero_K():

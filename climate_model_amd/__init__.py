@@ -6,7 +6,8 @@ from .fields import ModelFields, FIELD_TABLE, CPU, HIP
 from .hip_backend import HipDycore, DycoreError
 from .discretizations import TendencyFactory, DiagnosticsFactory, PrognosticsFactory
 from .matsuno import step_matsuno, step_matsuno_fused, compute_tendencies
+from .turbulence import Turbulence
 
 __all__ = ['Namelist', 'Grid', 'ModelFields', 'FIELD_TABLE', 'CPU', 'HIP', 'HipDycore',
            'DycoreError', 'TendencyFactory', 'DiagnosticsFactory', 'PrognosticsFactory',
-           'step_matsuno', 'step_matsuno_fused', 'compute_tendencies']
+           'step_matsuno', 'step_matsuno_fused', 'compute_tendencies', 'Turbulence']

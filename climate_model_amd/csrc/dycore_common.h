@@ -52,6 +52,8 @@ struct Ptrs {
     double *SSHFLX, *SMOMXFLX, *SMOMYFLX, *dPOTTdt_RAD;
     // moisture (dyn_moist.py)
     double *QV, *QV_OLD, *QC, *QC_OLD, *dQVdt, *dQCdt, *dQVdt_TURB, *SLHFLX, *QV_EST, *QC_EST;
+    // full secondary diagnostics (dyn_diagnostics.py:199-222)
+    double *TAIR, *TAIRVB, *PAIR, *PAIRVB, *WINDX, *WINDY, *WIND;
     // grid constants, 2-D
     const double *A, *dxjs, *dyis, *corf, *corf_is, *lat_rad, *lat_is_rad, *dlon_rad, *dlat_rad;
     // grid constants, vertical 1-D

@@ -70,6 +70,8 @@ const FieldDesc kFields[] = {
     F_(SSHFLX, 0, 0, 1), F_(SMOMXFLX, 0, 0, 1), F_(SMOMYFLX, 0, 0, 1), F_(dPOTTdt_RAD, 0, 0, 0),
     F_(QV, 0, 0, 0), F_(QV_OLD, 0, 0, 0), F_(QC, 0, 0, 0), F_(QC_OLD, 0, 0, 0), F_(dQVdt, 0, 0, 0), F_(dQCdt, 0, 0, 0),
     F_(dQVdt_TURB, 0, 0, 0), F_(SLHFLX, 0, 0, 1), F_(QV_EST, 0, 0, 0), F_(QC_EST, 0, 0, 0),
+    F_(TAIR, 0, 0, 0), F_(TAIRVB, 0, 0, -1), F_(PAIR, 0, 0, 0), F_(PAIRVB, 0, 0, -1),
+    F_(WINDX, 0, 0, 0), F_(WINDY, 0, 0, 0), F_(WIND, 0, 0, 0),
 };
 #undef F_
 constexpr int kNFields = sizeof(kFields) / sizeof(kFields[0]);
@@ -92,12 +94,12 @@ constexpr int kNGrid = sizeof(kGrid) / sizeof(kGrid[0]);
 
 // kernels tracked by the profiler
 enum KernelId {
-    K_CONTINUITY = 0, K_PREPARE, K_UFLX, K_VFLX, K_POTT, K_EULER, K_DIAG, K_RHO, K_EXCHANGE, K_COPY, K_HALO, K_MOM_FUSED, K_POTT_FUSED, K_DIAG_ROWS, K_HALO_MULTI, K_CONT_REG, K_DERIVE, K_MOIST,
+    K_CONTINUITY = 0, K_PREPARE, K_UFLX, K_VFLX, K_POTT, K_EULER, K_DIAG, K_RHO, K_EXCHANGE, K_COPY, K_HALO, K_MOM_FUSED, K_POTT_FUSED, K_DIAG_ROWS, K_HALO_MULTI, K_CONT_REG, K_DERIVE, K_MOIST, K_SECONDARY, K_TURB,
     K_COUNT
 };
 const char *kKernelNames[K_COUNT] = {
     "k_continuity", "k_prepare", "k_uflx_tendency", "k_vflx_tendency", "k_pott_tendency",
-    "k_euler_forward", "k_primary_diag", "k_diag_rho", "k_exchange_bc", "copy_field", "k_rows", "k_momentum_fused", "k_pott_fused", "k_primary_diag_rows", "k_halo_multi", "k_continuity_reg", "k_derive", "k_moist",
+    "k_euler_forward", "k_primary_diag", "k_diag_rho", "k_exchange_bc", "copy_field", "k_rows", "k_momentum_fused", "k_pott_fused", "k_primary_diag_rows", "k_halo_multi", "k_continuity_reg", "k_derive", "k_moist", "k_diag_secondary", "k_turbulence",
 };
 
 struct ProfRec { int kid; hipEvent_t a, b; };
@@ -306,6 +308,18 @@ int do_rho(dycore *h, const Ptrs &p)
     Scope s(h, K_RHO);
     hipLaunchKernelGGL(k_diag_rho, grid_for(h->g, h->g.nx + 2, h->g.ny + 2), dim3(TI, TJ), 0, h->stream, h->g, p);
     return launch_check("k_diag_rho");
+}
+int do_secondary(dycore *h, const Ptrs &p)
+{
+    Scope s(h, K_SECONDARY);
+    hipLaunchKernelGGL(k_diag_secondary, grid_for(h->g, h->g.nx + 2, h->g.ny + 2), dim3(TI, TJ), 0, h->stream, h->g, p);
+    return launch_check("k_diag_secondary");
+}
+int do_turbulence(dycore *h, const Ptrs &p)
+{
+    Scope s(h, K_TURB);
+    hipLaunchKernelGGL(k_turbulence, grid_for(h->g, h->g.nx + 2, h->g.ny + 2), dim3(TI, TJ), 0, h->stream, h->g, p);
+    return launch_check("k_turbulence");
 }
 int do_exchange(dycore *h, double *F, int stgx, int stgy, int nk)
 {
@@ -854,6 +868,8 @@ int dycore_moist_tendency(dycore_t *h)
 int dycore_euler_forward(dycore_t *h, double dt) { int rc = ready_join(h); return rc ? rc : do_euler(h, h->p, dt); }
 int dycore_primary_diag(dycore_t *h) { int rc = ready_join(h); return rc ? rc : do_diag(h, h->p); }
 int dycore_secondary_diag_rho(dycore_t *h) { int rc = ready_join(h); return rc ? rc : do_rho(h, h->p); }
+int dycore_secondary_diag(dycore_t *h) { int rc = ready_join(h); return rc ? rc : do_secondary(h, h->p); }
+int dycore_compute_turbulence(dycore_t *h) { int rc = ready_join(h); return rc ? rc : do_turbulence(h, h->p); }
 
 int dycore_step_matsuno(dycore_t *h, double dt, int32_t nsteps, int32_t with_rho)
 {

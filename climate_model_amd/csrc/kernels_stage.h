@@ -683,6 +683,67 @@ __global__ __launch_bounds__(TI *TJ) void k_diag_rho(Geo g, Ptrs p)
     }
 }
 
+// secondary diagnostics, every output: dyn_diagnostics.py:199-222 (whole array incl. halos)
+__global__ __launch_bounds__(TI *TJ) void k_diag_secondary(Geo g, Ptrs p)
+{
+    DYC_IJ(0, 0)
+    if (i > g.nx + 1 || j > g.ny + 1) return;
+    const size_t c = at2(g, i, j);
+    for (int k = 0; k <= g.nz; k++) {
+        const size_t q = c + (size_t)k * g.plane;
+        const double pvb = p.PVTFVB[q];
+        const double pairvb = 100000.0 * pow(pvb, 1.0 / CON_KAPPA), tairvb = p.POTTVB[q] * pvb;
+        p.PAIRVB[q] = pairvb;
+        p.TAIRVB[q] = tairvb;
+        p.RHOVB[q] = pairvb / (CON_RD * tairvb);
+        if (k < g.nz) {
+            const double pv = p.PVTF[q];
+            const double tair = p.POTT[q] * pv, pair = 100000.0 * pow(pv, 1.0 / CON_KAPPA);
+            p.TAIR[q] = tair;
+            p.PAIR[q] = pair;
+            p.RHO[q] = pair / (CON_RD * tair);
+            const double wx = (p.UWIND[q] + p.UWIND[q + 1]) / 2.0, wy = (p.VWIND[q] + p.VWIND[q + g.P]) / 2.0;
+            p.WINDX[q] = wx;
+            p.WINDY[q] = wy;
+            p.WIND[q] = sqrt(wx * wx + wy * wy);
+        }
+    }
+}
+
+// turbulence scheme: turb_compute.py:191-208 (loop), :54-142 (formulae), :28-48 (constants).
+// KMOM, KHEAT at interfaces 1..nz-1 of the whole array incl. halos.
+__global__ __launch_bounds__(TI *TJ) void k_turbulence(Geo g, Ptrs p)
+{
+    DYC_IJ(0, 0)
+    if (i > g.nx + 1 || j > g.ny + 1) return;
+    const double Ri_c = 1.0, free_mix_len = 200.0, con_k = 0.35, con_Pr = 0.72;
+    const double min_wind_diff = 0.0001, min_KMOM = 0.000001, max_KMOM = 0.01;
+    const size_t c = at2(g, i, j);
+    const double hsurf = p.HSURF[c];
+    double wx_km = p.WINDX[c], wy_km = p.WINDY[c], phi_km = p.PHI[c], qv_km = p.QV[c], pott_km = p.POTT[c];
+    for (int k = 1; k < g.nz; k++) {
+        const size_t q = c + (size_t)k * g.plane;
+        const double wx_kp = p.WINDX[q], wy_kp = p.WINDY[q], phi_kp = p.PHI[q], qv_kp = p.QV[q], pott_kp = p.POTT[q];
+        double ax = wx_km, ay = wy_km;
+        if (ax == wx_kp) ax += min_wind_diff;
+        if (ay == wy_kp) ay += min_wind_diff;
+        const double alt_k = p.PHIVB[q] / CON_G, alt_km = phi_km / CON_G, alt_kp = phi_kp / CON_G;
+        const double hgt = alt_k - hsurf;
+        const double mix_len = con_k * hgt / (1.0 + con_k * hgt / free_mix_len);
+        const double qv_k = varvb_log(qv_kp, qv_km);
+        const double pott_v = p.POTTVB[q] * (1.0 + qv_k / 0.622) / (1.0 + qv_k);
+        const double dwx = ax - wx_kp, dwy = ay - wy_kp, dz = alt_km - alt_kp;
+        const double ri_b = (CON_G / pott_v * (pott_km - pott_kp) * dz) / (dwx * dwx + dwy * dwy);
+        const double shear = sqrt((dwx / dz) * (dwx / dz) + (dwy / dz) * (dwy / dz));
+        double kmom = mix_len * mix_len * shear * (Ri_c - ri_b) / Ri_c;
+        if (kmom < min_KMOM) kmom = min_KMOM;
+        if (kmom > max_KMOM) kmom = max_KMOM;
+        p.KMOM[q] = kmom;
+        p.KHEAT[q] = kmom / con_Pr;
+        wx_km = wx_kp; wy_km = wy_kp; phi_km = phi_kp; qv_km = qv_kp; pott_km = pott_kp;
+    }
+}
+
 // ------------------------------------------------------------------------------------
 // lateral boundary conditions of one field: misc_boundaries.py:47-82.  Every halo cell
 // pulls from the interior cell it mirrors, so one pass suffices (corners included).

@@ -117,12 +117,16 @@ class DiagnosticsFactory(_Factory):
         _core_of(COLP, PVTF, POTT).primary_diag()
 
     def secondary_diag(self,
-                       POTTVB, PVTFVB,
-                       POTT, RHO, RHOVB, PVTF):
-        """The part of the reference's secondary_diag (:329-347) the dycore consumes: RHO
-        and RHOVB.  TAIR, PAIR, WIND* feed only physics/output (out of scope)."""
-        _expect(POTTVB=POTTVB, PVTFVB=PVTFVB, POTT=POTT, RHO=RHO, RHOVB=RHOVB, PVTF=PVTF)
-        _core_of(RHO, RHOVB).secondary_diag_rho()
+                       POTTVB, TAIRVB, PVTFVB,
+                       COLP, PAIR, PAIRVB, PHI, POTT,
+                       TAIR, RHO, RHOVB, PVTF,
+                       UWIND, VWIND, WINDX, WINDY, WIND):
+        """dyn_org_discretizations.py:329-347, every output of diag_secondary
+        (dyn_diagnostics.py:199-222)."""
+        _expect(POTTVB=POTTVB, TAIRVB=TAIRVB, PVTFVB=PVTFVB, PAIR=PAIR, PAIRVB=PAIRVB, POTT=POTT,
+                TAIR=TAIR, RHO=RHO, RHOVB=RHOVB, PVTF=PVTF, UWIND=UWIND, VWIND=VWIND,
+                WINDX=WINDX, WINDY=WINDY, WIND=WIND)
+        _core_of(RHO, RHOVB, WIND).secondary_diag()
 
 
 class PrognosticsFactory(_Factory):

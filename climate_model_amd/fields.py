@@ -84,6 +84,14 @@ FIELD_TABLE = OrderedDict([
     ('SLHFLX',        (0, 0, 1)),
     ('QV_EST',        (0, 0, 'nz')),
     ('QC_EST',        (0, 0, 'nz')),
+    # full secondary diagnostics (dyn_diagnostics.py:199-222)
+    ('TAIR',          (0, 0, 'nz')),
+    ('TAIRVB',        (0, 0, 'nzs')),
+    ('PAIR',          (0, 0, 'nz')),
+    ('PAIRVB',        (0, 0, 'nzs')),
+    ('WINDX',         (0, 0, 'nz')),
+    ('WINDY',         (0, 0, 'nz')),
+    ('WIND',          (0, 0, 'nz')),
 ])
 
 # fields the reference passes through a factory signature that the dycore does not own

@@ -33,7 +33,8 @@ ABI_SYMBOLS = [
     'dycore_continuity', 'dycore_momentum', 'dycore_momentum_prepare', 'dycore_uflx_tendency',
     'dycore_vflx_tendency', 'dycore_pott_tendency', 'dycore_moist_tendency', 'dycore_euler_forward',
     'dycore_primary_diag',
-    'dycore_secondary_diag_rho', 'dycore_step_matsuno', 'dycore_time_steps',
+    'dycore_secondary_diag_rho', 'dycore_secondary_diag', 'dycore_compute_turbulence',
+    'dycore_step_matsuno', 'dycore_time_steps',
     'dycore_step_begin', 'dycore_substep_part', 'dycore_rows_size', 'dycore_pack_rows',
     'dycore_unpack_rows', 'dycore_substep_field',
     'dycore_profile', 'dycore_n_kernels', 'dycore_kernel_stats',
@@ -70,7 +71,7 @@ def load_library(path=None):
         getattr(lib, n).argtypes = [hp, C.c_double]
     for n in ('dycore_momentum', 'dycore_momentum_prepare', 'dycore_uflx_tendency',
               'dycore_vflx_tendency', 'dycore_pott_tendency', 'dycore_moist_tendency', 'dycore_primary_diag',
-              'dycore_secondary_diag_rho'):
+              'dycore_secondary_diag_rho', 'dycore_secondary_diag', 'dycore_compute_turbulence'):
         getattr(lib, n).argtypes = [hp]
     lib.dycore_step_matsuno.argtypes = [hp, C.c_double, C.c_int32, C.c_int32]
     lib.dycore_time_steps.argtypes = [hp, C.c_double, C.c_int32, C.c_int32, C.POINTER(C.c_double)]
@@ -208,6 +209,12 @@ class HipDycore:
 
     def secondary_diag_rho(self):
         self._check(self.lib.dycore_secondary_diag_rho(self._h))
+
+    def secondary_diag(self):
+        self._check(self.lib.dycore_secondary_diag(self._h))
+
+    def compute_turbulence(self):
+        self._check(self.lib.dycore_compute_turbulence(self._h))
 
     def step_matsuno(self, dt, nsteps=1, with_rho=None):
         with_rho = self.i_turb if with_rho is None else with_rho

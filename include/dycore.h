@@ -113,6 +113,12 @@ int dycore_euler_forward(dycore_t *h, double dt);
 int dycore_primary_diag(dycore_t *h);
 /* DiagnosticsFactory.secondary_diag (:329-347), the part the dycore consumes: RHO, RHOVB */
 int dycore_secondary_diag_rho(dycore_t *h);
+/* DiagnosticsFactory.secondary_diag (:329-347), every output: TAIR, TAIRVB, PAIR, PAIRVB, RHO,
+ * RHOVB, WINDX, WINDY, WIND (dyn_diagnostics.py:199-222) */
+int dycore_secondary_diag(dycore_t *h);
+/* Turbulence.compute_turbulence (turb_main.py:36-48, turb_compute.py:191-208): KMOM, KHEAT from
+ * PHIVB, HSURF, PHI, QV, WINDX, WINDY, POTTVB, POTT */
+int dycore_compute_turbulence(dycore_t *h);
 
 /* ---- the whole hot loop body: dyn_matsuno.py:28-131, nsteps times ------------------- */
 /* with_rho != 0 re-diagnoses RHO/RHOVB before each step (solver.py:99-101); needed only

@@ -745,6 +745,73 @@ void oracle_diag_rho(const oracle_cfg *c, oracle_fields *f)
         }
 }
 
+/* dyn_diagnostics.py:199-222, all outputs.  x ** 2 and x ** (1/2) are written as products
+ * and sqrt. */
+void oracle_diag_secondary(const oracle_cfg *c, oracle_fields *f)
+{
+    const int nx = c->nx, ny = c->ny, nz = c->nz, nzs = nz + 1;
+    const int nthr = nthreads_of(c);
+    (void)nthr;
+    PAR_FOR
+    for (int i = 0; i < nx + 2; i++)
+        for (int j = 0; j < ny + 2; j++) {
+            for (int k = 0; k < nzs; k++) {
+                const double pairvb = 100000.0 * pow(AT(f->PVTFVB, i, j, k, 0, nzs), 1.0 / CON_KAPPA);
+                const double tairvb = AT(f->POTTVB, i, j, k, 0, nzs) * AT(f->PVTFVB, i, j, k, 0, nzs);
+                AT(f->PAIRVB, i, j, k, 0, nzs) = pairvb;
+                AT(f->TAIRVB, i, j, k, 0, nzs) = tairvb;
+                AT(f->RHOVB, i, j, k, 0, nzs) = pairvb / (CON_RD * tairvb);
+            }
+            for (int k = 0; k < nz; k++) {
+                const double tair = AT(f->POTT, i, j, k, 0, nz) * AT(f->PVTF, i, j, k, 0, nz);
+                const double pair = 100000.0 * pow(AT(f->PVTF, i, j, k, 0, nz), 1.0 / CON_KAPPA);
+                AT(f->TAIR, i, j, k, 0, nz) = tair;
+                AT(f->PAIR, i, j, k, 0, nz) = pair;
+                AT(f->RHO, i, j, k, 0, nz) = pair / (CON_RD * tair);
+                const double wx = (AT(f->UWIND, i, j, k, 0, nz) + AT(f->UWIND, i + 1, j, k, 0, nz)) / 2.0;
+                const double wy = (AT(f->VWIND, i, j, k, 1, nz) + AT(f->VWIND, i, j + 1, k, 1, nz)) / 2.0;
+                AT(f->WINDX, i, j, k, 0, nz) = wx;
+                AT(f->WINDY, i, j, k, 0, nz) = wy;
+                AT(f->WIND, i, j, k, 0, nz) = sqrt(wx * wx + wy * wy);
+            }
+        }
+}
+
+/* turb_compute.py:28-48 (constants), :54-142 (formulae), :191-208 (loop) */
+void oracle_compute_turbulence(const oracle_cfg *c, oracle_fields *f)
+{
+    const int nx = c->nx, ny = c->ny, nz = c->nz, nzs = nz + 1;
+    const int nthr = nthreads_of(c);
+    (void)nthr;
+    const double Ri_c = 1.0, free_mix_len = 200.0, con_k = 0.35, con_Pr = 0.72;
+    const double min_wind_diff = 0.0001, min_KMOM = 0.000001, max_KMOM = 0.01;
+    PAR_FOR
+    for (int i = 0; i < nx + 2; i++)
+        for (int j = 0; j < ny + 2; j++)
+            for (int k = 1; k < nzs - 1; k++) {
+                double wx_km = AT(f->WINDX, i, j, k - 1, 0, nz), wx_kp = AT(f->WINDX, i, j, k, 0, nz);
+                double wy_km = AT(f->WINDY, i, j, k - 1, 0, nz), wy_kp = AT(f->WINDY, i, j, k, 0, nz);
+                if (wx_km == wx_kp) wx_km += min_wind_diff;
+                if (wy_km == wy_kp) wy_km += min_wind_diff;
+                const double alt_k = AT(f->PHIVB, i, j, k, 0, nzs) / CON_G;
+                const double alt_km = AT(f->PHI, i, j, k - 1, 0, nz) / CON_G, alt_kp = AT(f->PHI, i, j, k, 0, nz) / CON_G;
+                const double hgt = alt_k - A2(f->HSURF, i, j);
+                const double mix_len = con_k * hgt / (1.0 + con_k * hgt / free_mix_len);
+                const double qv_k = varvb_log(AT(f->QV, i, j, k, 0, nz), AT(f->QV, i, j, k - 1, 0, nz));
+                const double pott_k = AT(f->POTTVB, i, j, k, 0, nzs);
+                const double pott_v = pott_k * (1.0 + qv_k / 0.622) / (1.0 + qv_k);   /* misc_meteo_utilities.py:38-52 */
+                const double dwx = wx_km - wx_kp, dwy = wy_km - wy_kp, dz = alt_km - alt_kp;
+                const double ri_b = (CON_G / pott_v * (AT(f->POTT, i, j, k - 1, 0, nz) - AT(f->POTT, i, j, k, 0, nz)) * dz) /
+                                    (dwx * dwx + dwy * dwy);
+                const double shear = sqrt((dwx / dz) * (dwx / dz) + (dwy / dz) * (dwy / dz));
+                double kmom = mix_len * mix_len * shear * (Ri_c - ri_b) / Ri_c;
+                if (kmom < min_KMOM) kmom = min_KMOM;
+                if (kmom > max_KMOM) kmom = max_KMOM;
+                AT(f->KMOM, i, j, k, 0, nzs) = kmom;
+                AT(f->KHEAT, i, j, k, 0, nzs) = kmom / con_Pr;
+            }
+}
+
 /* ------------------------------------------------------------------------- */
 /* dyn_org_discretizations.py:89-117 */
 void oracle_stage_continuity(const oracle_cfg *c, const oracle_grid *g, oracle_fields *f, double dt)

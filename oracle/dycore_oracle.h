@@ -57,6 +57,8 @@ typedef struct {
     double *SSHFLX, *SMOMXFLX, *SMOMYFLX, *dPOTTdt_RAD;
     /* moisture (dyn_moist.py) */
     double *QV, *QV_OLD, *QC, *QC_OLD, *dQVdt, *dQCdt, *dQVdt_TURB, *SLHFLX;
+    /* full secondary diagnostics (dyn_diagnostics.py:199-222) */
+    double *TAIR, *TAIRVB, *PAIR, *PAIRVB, *WINDX, *WINDY, *WIND;
 } oracle_fields;
 
 /* misc_boundaries.py:22-42 ; stgx/stgy = 1 if staggered in that direction */
@@ -82,6 +84,11 @@ void oracle_diag_phi(const oracle_cfg *c, oracle_fields *f);
 void oracle_diag_pottvb(const oracle_cfg *c, oracle_fields *f);
 /* dyn_diagnostics.py:199-222, RHO and RHOVB only (the two the dycore consumes) */
 void oracle_diag_rho(const oracle_cfg *c, oracle_fields *f);
+
+/* dyn_diagnostics.py:199-222, every output */
+void oracle_diag_secondary(const oracle_cfg *c, oracle_fields *f);
+/* turb_compute.py:191-208 (loop), :54-142 (formulae): KMOM, KHEAT at interfaces 1..nz-1 */
+void oracle_compute_turbulence(const oracle_cfg *c, oracle_fields *f);
 
 /* factory-level stages: dyn_org_discretizations.py:89-117, 121-249, 253-273, 359-393, 310-326 */
 void oracle_stage_continuity(const oracle_cfg *c, const oracle_grid *g, oracle_fields *f, double dt);

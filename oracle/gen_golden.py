@@ -56,6 +56,9 @@ CASES = {
     'g10x4_dry':  dict(d=10, nz=4, steps=10, snaps=(1, 2, 10), stages=True,  turb=False),
     'g10x4_turb': dict(d=10, nz=4, steps=1,  snaps=(1,),       stages=True,  turb=True),
     'g4x8_dry':   dict(d=4,  nz=8, steps=10, snaps=(1, 10),    stages=False, turb=False),
+    # turbulence scheme of the reference switched on (turb_main.Turbulence): KMOM/KHEAT are
+    # produced by compute_turbulence from the full secondary diagnostics every step
+    'g10x4_phys': dict(d=10, nz=4, steps=5,  snaps=(1, 5),     stages=True,  turb=False, turbulence=True),
 }
 
 NUMBA_SHIM = r'''
@@ -133,7 +136,7 @@ i_save_to_restart = 0
 i_load_from_IC = 0
 i_radiation = 0
 i_microphysics = 0
-i_turbulence = 0
+i_turbulence = %(turbulence)d
 i_surface_scheme = 0
 working_precision = %(wp)r
 nz = %(nz)d
@@ -157,7 +160,7 @@ UVFLX_dif_coef *= 2.0
 '''
 
 
-def _install_shims(tmp, d, nz, wp):
+def _install_shims(tmp, d, nz, wp, turbulence=0):
     os.makedirs(os.path.join(tmp, 'numba'))
     with open(os.path.join(tmp, 'numba', '__init__.py'), 'w') as f:
         f.write(NUMBA_SHIM)
@@ -170,7 +173,7 @@ def _install_shims(tmp, d, nz, wp):
                    'rad_calc_LW_RTE_matrix_c'):
             f.write('def %s(*a, **k):\n    raise NotImplementedError\n' % fn)
     with open(os.path.join(tmp, 'namelist.py'), 'w') as f:
-        f.write(NAMELIST_SHIM % dict(ref=REF, d=d, nz=nz, wp=wp))
+        f.write(NAMELIST_SHIM % dict(ref=REF, d=d, nz=nz, wp=wp, turbulence=int(turbulence)))
 
     # scipy.interpolate.interp2d (removed in SciPy >= 1.14): bilinear, nearest outside.
     import scipy.interpolate as si
@@ -206,7 +209,7 @@ def run_case(name):
     cfg = CASES[name]
     sys.dont_write_bytecode = True
     tmp = tempfile.mkdtemp(prefix='golden_shims_')
-    _install_shims(tmp, cfg['d'], cfg['nz'], 'float64')
+    _install_shims(tmp, cfg['d'], cfg['nz'], 'float64', cfg.get('turbulence', False))
     sys.path.insert(0, REF)
     sys.path.insert(0, tmp)
     os.chdir(REF)            # the reference opens data/... relative to cwd
@@ -226,17 +229,24 @@ def run_case(name):
     P = dyn_matsuno.Prognostics
     D = dyn_matsuno.Diagnostics
 
+    turbulence = cfg.get('turbulence', False)
     hot = []
-    for lst in (T.fields_continuity, T.fields_momentum, T.fields_temperature,
+    extra = [F.TURB.fields_main] if turbulence else []
+    for lst in [T.fields_continuity, T.fields_momentum, T.fields_temperature,
                 T.fields_moisture, D.fields_primary_diag, D.fields_secondary_diag,
-                P.fields_prognostic):
+                P.fields_prognostic] + extra:
         for n in lst:
             if n not in hot:
                 hot.append(n)
 
     rng = np.random.default_rng(11)
-    # physics-produced inputs: 0 in the dry definition, random in the turb variant
+    turbulence = cfg.get('turbulence', False)
+    # physics-produced inputs: 0 in the dry definition, random in the turb variant; with the
+    # turbulence scheme on, KMOM/KHEAT stay as allocated (NaN) until compute_turbulence fills
+    # levels 1..nz-1 (the end levels are never consumed)
     for n in ['KMOM', 'KHEAT', 'SSHFLX', 'SLHFLX', 'SMOMXFLX', 'SMOMYFLX', 'dPOTTdt_RAD']:
+        if turbulence and n in ('KMOM', 'KHEAT'):
+            continue
         F.host[n][:] = 0.
     if cfg['turb']:
         F.host['KMOM'][:] = rng.uniform(0.5, 20., F.host['KMOM'].shape)
@@ -295,9 +305,19 @@ def run_case(name):
         hook(P, 'euler_forward', 'euler_forward')
         hook(D, 'primary_diag', 'primary_diag')
 
+    if turbulence:
+        hook(Diagnostics, 'secondary_diag', 'secondary_diag')
+        hook(F.TURB, 'compute_turbulence', 'turbulence')
     for ts in range(1, cfg['steps'] + 1):
-        Diagnostics.secondary_diag(**F.get(Diagnostics.fields_secondary_diag, target=CPU))
-        if ts == 1 and cfg['stages']:
+        if turbulence:      # solver.py:99-113 with i_turbulence = 1
+            if ts == 1 and cfg['stages']:
+                capture('st00_pre', full=True)
+                state['on'] = True
+            Diagnostics.secondary_diag(**F.get(Diagnostics.fields_secondary_diag, target=CPU))
+            F.TURB.compute_turbulence(GR, **F.get(F.TURB.fields_main, target=CPU))
+        else:
+            Diagnostics.secondary_diag(**F.get(Diagnostics.fields_secondary_diag, target=CPU))
+        if ts == 1 and cfg['stages'] and not turbulence:
             capture('st00_pre', full=True)
             state['on'] = True
         dyn_matsuno.step_matsuno(GR, F)
@@ -312,6 +332,41 @@ def run_case(name):
             raise RuntimeError('reference run produced non-finite UWIND')
     if cfg['stages']:
         out['meta/stage_seq'] = np.array(state['seq'])
+
+    if turbulence:
+        # kernel-level vector for compute_turbulence_cpu (turb_compute.py:191-208): in the model
+        # state above every K sits on the lower clamp; random near-surface columns exercise the
+        # unclamped formula, both clamps and the equal-wind guard
+        import turb_compute
+        r2 = np.random.default_rng(23)
+        shp, shps = F.host['POTT'].shape, F.host['PHIVB'].shape
+        kin = {}
+        kin['HSURF'] = r2.uniform(0., 2000., F.host['HSURF'].shape)
+        hgt = np.cumsum(r2.uniform(0.02, 1.5, shps)[:, :, ::-1], axis=2)[:, :, ::-1]     # decreasing with k
+        kin['PHIVB'] = (kin['HSURF'] + hgt - hgt[:, :, -1:]) * 9.81
+        kin['PHI'] = 0.5 * (kin['PHIVB'][:, :, :-1] + kin['PHIVB'][:, :, 1:])
+        kin['QV'] = r2.uniform(0., 0.02, shp)
+        kin['QV'][r2.uniform(size=shp) < 0.1] = 0.                                        # below the 1e-7 clamp
+        amp = 10. ** r2.uniform(-3., 0.5, shp[:2] + (1,))                                 # per-column shear scale
+        kin['WINDX'] = 5. + amp * r2.uniform(-1., 1., shp)
+        kin['WINDY'] = -3. + amp * r2.uniform(-1., 1., shp)
+        same = r2.uniform(size=shp[:2]) < 0.1
+        kin['WINDX'][same] = kin['WINDX'][same][:, :1]                                    # equal winds in a column
+        kin['POTT'] = 300. - 1e-4 * np.arange(shp[2])[None, None, :] + r2.uniform(-2e-4, 2e-4, shp)
+        kin['POTTVB'] = 300. + r2.uniform(-0.5, 0.5, shps)
+        KM = np.full(shps, np.nan)
+        KH = np.full(shps, np.nan)
+        turb_compute.compute_turbulence_cpu(KM, KH, kin['PHIVB'].copy(), kin['HSURF'].copy(), kin['PHI'].copy(),
+                                            kin['QV'].copy(), kin['WINDX'].copy(), kin['WINDY'].copy(),
+                                            kin['POTTVB'].copy(), kin['POTT'].copy())
+        for n, a in kin.items():
+            out['kturb_in/' + n] = a
+        out['kturb_out/KMOM'] = KM
+        out['kturb_out/KHEAT'] = KH
+        inner = KM[:, :, 1:-1]
+        print('[%s] kernel-level turbulence vector: %.0f%% at min, %.0f%% at max, %.0f%% in between' % (
+            name, 100 * np.mean(inner == 1e-6), 100 * np.mean(inner == 0.01),
+            100 * np.mean((inner > 1e-6) & (inner < 0.01))))
 
     os.makedirs(GOLDEN, exist_ok=True)
     path = os.path.join(GOLDEN, name + '.npz')

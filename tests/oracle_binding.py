@@ -43,7 +43,8 @@ ORACLE_FIELDS = ['COLP', 'COLP_OLD', 'COLP_NEW', 'dCOLPdt', 'HSURF',
                  'PVTF', 'PVTFVB', 'PHI', 'PHIVB',
                  'RHO', 'RHOVB', 'KMOM', 'KHEAT',
                  'SSHFLX', 'SMOMXFLX', 'SMOMYFLX', 'dPOTTdt_RAD',
-                 'QV', 'QV_OLD', 'QC', 'QC_OLD', 'dQVdt', 'dQCdt', 'dQVdt_TURB', 'SLHFLX']
+                 'QV', 'QV_OLD', 'QC', 'QC_OLD', 'dQVdt', 'dQCdt', 'dQVdt_TURB', 'SLHFLX',
+                 'TAIR', 'TAIRVB', 'PAIR', 'PAIRVB', 'WINDX', 'WINDY', 'WIND']
 
 
 class OracleFields(C.Structure):
@@ -77,7 +78,8 @@ def load_oracle():
                   'oracle_stage_temperature', 'oracle_stage_primary_diag', 'oracle_stage_moisture',
                   'oracle_moist_tendency'):
             getattr(lib, n).argtypes = [cp, gp, fp]
-        for n in ('oracle_diag_phi', 'oracle_diag_pottvb', 'oracle_diag_rho'):
+        for n in ('oracle_diag_phi', 'oracle_diag_pottvb', 'oracle_diag_rho', 'oracle_diag_secondary',
+                  'oracle_compute_turbulence'):
             getattr(lib, n).argtypes = [cp, fp]
         lib.oracle_step_matsuno.argtypes = [cp, gp, fp, C.c_double, C.c_int, C.c_int]
         _lib = lib
@@ -148,6 +150,12 @@ class Oracle:
 
     def diag_rho(self):
         c, g, f = self._c(); self.lib.oracle_diag_rho(c, f)
+
+    def secondary_diag(self):
+        c, g, f = self._c(); self.lib.oracle_diag_secondary(c, f)
+
+    def compute_turbulence(self):
+        c, g, f = self._c(); self.lib.oracle_compute_turbulence(c, f)
 
     def step_matsuno(self, dt, nsteps=1, with_rho=True):
         c, g, f = self._c()

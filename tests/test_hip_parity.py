@@ -216,3 +216,61 @@ def test_config_errors_are_reported():
     with pytest.raises(DycoreError):
         core.upload('UWIND', np.zeros((3, 3, 3)))
     core.close()
+
+
+def test_secondary_diag_and_turbulence_vs_golden():
+    """SURVEY.md 8f rank 2 on the GPU: full secondary diagnostics and the turbulence scheme
+    (stage by stage in the model loop with the scheme on, incl. the dycore stages it feeds), and
+    the kernel-level vector that leaves the K clamps."""
+    from climate_model_amd import Turbulence
+    z = load_golden('g10x4_phys')
+    nx, ny = int(z['meta/nx']), int(z['meta/ny'])
+    GR = grid_from_golden(z, 1, 1)
+    core = make_core(GR, 1, 1)
+    F = fields_from(GR, core, fields_of(z, 'st00_pre'))
+    TURB = Turbulence(GR)
+    first_cont, checked = True, 0
+    for tag in stage_tags(z)[1:]:
+        stage = tag.split('_', 1)[1]
+        if stage == 'secondary_diag':
+            Diagnostics.secondary_diag(**F.get(Diagnostics.fields_secondary_diag, target='HIP'))
+        elif stage == 'turbulence':
+            TURB.compute_turbulence(GR, **F.get(TURB.fields_main, target='HIP'))
+        elif stage == 'continuity':
+            if first_cont:
+                for a in PROGNOSTIC + ['QV', 'QC']:
+                    core.copy_field(a + '_OLD', a)
+                first_cont = False
+            Tendencies.continuity(GR, GR.GRF['HIP'], **F.get(Tendencies.fields_continuity, target='HIP'))
+        elif stage == 'momentum':
+            Tendencies.momentum(GR.GRF['HIP'], **F.get(Tendencies.fields_momentum, target='HIP'))
+        elif stage == 'temperature':
+            Tendencies.temperature(GR.GRF['HIP'], **F.get(Tendencies.fields_temperature, target='HIP'))
+        elif stage == 'moisture':
+            Tendencies.moisture(GR.GRF['HIP'], **F.get(Tendencies.fields_moisture, target='HIP'))
+        elif stage == 'euler_forward':
+            core.copy_field('COLP', 'COLP_NEW')
+            Prognostics.euler_forward(GR, GR.GRF['HIP'], **F.get(Prognostics.fields_prognostic, target='HIP'))
+        elif stage == 'primary_diag':
+            Diagnostics.primary_diag(GR.GRF['HIP'], **F.get(Diagnostics.fields_primary_diag, target='HIP'))
+        for name, ref in fields_of(z, tag).items():
+            if name not in FIELD_TABLE:
+                continue
+            got = core.download(name)
+            err, ncmp, bad = rel_max_err(got, ref, name, nx, ny)
+            assert bad == 0 and err <= STAGE_TOL, '%s %s: rel err %.3e (%d bad)' % (tag, name, err, bad)
+            m = np.isfinite(ref)
+            got[m] = ref[m]
+            core.upload(name, got)
+            checked += 1
+    assert checked > 50
+    for n in ('HSURF', 'PHIVB', 'PHI', 'QV', 'WINDX', 'WINDY', 'POTT', 'POTTVB'):
+        core.upload(n, z['kturb_in/' + n])
+    core.upload('KMOM', np.full(core.field_shape('KMOM'), np.nan))
+    core.upload('KHEAT', np.full(core.field_shape('KHEAT'), np.nan))
+    core.compute_turbulence()
+    for n in ('KMOM', 'KHEAT'):
+        ref, got = z['kturb_out/' + n], core.download(n)
+        assert np.array_equal(np.isfinite(ref), np.isfinite(got))
+        m = np.isfinite(ref)
+        assert np.max(np.abs(got[m] - ref[m]) / np.abs(ref[m])) <= 1e-11

@@ -94,3 +94,61 @@ def test_dry_switch_equals_zero_K():
         o.step_matsuno(dt, 3, with_rho=True)
     for name in PROGNOSTIC:
         np.testing.assert_array_equal(a.F[name], b.F[name])
+
+
+def test_secondary_diag_and_turbulence_scheme():
+    """the full secondary diagnostics and the reference's turbulence
+    scheme (turb_compute.py) -- stage by stage on the model state with the scheme switched on,
+    and on the kernel-level vector whose columns leave the K clamps."""
+    z = load_golden('g10x4_phys')
+    nx, ny = int(z['meta/nx']), int(z['meta/ny'])
+    dt = float(z['meta/dt'])
+    o = oracle_from_golden(z, 'st00_pre', i_turb=1, i_moist=1)
+    n_checked = 0
+    first_cont = True
+    for tag in stage_tags(z)[1:]:
+        stage = tag.split('_', 1)[1]
+        if stage == 'secondary_diag':
+            o.secondary_diag()
+        elif stage == 'turbulence':
+            o.compute_turbulence()
+        elif stage == 'continuity':
+            if first_cont:
+                for a in ('COLP', 'UWIND', 'VWIND', 'POTT', 'QV', 'QC'):
+                    o.F[a + '_OLD'][...] = o.F[a]
+                first_cont = False
+            o.continuity(dt)
+        elif stage == 'momentum':
+            o.momentum()
+        elif stage == 'temperature':
+            o.temperature()
+        elif stage == 'moisture':
+            o.moisture()
+        elif stage == 'euler_forward':
+            o.F['COLP'][...] = o.F['COLP_NEW']
+            o.euler_forward(dt)
+        elif stage == 'primary_diag':
+            o.primary_diag()
+        for name, ref in fields_of(z, tag).items():
+            if name not in ORACLE_FIELDS:
+                continue
+            err, ncmp, bad = rel_max_err(o.F[name], ref, name, nx, ny)
+            assert bad == 0 and err <= STAGE_TOL, '%s %s: rel err %.3e (%d bad)' % (tag, name, err, bad)
+            m = np.isfinite(ref)
+            o.F[name][m] = ref[m]
+            n_checked += 1
+    assert n_checked > 50
+    # kernel-level vector
+    o2 = oracle_from_golden(z, None, i_turb=1, i_moist=1)
+    for n in ('HSURF', 'PHIVB', 'PHI', 'QV', 'WINDX', 'WINDY', 'POTT', 'POTTVB'):
+        o2.F[n][...] = z['kturb_in/' + n]
+    o2.F['KMOM'][...] = np.nan
+    o2.F['KHEAT'][...] = np.nan
+    o2.compute_turbulence()
+    for n in ('KMOM', 'KHEAT'):
+        ref = z['kturb_out/' + n]
+        assert np.array_equal(np.isfinite(ref), np.isfinite(o2.F[n]))
+        m = np.isfinite(ref)
+        assert np.max(np.abs(o2.F[n][m] - ref[m]) / np.abs(ref[m])) <= 1e-12
+    inner = z['kturb_out/KMOM'][:, :, 1:-1]
+    assert 0.2 < np.mean((inner > 1e-6) & (inner < 0.01)) < 0.8      # the vector leaves the clamps

@@ -7,6 +7,7 @@ from .hip_backend import HipDycore, DycoreError
 from .discretizations import TendencyFactory, DiagnosticsFactory, PrognosticsFactory
 from .matsuno import step_matsuno, step_matsuno_fused, compute_tendencies
 from .turbulence import Turbulence
+from . import solver
 
 __all__ = ['Namelist', 'Grid', 'ModelFields', 'FIELD_TABLE', 'CPU', 'HIP', 'HipDycore',
            'DycoreError', 'TendencyFactory', 'DiagnosticsFactory', 'PrognosticsFactory',

@@ -159,7 +159,7 @@ class ModelFields:
         self.field_groups = {
             self.ALL_FIELDS: list(self.host.keys()),
             self.PROGNOSTIC_FIELDS: ['COLP', 'UWIND', 'VWIND', 'POTT'],
-            self.PRINT_DIAG_FIELDS: ['COLP', 'UWIND', 'POTT'],
+            self.PRINT_DIAG_FIELDS: ['COLP', 'WIND', 'POTT', 'UWIND'],
         }
         # non-NaN values the kernels rely on (io_initial_conditions.py:45-46)
         self.host['POTTVB'][:] = 0.
@@ -188,13 +188,13 @@ class ModelFields:
     def copy_host_to_device(self, GR=None, field_group=ALL_FIELDS):
         """Upload a field group.  Device buffers are NaN-filled at creation like the host
         arrays, so fields whose host copy was never touched need no transfer."""
-        names = self.field_groups.get(field_group, field_group)
+        names = self.field_groups[field_group] if isinstance(field_group, str) else list(field_group)
         for name in names:
             if field_group == self.ALL_FIELDS and not dict.__contains__(self.host, name):
                 continue
             self.core.upload(name, self.host[name])
 
     def copy_device_to_host(self, GR=None, field_group=ALL_FIELDS):
-        names = self.field_groups.get(field_group, field_group)
+        names = self.field_groups[field_group] if isinstance(field_group, str) else list(field_group)
         for name in names:
             self.core.download(name, self.host[name])

@@ -149,6 +149,12 @@ class Grid:
         self.nb = 1
         self.nx, self.ny, self.nz = int(nx), int(ny), int(nz)
         self.nxs, self.nys, self.nzs = self.nx + 1, self.ny + 1, self.nz + 1
+        self.i = np.arange(1, self.nx + 1)
+        self.i_s = np.arange(1, self.nxs + 1)
+        self.j = np.arange(1, self.ny + 1)
+        self.js = np.arange(1, self.nys + 1)
+        self.ii, self.jj = np.ix_(self.i, self.j)
+        self.iis, self.jjs = np.ix_(self.i_s, self.js)
         for name in cls.GRID_FIELD_NAMES:
             src = name if name in grf else 'POTT_dif_coef'       # moist_dif_coef defaults to POTT's
             setattr(self, name, np.array(grf[src], dtype=np.float64))

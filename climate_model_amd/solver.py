@@ -1,0 +1,101 @@
+"""Time loop around the dycore step, the way the reference's `solver.py:82-226` runs it.
+
+Per time step: status line every `nth_ts_print_diag` steps (io_functions.py:93-134, with the
+"MODEL CRASH" test), secondary diagnostics, turbulence if switched on, then the Matsuno step.
+Microphysics, surface, radiation and NetCDF output of the reference's loop are outside the hot
+path (out of scope) and have no slot here.
+
+`fused_steps > 1` hands up to that many Matsuno steps to the library in one call
+(dycore_step_matsuno) when no per-step physics is active; chunks end at the status lines.
+"""
+import numpy as np
+
+from .fields import HIP
+from .discretizations import DiagnosticsFactory
+from .matsuno import step_matsuno, step_matsuno_fused
+from .turbulence import Turbulence
+
+Diagnostics = DiagnosticsFactory(target=HIP)
+
+
+def diagnose_print_diag_fields(GR, WIND, COLP, POTT):
+    """io_functions.py:68-90: max wind, mass-weighted mean wind and potential temperature,
+    area-weighted mean column pressure."""
+    ii, jj = GR.ii, GR.jj
+    A = GR.A
+    w = COLP[ii, jj, 0] * A[ii, jj, 0]
+    max_wind = np.max(WIND[ii, jj, :])
+    mean_wind = 0
+    mean_temp = 0
+    for k in range(GR.nz):
+        mean_wind += np.sum(WIND[ii, jj, k] * w) / np.sum(w)
+        mean_temp += np.sum(POTT[ii, jj, k] * w) / np.sum(w)
+    mean_wind = mean_wind / GR.nz
+    mean_temp = mean_temp / GR.nz
+    mean_colp = np.sum(COLP[ii, jj, 0] * A[ii, jj, 0]) / np.sum(A[ii, jj, 0])
+    return max_wind, mean_wind, mean_temp, mean_colp
+
+
+def print_ts_info(GR, F, nth_ts_print_diag=50, out=print):
+    """io_functions.py:93-111.  Returns the four diagnostics (or None when it is not a
+    printing step)."""
+    if GR.ts % nth_ts_print_diag != 0:
+        return None
+    F.copy_device_to_host(GR, F.PRINT_DIAG_FIELDS)
+    GR.timer.start('diag')
+    vmax, mean_wind, mean_temp, mean_colp = diagnose_print_diag_fields(
+        GR, F.host['WIND'], F.host['COLP'], F.host['POTT'])
+    GR.timer.stop('diag')
+    out(str(GR.ts) + '  ' + str(np.round(GR.ts * GR.dt / 3600 / 24, 3)) + '\t days' +
+        ' vmax: ' + str(np.round(vmax, 1)) + '  m/s vmean: ' + str(np.round(mean_wind, 3)) +
+        ' m/s Tmean: ' + str(np.round(mean_temp, 7)) + '  K  COLP: ' + str(np.round(mean_colp, 2)) + ' Pa')
+    UW = F.host['UWIND'][GR.iis, GR.jj]
+    if np.sum(np.isnan(UW)) > 0 or np.max(UW) > 500:
+        raise ValueError('MODEL CRASH')
+    return vmax, mean_wind, mean_temp, mean_colp
+
+
+def run(GR, F, nts, nth_ts_print_diag=50, fused=True, fused_steps=1, out=print):
+    """solver.py:70-226.  F.host must already be uploaded.  Returns the list of printed
+    diagnostics tuples."""
+    core = F.core
+    turb = Turbulence(GR) if GR.nl.i_turb else None
+    fused_steps = max(1, int(fused_steps))
+    if turb is not None or not fused:
+        fused_steps = 1
+    log = []
+
+    GR.timer.start('diag')
+    Diagnostics.primary_diag(GR.GRF[Diagnostics.target],
+                             **F.get(Diagnostics.fields_primary_diag, target=Diagnostics.target))
+    GR.timer.stop('diag')
+
+    end = GR.ts + int(nts)
+    while GR.ts < end:
+        GR.timer.start('total')
+        step = GR.ts + 1                      # the reference counts the step before running it
+        # a fused chunk may not run past the next status line
+        n = min(fused_steps, end - GR.ts, (step // nth_ts_print_diag + 1) * nth_ts_print_diag - step)
+
+        GR.timer.start('diag')
+        Diagnostics.secondary_diag(**F.get(Diagnostics.fields_secondary_diag, target=Diagnostics.target))
+        GR.timer.stop('diag')
+        if step % nth_ts_print_diag == 0:
+            GR.ts = step
+            try:
+                log.append(print_ts_info(GR, F, nth_ts_print_diag, out))
+            finally:
+                GR.ts = step - 1
+
+        if turb is not None:
+            GR.timer.start('turb')
+            turb.compute_turbulence(GR, **F.get(turb.fields_main, target=turb.target))
+            GR.timer.stop('turb')
+
+        if fused:
+            step_matsuno_fused(GR, F, n)
+        else:
+            step_matsuno(GR, F)
+        GR.timer.stop('total')
+    core.sync()
+    return log

@@ -69,3 +69,24 @@ def test_grid_and_fields_shapes():
     assert np.isnan(F.host['UFLX']).all() and (F.host['WWIND'] == 0).all()
     for name in GR.GRID_FIELD_NAMES:
         assert name in GR.GRF['HIP']
+
+
+@pytest.mark.parametrize('case,d,nz', [('g10x4_dry', 10, 4), ('g4x8_dry', 4, 8)])
+def test_reference_initial_conditions_rebuilt(case, d, nz):
+    """initial_conditions.py rebuilds the reference's sigma levels and initial state from its two
+    input data files: compared with what the reference itself produced (golden ic/ and grid/)."""
+    from climate_model_amd import initial_conditions as ic
+    data_dir = os.path.join(ROOT, 'tests', 'golden', 'data')
+    z = np.load(os.path.join(ROOT, 'tests', 'golden', case + '.npz'))
+    GR0 = Grid(Namelist(nz=nz, dlat_deg=d, dlon_deg=d))
+    sig = ic.sigma_levels(GR0, data_dir)
+    np.testing.assert_allclose(sig, z['grid/sigma_vb'].ravel(), rtol=0, atol=1e-15)
+    GR = Grid(Namelist(nz=nz, dlat_deg=d, dlon_deg=d), sigma_vb=z['grid/sigma_vb'].ravel())
+    F = ModelFields(GR)
+    ic.initialize_fields(GR, F, data_dir)
+    for n, tol in [('HSURF', 1e-12), ('COLP', 1e-13), ('POTT', 1e-13), ('UWIND', 1e-14), ('VWIND', 1e-14)]:
+        ref, got = z['ic/' + n], F.host[n]
+        m = np.isfinite(ref)
+        assert np.array_equal(m, np.isfinite(got)), n
+        scale = np.max(np.abs(ref[m]))
+        assert np.max(np.abs(got[m] - ref[m])) <= tol * scale, (n, np.max(np.abs(got[m] - ref[m])) / scale)

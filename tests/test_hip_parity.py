@@ -274,3 +274,38 @@ def test_secondary_diag_and_turbulence_vs_golden():
         assert np.array_equal(np.isfinite(ref), np.isfinite(got))
         m = np.isfinite(ref)
         assert np.max(np.abs(got[m] - ref[m]) / np.abs(ref[m])) <= 1e-11
+
+
+@pytest.mark.gpu
+def test_solver_loop_matches_oracle_and_reports():
+    """solver.run: reference loop order (secondary diag, turbulence, Matsuno step) with the status
+    line of io_functions.print_ts_info; end state against the oracle run the same way."""
+    from climate_model_amd import solver
+    z = load_golden('g10x4_phys')
+    GR = grid_from_golden(z, i_turb=1, i_moist=1)
+    core = make_core(GR, i_turb=1, i_moist=1)
+    F = fields_from(GR, core, fields_of(z, 'ic'))
+    lines = []
+    log = solver.run(GR, F, 5, nth_ts_print_diag=2, fused=True, out=lines.append)
+    assert GR.ts == 5 and len(log) == 2 and len(lines) == 2
+    assert lines[0].startswith('2  ') and ' vmax: ' in lines[0] and lines[1].startswith('4  ')
+    F.copy_device_to_host(GR, ['COLP', 'UWIND', 'VWIND', 'POTT', 'QV', 'QC'])
+    for n in ('COLP', 'UWIND', 'VWIND', 'POTT', 'QV'):
+        err, ncmp, bad = rel_max_err(F.host[n], z['step005/' + n], n, GR.nx, GR.ny)
+        assert ncmp > 0 and bad == 0 and err < 1e-9, (n, err)
+    # the line printed at step 2 describes the state after step 1
+    vmax, vmean, tmean, colp = log[0]
+    A = z['grid/A']
+    ii, jj = GR.ii, GR.jj
+    C1, T1 = z['step001/COLP'], z['step001/POTT']
+    ref_colp = np.sum(C1[ii, jj, 0] * A[ii, jj, 0]) / np.sum(A[ii, jj, 0])
+    w = C1[ii, jj, 0] * A[ii, jj, 0]
+    ref_t = np.mean([np.sum(T1[ii, jj, k] * w) / np.sum(w) for k in range(GR.nz)])
+    assert abs(colp - ref_colp) < 1e-11 * ref_colp and abs(tmean - ref_t) < 1e-11 * ref_t
+    assert 0 < vmean < vmax < 100
+    # crash test
+    bad = F.host['UWIND'].copy()
+    bad[3, 3, 1] = 900.
+    core.upload('UWIND', bad)
+    with pytest.raises(ValueError, match='MODEL CRASH'):
+        solver.print_ts_info(GR, F, 1, out=lambda s: None)

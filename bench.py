@@ -216,6 +216,10 @@ def main():
     roof = None
     if dom:
         per_launch_bytes = KERNEL_PASSES[dom] * band_cells * 8
+        # a band runs the kernel as two launches per substep (inner rows behind the exchange, edge
+        # rows after it): price the pair as the one pass over the band it is
+        if world > 1:
+            dom_n = 2 * args.steps
         avg_s = dom_ms / dom_n / 1e3
         ach = per_launch_bytes / avg_s / 1e9
         step_ach = PASSES_PER_STEP * 8 * value / 1e9 / world      # per GPU

@@ -9,6 +9,10 @@ y-staggered VFLX) and refreshes those rows from its neighbours twice per Matsuno
   phase 'A' after continuity : UFLX, VFLX, WWIND, COLP_NEW   (feed the 3x3 momentum fluxes)
   phase 'B' after Euler step : UWIND, VWIND, POTT            (the new state)
 
+The overlapped schedule (_overlapped_step) sends phase B in two pieces, 'B1' = UWIND, VWIND as
+soon as the momentum kernel is done and 'B2' = POTT (QV, QC) after the temperature kernel, so
+that every message travels behind a kernel that does not need it.
+
 Ownership: band r owns mass rows j in [j0, j0+ny) and the v-rows (js) on the southern edge
 of each of them; the northernmost band also owns js = ny_global+1 (the pole).  Every
 exchanged row therefore has exactly one owner, and an N-band run reproduces the 1-band
@@ -27,15 +31,20 @@ from .fields import FIELD_TABLE
 SEND_NORTH = {
     'A': [('UFLX', 'N'), ('VFLX', 'N'), ('WWIND', 'N'), ('COLP_NEW', 'N')],
     'B': [('UWIND', 'N'), ('VWIND', 'N'), ('POTT', 'N')],
+    'B1': [('UWIND', 'N'), ('VWIND', 'N')],
+    'B2': [('POTT', 'N')],
 }
 SEND_SOUTH = {
     'A': [('UFLX', 1), ('VFLX', 1), ('VFLX', 2), ('WWIND', 1), ('COLP_NEW', 1)],
     'B': [('UWIND', 1), ('VWIND', 1), ('POTT', 1)],
+    'B1': [('UWIND', 1), ('VWIND', 1)],
+    'B2': [('POTT', 1)],
 }
+PHASES = ('A', 'B', 'B1', 'B2')
 # rows at which the RECEIVER stores what its southern / northern neighbour sent
 # (offsets relative to the receiver's own ny: 'N+1' = north halo row, 'N+2' = second one)
-RECV_FROM_SOUTH = {'A': [0, 0, 0, 0], 'B': [0, 0, 0]}
-RECV_FROM_NORTH = {'A': ['N+1', 'N+1', 'N+2', 'N+1', 'N+1'], 'B': ['N+1', 'N+1', 'N+1']}
+RECV_FROM_SOUTH = {'A': [0, 0, 0, 0], 'B': [0, 0, 0], 'B1': [0, 0], 'B2': [0]}
+RECV_FROM_NORTH = {'A': ['N+1', 'N+1', 'N+2', 'N+1', 'N+1'], 'B': ['N+1', 'N+1', 'N+1'], 'B1': ['N+1', 'N+1'], 'B2': ['N+1']}
 
 
 class BandLayout:
@@ -97,8 +106,8 @@ class BandHalo:
         self._resolved = {}
         self.plan = {}
         moist = bool(getattr(core, 'i_moist', False))       # QV, QC travel with the state (phase B)
-        for ph in ('A', 'B'):
-            extra = [('QV', None), ('QC', None)] if (moist and ph == 'B') else []
+        for ph in PHASES:
+            extra = [('QV', None), ('QC', None)] if (moist and ph in ('B', 'B2')) else []
             sn = [f for f, _ in SEND_NORTH[ph]] + [f for f, _ in extra]
             ss = [f for f, _ in SEND_SOUTH[ph]] + [f for f, _ in extra]
             self.plan[ph] = dict(
@@ -120,7 +129,7 @@ class BandHalo:
             fn = getattr(self.core, 'substep_field', None)
             out = {}
             for k, (names, rows) in self.plan[ph].items():
-                out[k] = ([fn(sub, n) if (fn and ph == 'B') else n for n in names], rows)
+                out[k] = ([fn(sub, n) if (fn and ph != 'A') else n for n in names], rows)
             self._resolved[key] = out
         return self._resolved[key]
 
@@ -132,7 +141,7 @@ class _TorchBuffers:
     def __init__(self, halo, device):
         import torch
         self.send, self.recv, self.split_send, self.split_recv = {}, {}, {}, {}
-        for ph in ('A', 'B'):
+        for ph in PHASES:
             sz = halo.sizes(ph)
             ss = sz['send_south'] if halo.has_south else 0
             sn = sz['send_north'] if halo.has_north else 0
@@ -156,11 +165,94 @@ def _merged(halo, ph, sub, kind):
     return names, rows
 
 
+class _Streams:
+    """The two HIP streams of an overlapped band step: `main` is the stream the core launches on,
+    `comm` carries pack -> transport -> unpack (+ the diagnostics of the received rows).  One
+    event per exchange phase marks "halo rows of this phase are in place"."""
+
+    def __init__(self, cores, device):
+        import torch
+        self.torch = torch
+        ptrs = {c.stream_ptr for c in cores}
+        if len(ptrs) != 1:
+            raise ValueError('all bands of one process must launch on the same stream')
+        ptr = ptrs.pop()
+        self.main = torch.cuda.ExternalStream(ptr, device=device) if ptr else torch.cuda.default_stream(device)
+        self.comm = torch.cuda.Stream(device=device)
+        self.done = {ph: torch.cuda.Event() for ph in PHASES}
+        self.pending = {ph: False for ph in PHASES}
+
+    def wait(self, ph):
+        """main stream: do not pass this point before exchange `ph` has delivered."""
+        if self.pending[ph]:
+            self.main.wait_event(self.done[ph])
+            self.pending[ph] = False
+
+
+def _overlapped_step(cores, streams, deliver, dt, nsteps, with_rho):
+    """One schedule for one band per process (DistributedBands) and for several bands in one
+    process (LocalBands).  Per substep, on the main stream (| = point where it waits):
+
+        |B1  continuity                          pack A
+             momentum, inner tiles
+        |A |B2  momentum, edge tiles             pack B1
+             temperature (+ moisture), halos     pack B2
+
+    and on the comm stream, behind each pack: transport, unpack (after B2: primary diagnostics
+    of the received rows).  A travels behind the inner momentum tiles, B1 (winds) behind the
+    temperature kernel, B2 (POTT) behind the continuity kernel of the NEXT substep, which needs
+    the wind rows only.  deliver(ph, sub) issues transport + unpack on the current stream."""
+    torch = streams.torch
+    C0 = cores[0]
+
+    def on_comm(ph, sub):
+        for c in cores:
+            c.pack_rows(*_merged(c._band_halo, ph, sub, 'send'), c._band_bufs.send[ph].data_ptr())
+        streams.comm.wait_stream(streams.main)
+        with torch.cuda.stream(streams.comm):
+            for c in cores:
+                c.use_stream(streams.comm.cuda_stream)
+            try:
+                deliver(ph, sub)
+                if ph == 'B2':
+                    for c in cores:
+                        c.substep_part(dt, sub, 2)
+            finally:
+                for c in cores:
+                    c.use_stream(None)
+            streams.done[ph].record(streams.comm)
+        streams.pending[ph] = True
+
+    for _ in range(nsteps):
+        for c in cores:
+            c.step_begin(with_rho)
+        for sub in (0, 1):
+            streams.wait('B1')
+            for c in cores:
+                c.substep_part(dt, sub, 0)
+            on_comm('A', sub)
+            for c in cores:
+                c.substep_part(dt, sub, C0.PART_MOM_INNER)
+            streams.wait('A')
+            streams.wait('B2')
+            for c in cores:
+                c.substep_part(dt, sub, C0.PART_MOM_EDGE)
+            on_comm('B1', sub)
+            for c in cores:
+                c.substep_part(dt, sub, C0.PART_TEMP)
+            on_comm('B2', sub)
+    streams.wait('B1')      # leave with every stream joined into main
+    streams.wait('B2')
+
+
 class DistributedBands:
     """One process = one band.  Drives the Matsuno step in parts with neighbour exchanges
-    through torch.distributed (RCCL when the process group's backend is nccl)."""
+    through torch.distributed (RCCL when the process group's backend is nccl).  With
+    overlap=True (default on a GPU) the exchanges run on a second stream behind the rows that
+    do not depend on them (_overlapped_step); overlap=False is the plain sequence
+    part 0, exchange A, part 1, exchange B, part 2."""
 
-    def __init__(self, core, layout, rank, device, group=None):
+    def __init__(self, core, layout, rank, device, group=None, overlap=None):
         import torch.distributed as dist
         self.dist = dist
         self.core, self.layout, self.rank = core, layout, rank
@@ -168,14 +260,19 @@ class DistributedBands:
         self.south, self.north = layout.south(rank), layout.north(rank)
         self.halo = BandHalo(core, layout.ny(rank), self.south is not None, self.north is not None)
         self.bufs = _TorchBuffers(self.halo, device)
-        self.staged = dist.get_backend(group) != 'nccl' and str(device) != 'cpu'
+        on_gpu = str(device) != 'cpu'
+        self.staged = dist.get_backend(group) != 'nccl' and on_gpu
+        # the split parts exist for the fused (dry / moist) step; the turbulence-coupled staged step
+        # keeps the plain sequence
+        self.overlap = (on_gpu if overlap is None else bool(overlap)) and getattr(core, 'overlap_parts', False)
+        if self.overlap:
+            core._band_halo, core._band_bufs = self.halo, self.bufs
+            self.streams = _Streams([core], device)
 
-    def exchange(self, ph, sub=1):
+    def _transport(self, ph):
+        """send/recv of the packed buffers with both neighbours, on the current stream."""
         import torch
-        if self.south is None and self.north is None:
-            return
-        dist, b, core = self.dist, self.bufs, self.core
-        core.pack_rows(*_merged(self.halo, ph, sub, 'send'), b.send[ph].data_ptr())
+        dist, b = self.dist, self.bufs
         if self.staged:     # gloo: through host memory
             send, recv = b.send[ph].cpu(), torch.empty(b.recv[ph].shape, dtype=torch.float64)
         else:
@@ -192,10 +289,25 @@ class DistributedBands:
             w.wait()
         if self.staged:
             b.recv[ph].copy_(recv)
-        core.unpack_rows(*_merged(self.halo, ph, sub, 'recv'), b.recv[ph].data_ptr())
+
+    def exchange(self, ph, sub=1):
+        """pack, transport, unpack on the current stream."""
+        if self.south is None and self.north is None:
+            return
+        self.core.pack_rows(*_merged(self.halo, ph, sub, 'send'), self.bufs.send[ph].data_ptr())
+        self._transport(ph)
+        self.core.unpack_rows(*_merged(self.halo, ph, sub, 'recv'), self.bufs.recv[ph].data_ptr())
+
+    def _deliver(self, ph, sub):
+        self._transport(ph)
+        self.core.unpack_rows(*_merged(self.halo, ph, sub, 'recv'), self.bufs.recv[ph].data_ptr())
 
     def step_matsuno(self, dt, nsteps=1, with_rho=None):
         core = self.core
+        if self.south is None and self.north is None:
+            return core.step_matsuno(dt, nsteps, with_rho)
+        if self.overlap:
+            return _overlapped_step([core], self.streams, self._deliver, dt, nsteps, with_rho)
         for _ in range(nsteps):
             core.step_begin(with_rho)
             for sub in (0, 1):
@@ -207,24 +319,24 @@ class DistributedBands:
 
 
 class LocalBands:
-    """All bands inside one process (one or several handles on the same GPU), exchanging
-    through device-to-device copies.  Test vehicle for the band-aware kernels."""
+    """All bands inside one process (several handles on the same GPU and stream), exchanging
+    through device-to-device copies.  Test vehicle for the band-aware kernels and for the
+    overlapped schedule (overlap=True: same stream choreography as DistributedBands)."""
 
-    def __init__(self, cores, layout, device):
+    def __init__(self, cores, layout, device, overlap=True):
         self.cores, self.layout = cores, layout
         self.halos = [BandHalo(c, layout.ny(r), layout.south(r) is not None, layout.north(r) is not None)
                       for r, c in enumerate(cores)]
         self.bufs = [_TorchBuffers(h, device) for h in self.halos]
+        self.overlap = bool(overlap) and len(cores) > 1 and all(c.overlap_parts for c in cores)
+        if self.overlap:
+            for c, h, b in zip(cores, self.halos, self.bufs):
+                c._band_halo, c._band_bufs = h, b
+            self.streams = _Streams(cores, device)
 
-    def exchange(self, ph, sub=1):
-        import torch
+    def _deliver(self, ph, sub, host_sync=False):
+        """neighbour copies + unpack on the current stream (the packs were queued before it)."""
         n = len(self.cores)
-        if n == 1:
-            return
-        for r in range(n):
-            self.cores[r].pack_rows(*_merged(self.halos[r], ph, sub, 'send'), self.bufs[r].send[ph].data_ptr())
-        for c in self.cores:
-            c.sync()
         for r in range(n):
             b = self.bufs[r]
             (rs, rn) = b.split_recv[ph]
@@ -234,11 +346,25 @@ class LocalBands:
             if r < n - 1:   # from the northern neighbour: its south part
                 ss2, sn2 = self.bufs[r + 1].split_send[ph]
                 b.recv[ph][rs:rs + rn].copy_(self.bufs[r + 1].send[ph][:ss2])
-        torch.cuda.synchronize()
+        if host_sync:
+            import torch
+            torch.cuda.synchronize()
         for r in range(n):
             self.cores[r].unpack_rows(*_merged(self.halos[r], ph, sub, 'recv'), self.bufs[r].recv[ph].data_ptr())
 
+    def exchange(self, ph, sub=1):
+        n = len(self.cores)
+        if n == 1:
+            return
+        for r in range(n):
+            self.cores[r].pack_rows(*_merged(self.halos[r], ph, sub, 'send'), self.bufs[r].send[ph].data_ptr())
+        for c in self.cores:
+            c.sync()
+        self._deliver(ph, sub, host_sync=True)
+
     def step_matsuno(self, dt, nsteps=1, with_rho=None):
+        if self.overlap:
+            return _overlapped_step(self.cores, self.streams, self._deliver, dt, nsteps, with_rho)
         for _ in range(nsteps):
             for c in self.cores:
                 c.step_begin(with_rho)

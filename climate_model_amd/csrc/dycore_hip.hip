@@ -110,7 +110,8 @@ struct dycore {
     DycoreConfig cfg;
     Geo g;
     Ptrs p;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;   // where launches go (dycore_use_stream can redirect them)
+    hipStream_t home = nullptr;     // the handle's own stream (DycoreConfig.stream or created here)
     bool own_stream = false;
     hipStream_t side = nullptr;     // halo-row diagnostics of a band overlap the next continuity
     hipEvent_t ev_main = nullptr, ev_side = nullptr;
@@ -214,7 +215,7 @@ int launch_check(const char *what)
 
 // lateral halo (misc_boundaries.py:22-42) of up to 12 fields in one launch
 struct HaloSpec { double *ptr; int stgx, stgy, nk; };
-int do_halo(dycore *h, std::initializer_list<HaloSpec> fields)
+int do_halo(dycore *h, const std::vector<HaloSpec> &fields)
 {
     Scope s(h, K_HALO_MULTI);
     HaloList l;
@@ -375,10 +376,32 @@ int refresh_lazy(dycore *h)
     return 0;
 }
 
+// Which tile rows of the momentum kernel a launch covers.  A latitude band overlaps its
+// neighbour exchange with the tiles whose stencils stay clear of the received halo rows
+// (INNER) and finishes the edge tiles (EDGE) once the rows have arrived; a band that touches a
+// pole has no neighbour on that side.  ALL = INNER + EDGE in one launch.
+enum { ROWS_ALL = 0, ROWS_INNER = 1, ROWS_EDGE = 2 };
+// inner range out of [0, n-1] given how many rows at each end depend on a neighbour
+bool row_subset(int n, int dep_s, int dep_n, int mode, RowSet &rs)
+{
+    int lo = dep_s, hi = n - 1 - dep_n;
+    if (lo > hi) { lo = n; hi = n - 1; }              // no inner part: everything is edge
+    if (mode == ROWS_ALL) rs = {0, n, n, 0};
+    else if (mode == ROWS_INNER) rs = {lo, hi - lo + 1, n, 0};
+    else rs = {0, n - (hi - lo + 1), lo, hi - lo + 1};
+    return rs.n > 0;
+}
+
 // prepare + dUFLXdt + dVFLXdt (+ Euler step of the winds when u_out != nullptr)
 int do_momentum_fused(dycore *h, const Ptrs &p, const double *u_old, const double *v_old,
-                      double *u_out, double *v_out, double dt)
+                      double *u_out, double *v_out, double dt, int mode = ROWS_ALL)
 {
+    // only the LDS-DMA kernel takes a tile-row subset; the others run whole with the edge part
+    const bool dma = u_out && h->mom_dma == 1 && h->g.nz <= DMAXZ;
+    if (!dma) {
+        if (mode == ROWS_INNER) return 0;
+        mode = ROWS_ALL;
+    }
     Scope s(h, K_MOM_FUSED);
     const int gbx = (h->g.nx + FTI - 1) / FTI, gby = (h->g.ny + FTJ - 1) / FTJ;
     const int nblk = gbx * gby;
@@ -390,7 +413,7 @@ int do_momentum_fused(dycore *h, const Ptrs &p, const double *u_old, const doubl
             hipLaunchKernelGGL(k_momentum_split<true>, gr, bl2, DMA_LDS_BYTES, h->stream, h->g, p, gbx, gby, jv_lo, u_old, v_old, u_out, v_out, dt);
         else
             hipLaunchKernelGGL(k_momentum_split<false>, gr, bl2, DMA_LDS_BYTES, h->stream, h->g, p, gbx, gby, jv_lo, u_old, v_old, u_out, v_out, dt);
-    } else if (u_out && h->mom_dma && h->g.nz <= DMAXZ) {
+    } else if (dma) {
         // rows per workgroup: 8 (8 wavefronts = 2 per SIMD, up to 256 VGPRs each).  Taller tiles
         // (9, 10 rows: fewer halo rows, better fit of 90-row bands on 256 CUs) are compiled in for
         // experiments (DYCORE_MOM_TJ) but need a third wavefront on one SIMD, which caps the
@@ -401,9 +424,16 @@ int do_momentum_fused(dycore *h, const Ptrs &p, const double *u_old, const doubl
         // level chunks per tile: with one workgroup per CU, `tiles` workgroups of 64 levels take
         // ceil(tiles / CUs) rounds; ks chunks take ceil(tiles*ks / CUs) rounds of (64/ks + 1)
         // levels (one extra level of prologue per chunk).  Pick the cheapest of 1, 2, 4.
+        // a tile reads rows j0-1 .. j0+tj+1 (VFLX): the first tile row of a band with a southern
+        // neighbour and every tile row that reaches beyond row ny of one with a northern neighbour
+        int dep_n = 0;
+        if (!h->g.pole_n)
+            for (int by = gby2 - 1; by >= 0 && by * tj + 1 + tj + 1 > h->g.ny; by--) dep_n++;
+        RowSet trows;
+        if (!row_subset(gby2, h->g.pole_s ? 0 : 1, dep_n, mode, trows)) return 0;
         int ks = 1;
         {
-            const long tiles = (long)gbx * gby2;
+            const long tiles = (long)gbx * trows.n;
             double best = -1.0;
             for (int cand : {1, 2, 4}) {
                 if (h->g.nz / cand < 4) break;
@@ -412,11 +442,11 @@ int do_momentum_fused(dycore *h, const Ptrs &p, const double *u_old, const doubl
             }
             if (h->mom_ks) ks = h->mom_ks;
         }
-        const dim3 gr2(8 * ((gbx * gby2 * ks + 7) / 8)), blk(FTI, tj);
+        const dim3 gr2(8 * ((gbx * trows.n * ks + 7) / 8)), blk(FTI, tj);
         const bool cur = (u_old == p.UWIND);
 #define DMA_LAUNCH(TJ_)                                                                                        \
-        if (cur) hipLaunchKernelGGL((k_momentum_dma<true, TJ_>), gr2, blk, dma_lds_bytes(TJ_), h->stream, h->g, p, gbx, gby2, ks, jv_lo, u_old, v_old, u_out, v_out, dt); \
-        else hipLaunchKernelGGL((k_momentum_dma<false, TJ_>), gr2, blk, dma_lds_bytes(TJ_), h->stream, h->g, p, gbx, gby2, ks, jv_lo, u_old, v_old, u_out, v_out, dt);
+        if (cur) hipLaunchKernelGGL((k_momentum_dma<true, TJ_>), gr2, blk, dma_lds_bytes(TJ_), h->stream, h->g, p, gbx, trows, ks, jv_lo, u_old, v_old, u_out, v_out, dt); \
+        else hipLaunchKernelGGL((k_momentum_dma<false, TJ_>), gr2, blk, dma_lds_bytes(TJ_), h->stream, h->g, p, gbx, trows, ks, jv_lo, u_old, v_old, u_out, v_out, dt);
         if (tj == 8) { DMA_LAUNCH(8) } else if (tj == 9) { DMA_LAUNCH(9) } else { DMA_LAUNCH(10) }
 #undef DMA_LAUNCH
     } else if (u_out)
@@ -515,7 +545,7 @@ int step_begin(dycore *h, int with_rho)
 {
     int rc;
     Ptrs &p = h->p;
-    if (with_rho && (rc = do_rho(h, p))) return rc;
+    if (with_rho && ((rc = join_side(h)) || (rc = do_rho(h, p)))) return rc;
     if (fused_path(h)) return do_copy(h, p.COLP_OLD, p.COLP, (size_t)h->g.plane);
     std::swap(p.UWIND, p.UWIND_OLD);
     std::swap(p.VWIND, p.VWIND_OLD);
@@ -548,22 +578,31 @@ int substep_part(dycore *h, double dt, int sub, int part)
         switch (part) {
         case 0:                     // -> UFLX, VFLX, WWIND, COLP_NEW halo rows
             return do_continuity_fused(h, q, dt);
-        case 1: {                   // momentum reads the old diagnostics, so it runs first
+        case DYCORE_PART_MOM_INNER:
+            return do_momentum_fused(h, q, p.UWIND, p.VWIND, u_out, v_out, dt, ROWS_INNER);
+        case DYCORE_PART_MOM_EDGE:  // -> new winds complete: their rows can travel while part TEMP runs
             if ((rc = join_side(h))) return rc;
-            if ((rc = do_momentum_fused(h, q, p.UWIND, p.VWIND, u_out, v_out, dt))) return rc;
+            if ((rc = do_momentum_fused(h, q, p.UWIND, p.VWIND, u_out, v_out, dt, ROWS_EDGE))) return rc;
+            return do_halo(h, {{u_out, 1, 0, h->g.nz}, {v_out, 0, 1, h->g.nz}});
+        case 1:
+        case DYCORE_PART_TEMP: {    // momentum reads the old diagnostics, so it runs first
+            if (part == 1) {
+                if ((rc = join_side(h))) return rc;
+                if ((rc = do_momentum_fused(h, q, p.UWIND, p.VWIND, u_out, v_out, dt))) return rc;
+            }
             if ((rc = do_pott_fused(h, q, p.POTT, t_out, dt))) return rc;
             double *qv_out = sub == 0 ? p.QV_EST : p.QV, *qc_out = sub == 0 ? p.QC_EST : p.QC;
             if (h->g.i_moist && (rc = do_moist(h, q, p.QV, p.QC, qv_out, qc_out, dt))) return rc;
             const int nz = h->g.nz;
             if (h->g.i_moist && (rc = do_halo(h, {{qv_out, 0, 0, nz}, {qc_out, 0, 0, nz}}))) return rc;
-            if (h->lazy)
-                rc = do_halo(h, {{u_out, 1, 0, nz}, {v_out, 0, 1, nz}, {t_out, 0, 0, nz}, {p.PVTF, 0, 0, nz},
-                                 {p.PVTFVB, 0, 0, nz + 1}, {p.PHI, 0, 0, nz}, {p.POTTVB, 0, 0, nz + 1}});
-            else
-                rc = do_halo(h, {{u_out, 1, 0, nz}, {v_out, 0, 1, nz}, {t_out, 0, 0, nz}, {p.PVTF, 0, 0, nz},
-                                 {p.PVTFVB, 0, 0, nz + 1}, {p.PHI, 0, 0, nz}, {p.PHIVB, 0, 0, nz + 1},
-                                 {p.POTTVB, 0, 0, nz + 1}});
-            if (rc) return rc;
+            std::vector<HaloSpec> hl = {{t_out, 0, 0, nz}, {p.PVTF, 0, 0, nz}, {p.PVTFVB, 0, 0, nz + 1},
+                                        {p.PHI, 0, 0, nz}, {p.POTTVB, 0, 0, nz + 1}};
+            if (!h->lazy) hl.push_back({p.PHIVB, 0, 0, nz + 1});
+            if (part == 1) {            // after MOM_EDGE the winds are done (their rows may be travelling)
+                hl.push_back({u_out, 1, 0, nz});
+                hl.push_back({v_out, 0, 1, nz});
+            }
+            if ((rc = do_halo(h, hl))) return rc;
             return do_copy(h, p.COLP, p.COLP_NEW, (size_t)h->g.plane);   // -> winds, POTT halo rows
         }
         case 2: {
@@ -575,6 +614,10 @@ int substep_part(dycore *h, double dt, int sub, int part)
         return fail(DYCORE_EINVAL, "substep part %d out of range", part);
     }
     switch (part) {
+    case DYCORE_PART_MOM_INNER:
+    case DYCORE_PART_MOM_EDGE:
+    case DYCORE_PART_TEMP:
+        return fail(DYCORE_ESTATE, "split parts need the fused step (dycore_overlap_parts)");
     case 0:                         // -> needs UFLX, VFLX, WWIND, COLP_NEW halo rows afterwards
         return do_continuity(h, q, dt);
     case 1:
@@ -660,6 +703,7 @@ int dycore_create(const DycoreConfig *cfg, dycore_t **out)
         if (e != hipSuccess) { delete h; return fail(DYCORE_EHIP, "hipStreamCreate: %s", hipGetErrorString(e)); }
         h->own_stream = true;
     }
+    h->home = h->stream;
     if (!(g.pole_s && g.pole_n)) {      // a band of a decomposed grid
         if (hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking) != hipSuccess ||
             hipEventCreateWithFlags(&h->ev_main, hipEventDisableTiming) != hipSuccess ||
@@ -721,11 +765,19 @@ int dycore_destroy(dycore_t *h)
     if (h->side) { (void)hipStreamSynchronize(h->side); (void)hipStreamDestroy(h->side); }
     if (h->ev_main) (void)hipEventDestroy(h->ev_main);
     if (h->ev_side) (void)hipEventDestroy(h->ev_side);
-    if (h->own_stream) (void)hipStreamDestroy(h->stream);
+    if (h->own_stream) (void)hipStreamDestroy(h->home);
     delete h;
     return 0;
 }
 
+int dycore_use_stream(dycore_t *h, void *stream)
+{
+    if (!h) return fail(DYCORE_EINVAL, "null handle");
+    h->stream = stream ? (hipStream_t)stream : h->home;
+    return 0;
+}
+void *dycore_get_stream(dycore_t *h) { return h ? (void *)h->home : nullptr; }
+int dycore_overlap_parts(dycore_t *h) { return h && fused_path(h) ? 1 : 0; }
 int dycore_sync(dycore_t *h)
 {
     if (!h) return fail(DYCORE_EINVAL, "null handle");

@@ -57,6 +57,12 @@ __device__ __forceinline__ bool xcd_tile(int gbx, int gby, int &bx, int &by)
     return true;
 }
 
+// Tile-row subset of a launch: launch row r (0 .. rs.n-1) is tile row rs.first + r, plus rs.gap
+// once r has reached rs.split -- one contiguous range (gap 0) or the two edge ranges of a
+// latitude band (the tile rows whose stencils touch rows received from the neighbours).
+struct RowSet { int first, n, split, gap; };
+__device__ __forceinline__ int rowset_row(const RowSet &rs, int r) { return rs.first + r + (r >= rs.split ? rs.gap : 0); }
+
 // EULER: the pressure-weighted Euler step (dyn_timestep.py:212-297, UWIND/VWIND part) is
 // applied in the same thread -- dUFLXdt/dVFLXdt never reach HBM; u_old/v_old hold the state at
 // step start (read at the own cell only), u_out/v_out receive the new winds (interior cells;
@@ -318,10 +324,11 @@ typedef __attribute__((address_space(3))) void lds_void_t;
 typedef const __attribute__((address_space(1))) void gbl_void_t;
 
 template <bool OLD_IS_CUR, int TJ>
-__global__ __launch_bounds__(FTI *TJ) void k_momentum_dma(Geo g, Ptrs p, int gbx, int gby, int ksplit, int jv_lo,
+__global__ __launch_bounds__(FTI *TJ) void k_momentum_dma(Geo g, Ptrs p, int gbx, RowSet trows, int ksplit, int jv_lo,
                                                       const double *u_old, const double *v_old,
                                                       double *u_out, double *v_out, double dt)
 {
+    const int gby = trows.n;            // tile rows of this launch (a subset of the band's, see RowSet)
     // tile geometry for TJ rows per workgroup (TJ is chosen per launch so that the number of
     // workgroups fits the 256 CUs with the least idle tail: dma_pick_tj on the host)
     constexpr int TH = TJ + 3, TN = FTW * TH, NT = FTI * TJ;          // tile rows, doubles, threads
@@ -335,7 +342,7 @@ __global__ __launch_bounds__(FTI *TJ) void k_momentum_dma(Geo g, Ptrs p, int gbx
     int bx, by;
     if (!xcd_tile(gbx, gby * ksplit, bx, by)) return;
     const int kc = by / gby;
-    by -= kc * gby;
+    by = rowset_row(trows, by - kc * gby);
     const int k0 = (int)((long long)kc * g.nz / ksplit), k1 = (int)((long long)(kc + 1) * g.nz / ksplit);
     const int tx = threadIdx.x, ty = threadIdx.y;
     const int tid = ty * FTI + tx;
@@ -956,8 +963,10 @@ __global__ __launch_bounds__(TI *TJ) void k_pott_fused(Geo g, Ptrs p, const doub
     double pvbo_kp1 = p.POTTVB[c + (size_t)nz * g.plane];        // old interface values
     double pottn_kp1 = 0.0, pvtf_kp1 = 0.0, pottvb_first = 0.0;
     // software pipeline: the inputs of level k-1 are requested before level k is computed, so the
-    // HBM latency overlaps the pow/division chain instead of preceding it (the kernel is
-    // latency-bound: 3 waves per SIMD, one dependent chain per level)
+    // HBM latency overlaps the pow/division chain instead of preceding it.  One level ahead is
+    // enough: the kernel is bound by fp64 instruction issue (~250 instructions per level, pow and
+    // five divisions), and rings of 2-4 levels in flight cost the third wave per SIMD and ran
+    // 5-15 % slower (profiles/r01_notes.md)
     struct In { double pt, im1, ip1, jm1, jp1, uf, uf1, vf, vf1, w, pvb, po; };
     auto load = [&](int k) {
         In r;

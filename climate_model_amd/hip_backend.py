@@ -35,7 +35,7 @@ ABI_SYMBOLS = [
     'dycore_primary_diag',
     'dycore_secondary_diag_rho', 'dycore_secondary_diag', 'dycore_compute_turbulence',
     'dycore_step_matsuno', 'dycore_time_steps',
-    'dycore_step_begin', 'dycore_substep_part', 'dycore_rows_size', 'dycore_pack_rows',
+    'dycore_step_begin', 'dycore_substep_part', 'dycore_use_stream', 'dycore_get_stream', 'dycore_overlap_parts', 'dycore_rows_size', 'dycore_pack_rows',
     'dycore_unpack_rows', 'dycore_substep_field',
     'dycore_profile', 'dycore_n_kernels', 'dycore_kernel_stats',
 ]
@@ -77,6 +77,10 @@ def load_library(path=None):
     lib.dycore_time_steps.argtypes = [hp, C.c_double, C.c_int32, C.c_int32, C.POINTER(C.c_double)]
     lib.dycore_step_begin.argtypes = [hp, C.c_int32]
     lib.dycore_substep_part.argtypes = [hp, C.c_double, C.c_int32, C.c_int32]
+    lib.dycore_use_stream.argtypes = [hp, C.c_void_p]
+    lib.dycore_overlap_parts.argtypes = [hp]
+    lib.dycore_get_stream.argtypes = [hp]
+    lib.dycore_get_stream.restype = C.c_void_p
     lib.dycore_substep_field.argtypes = [hp, C.c_int32, C.c_char_p]
     lib.dycore_substep_field.restype = C.c_char_p
     cpp = C.POINTER(C.c_char_p)
@@ -225,8 +229,24 @@ class HipDycore:
         with_rho = self.i_turb if with_rho is None else with_rho
         self._check(self.lib.dycore_step_begin(self._h, int(bool(with_rho))))
 
+    # pieces of part 1 (include/dycore.h) between which the neighbour exchanges are hidden
+    PART_MOM_INNER, PART_MOM_EDGE, PART_TEMP = 10, 11, 12
+
+    @property
+    def overlap_parts(self):
+        return bool(self.lib.dycore_overlap_parts(self._h))
+
     def substep_part(self, dt, substep, part):
         self._check(self.lib.dycore_substep_part(self._h, float(dt), int(substep), int(part)))
+
+    def use_stream(self, stream_ptr):
+        """Redirect subsequent launches to the HIP stream with this handle (None: back to the
+        core's own stream)."""
+        self._check(self.lib.dycore_use_stream(self._h, C.c_void_p(stream_ptr or None)))
+
+    @property
+    def stream_ptr(self):
+        return int(self.lib.dycore_get_stream(self._h) or 0)
 
     def substep_field(self, substep, name):
         r = self.lib.dycore_substep_field(self._h, int(substep), name.encode())

@@ -135,14 +135,31 @@ int dycore_step_matsuno(dycore_t *h, double dt, int32_t nsteps, int32_t with_rho
  *   dycore_substep_part(s, 1)  momentum, temperature, COLP<-COLP_NEW, Euler forward
  *                                                     -> exchange UWIND, VWIND, POTT rows
  *   dycore_substep_part(s, 2)  primary diagnostics (halo rows included)
- * for s = 0 (estimate) and 1 (final).  pack/unpack move whole rows (columns 0..nx+2, all
+ * for s = 0 (estimate) and 1 (final).  To overlap the exchanges with compute, part 1 of the fused
+ * step (dycore_overlap_parts(h) != 0) can be issued in three pieces:
+ *   DYCORE_PART_MOM_INNER  momentum tiles whose stencils stay clear of the halo rows: may run while
+ *                          the exchange after part 0 is in flight
+ *   DYCORE_PART_MOM_EDGE   the remaining momentum tiles (need those rows and the diagnostics of the
+ *                          previous part 2)      -> the new UWIND, VWIND rows can be exchanged
+ *   DYCORE_PART_TEMP       temperature (+ moisture), COLP<-COLP_NEW: does not touch the winds, so the
+ *                          wind rows travel meanwhile -> exchange POTT (QV, QC) rows, then part 2
+ * Part 0 of the next substep needs the wind rows only.
+ * dycore_use_stream redirects every subsequent launch of the handle to another HIP stream (NULL:
+ * back to the handle's own stream) so that pack/unpack and part 2 can be queued on the stream the
+ * transport runs on; ordering between the streams is the caller's (events).
+ * pack/unpack move whole rows (columns 0..nx+2, all
  * levels) of the named fields between the field buffers and one contiguous device buffer,
  * entry e at offset sum_{e'<e} levels(e')*(nx+3) doubles. */
 int dycore_step_begin(dycore_t *h, int32_t with_rho);
 /* name of the registered field that holds `name` (UWIND, VWIND or POTT) right after part 1 of
  * the given substep: the fused step writes the predictor state into *_EST scratch fields */
 const char *dycore_substep_field(dycore_t *h, int32_t substep, const char *name);
+enum { DYCORE_PART_MOM_INNER = 10, DYCORE_PART_MOM_EDGE = 11, DYCORE_PART_TEMP = 12 };
+int dycore_overlap_parts(dycore_t *h);
 int dycore_substep_part(dycore_t *h, double dt, int32_t substep, int32_t part);
+int dycore_use_stream(dycore_t *h, void *stream);
+/* the handle's own stream (DycoreConfig.stream, or the one the library created) */
+void *dycore_get_stream(dycore_t *h);
 int dycore_rows_size(dycore_t *h, int32_t n, const char *const *names, int64_t *n_doubles);
 int dycore_pack_rows(dycore_t *h, int32_t n, const char *const *names, const int32_t *rows,
                      void *dev_buf);

@@ -28,7 +28,7 @@ for nb in [1, 2, 4, 8]:
             c.upload(n, L.slice_rows(F.host[n], r, FIELD_TABLE[n][1]))
         c.primary_diag()
         cores.append(c)
-    lb = LocalBands(cores, L, torch.device('cuda:0'))
+    lb = LocalBands(cores, L, torch.device('cuda:0'), overlap=bool(int(os.environ.get('OVERLAP', '1'))))
     lb.step_matsuno(GR.dt, 1)
     for c in cores: c.profile(True)
     lb.step_matsuno(GR.dt, steps)
@@ -36,9 +36,13 @@ for nb in [1, 2, 4, 8]:
     for c in cores:
         for k, (n, ms) in c.kernel_stats().items():
             if n: tot[k] = tot.get(k, 0.) + ms
+    for c in cores: c.profile(False)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    lb.step_matsuno(GR.dt, steps)
+    torch.cuda.synchronize(); wall = (time.perf_counter() - t0) / steps / nb * 1e3
     per_gpu = sum(tot.values()) / nb / steps
     if base is None: base = per_gpu
-    print('bands=%d  kernel ms/step per band: %.3f   compute-only speedup %.2fx (eff %.0f%%)  | %s' % (
-        nb, per_gpu, base / per_gpu, 100 * base / per_gpu / nb,
+    print('bands=%d  wall %.3f ms/band-step  kernel ms/step per band: %.3f   compute-only speedup %.2fx (eff %.0f%%)  | %s' % (
+        nb, wall, per_gpu, base / per_gpu, 100 * base / per_gpu / nb,
         '  '.join('%s=%.3f' % (k.replace('k_', ''), v / nb / steps) for k, v in tot.items() if v / nb / steps > 0.005)), flush=True)
     for c in cores: c.close()

@@ -59,23 +59,29 @@ def _single(GR, state, i_turb, nsteps, i_moist=0, check=None):
     return out
 
 
+@pytest.mark.parametrize('overlap', [False, True])
 @pytest.mark.parametrize('nbands', [2, 3, 5])
 @pytest.mark.parametrize('i_turb,i_moist', [(0, 0), (1, 0), (0, 1), (1, 1)])
-def test_local_bands_bitwise_equal_single(nbands, i_turb, i_moist):
+def test_local_bands_bitwise_equal_single(nbands, i_turb, i_moist, overlap):
+    """overlap=True: the exchanges run on a second stream behind the inner rows (the schedule of
+    the multi-GPU run); overlap=False: plain part / exchange sequence with host synchronisation."""
     import torch
+    stream = torch.cuda.Stream()
     GR, state = _initial_state(4, 8, i_turb, i_moist)
     check = CHECK + (['QV', 'QC'] if i_moist else [])
     ref = _single(GR, state, i_turb, 3, i_moist, check)
     L = BandLayout(GR.ny, nbands)
     cores = []
     for r in range(nbands):
-        c = HipDycore(GR.nx, L.ny(r), GR.nz, i_turb=i_turb, ny_global=GR.ny, j_offset=L.j_offset(r), i_moist=i_moist)
+        c = HipDycore(GR.nx, L.ny(r), GR.nz, i_turb=i_turb, ny_global=GR.ny, j_offset=L.j_offset(r), i_moist=i_moist,
+                      stream=stream.cuda_stream)
         c.set_grid(band_grid_arrays(GR.GRF['HIP'], L, r))
         for n, a in state.items():
             c.upload(n, L.slice_rows(a, r, FIELD_TABLE[n][1]))
         c.primary_diag()
         cores.append(c)
-    lb = LocalBands(cores, L, torch.device('cuda:0'))
+    lb = LocalBands(cores, L, torch.device('cuda:0'), overlap=overlap)
+    assert lb.overlap == (overlap and not i_turb)     # the staged (turbulence-coupled) step is not split
     lb.step_matsuno(GR.dt, 3)
     for n in check:
         got = gather_global(L, [c.download(n) for c in cores], n)

@@ -92,8 +92,9 @@ def test_bands_equal_single_full_size(d, nz, nbands):
     ref = _run_hip(GR, state, 2)
     L = BandLayout(GR.ny, nbands)
     cores = []
+    stream = torch.cuda.Stream()
     for r in range(nbands):
-        c = HipDycore(GR.nx, L.ny(r), GR.nz, ny_global=GR.ny, j_offset=L.j_offset(r))
+        c = HipDycore(GR.nx, L.ny(r), GR.nz, ny_global=GR.ny, j_offset=L.j_offset(r), stream=stream.cuda_stream)
         c.set_grid(band_grid_arrays(GR.GRF['HIP'], L, r))
         for n, a in state.items():
             c.upload(n, L.slice_rows(a, r, FIELD_TABLE[n][1]))

@@ -126,6 +126,7 @@ struct dycore {
     bool stale_flxdiv = false, stale_phivb = false;
     int n_cu = 256;                 // compute units of the device
     int mom_tj = 0;                 // DYCORE_MOM_TJ: force the rows per momentum workgroup (8, 9, 10)
+    int cell_lin = -1;              // DYCORE_CELL_LINEAR: force the 1-D (1) / 2-D (0) launch of the column kernels
     int mom_ks = 0;                 // DYCORE_MOM_KS: force the level chunks per momentum tile (1, 2, 4)
     int mom_dma = 1;                // momentum kernel: 1 = LDS-DMA (default); 2 = LDS-DMA, role-split; 0 = register-staged tiles (DYCORE_MOM_DMA)
     // profiler
@@ -183,6 +184,13 @@ struct Scope {          // brackets one launch with events when profiling is on
 };
 
 dim3 grid_for(const Geo &g, int ni, int nj) { return dim3((ni + TI - 1) / TI, (nj + TJ - 1) / TJ, 1); }
+// launch geometry of the column kernels over the owned cells: see owned_cell (kernels_stage.h)
+int cells_linear(const dycore *h) { return h->cell_lin >= 0 ? h->cell_lin : (h->g.nx % 32 == 0); }
+dim3 grid_cells(const dycore *h)
+{
+    if (cells_linear(h)) return dim3((unsigned)(((long long)h->g.nx * h->g.ny + TI * TJ - 1) / (TI * TJ)));
+    return grid_for(h->g, h->g.nx, h->g.ny);
+}
 
 int check_ready(dycore *h)
 {
@@ -343,12 +351,13 @@ int do_continuity_fused(dycore *h, const Ptrs &p, double dt)
     if (!h->lazy || !(nz == 8 || nz == 16 || nz == 32 || nz == 64)) return do_continuity(h, p, dt);
     {
         Scope s(h, K_CONT_REG);
-        const dim3 gr = grid_for(h->g, h->g.nx, h->g.ny), bl(TI, TJ);
+        const dim3 gr = grid_cells(h), bl(TI, TJ);
+        const int lin = cells_linear(h);
         switch (nz) {
-        case 8: hipLaunchKernelGGL(k_continuity_reg<8>, gr, bl, 0, h->stream, h->g, p, dt); break;
-        case 16: hipLaunchKernelGGL(k_continuity_reg<16>, gr, bl, 0, h->stream, h->g, p, dt); break;
-        case 32: hipLaunchKernelGGL(k_continuity_reg<32>, gr, bl, 0, h->stream, h->g, p, dt); break;
-        default: hipLaunchKernelGGL(k_continuity_reg<64>, gr, bl, 0, h->stream, h->g, p, dt); break;
+        case 8: hipLaunchKernelGGL(k_continuity_reg<8>, gr, bl, 0, h->stream, h->g, p, dt, lin); break;
+        case 16: hipLaunchKernelGGL(k_continuity_reg<16>, gr, bl, 0, h->stream, h->g, p, dt, lin); break;
+        case 32: hipLaunchKernelGGL(k_continuity_reg<32>, gr, bl, 0, h->stream, h->g, p, dt, lin); break;
+        default: hipLaunchKernelGGL(k_continuity_reg<64>, gr, bl, 0, h->stream, h->g, p, dt, lin); break;
         }
         int rc = launch_check("k_continuity_reg");
         if (rc) return rc;
@@ -459,23 +468,24 @@ int do_pott_fused(dycore *h, const Ptrs &p, const double *pott_old, double *pott
 {
     Scope s(h, K_POTT_FUSED);
     if (h->lazy) {
-        hipLaunchKernelGGL(k_pott_fused<false>, grid_for(h->g, h->g.nx, h->g.ny), dim3(TI, TJ), 0, h->stream, h->g, p, pott_old, pott_out, dt);
+        hipLaunchKernelGGL(k_pott_fused<false>, grid_cells(h), dim3(TI, TJ), 0, h->stream, h->g, p, pott_old, pott_out, dt, cells_linear(h));
         h->stale_phivb = true;
     } else
-        hipLaunchKernelGGL(k_pott_fused<true>, grid_for(h->g, h->g.nx, h->g.ny), dim3(TI, TJ), 0, h->stream, h->g, p, pott_old, pott_out, dt);
+        hipLaunchKernelGGL(k_pott_fused<true>, grid_cells(h), dim3(TI, TJ), 0, h->stream, h->g, p, pott_old, pott_out, dt, cells_linear(h));
     return launch_check("k_pott_fused");
 }
 // dQVdt, dQCdt (stage) or the new QV, QC directly (fused): dyn_moist.py
 int do_moist(dycore *h, const Ptrs &p, const double *qv_old, const double *qc_old, double *qv_out, double *qc_out, double dt)
 {
     Scope s(h, K_MOIST);
-    const dim3 gr = grid_for(h->g, h->g.nx, h->g.ny), bl(TI, TJ);
+    const dim3 gr = grid_cells(h), bl(TI, TJ);
+    const int lin = cells_linear(h);
     if (qv_out) {
-        if (h->g.i_turb) hipLaunchKernelGGL((k_moist<true, true>), gr, bl, 0, h->stream, h->g, p, qv_old, qc_old, qv_out, qc_out, dt);
-        else hipLaunchKernelGGL((k_moist<false, true>), gr, bl, 0, h->stream, h->g, p, qv_old, qc_old, qv_out, qc_out, dt);
+        if (h->g.i_turb) hipLaunchKernelGGL((k_moist<true, true>), gr, bl, 0, h->stream, h->g, p, qv_old, qc_old, qv_out, qc_out, dt, lin);
+        else hipLaunchKernelGGL((k_moist<false, true>), gr, bl, 0, h->stream, h->g, p, qv_old, qc_old, qv_out, qc_out, dt, lin);
     } else {
-        if (h->g.i_turb) hipLaunchKernelGGL((k_moist<true, false>), gr, bl, 0, h->stream, h->g, p, qv_old, qc_old, qv_out, qc_out, dt);
-        else hipLaunchKernelGGL((k_moist<false, false>), gr, bl, 0, h->stream, h->g, p, qv_old, qc_old, qv_out, qc_out, dt);
+        if (h->g.i_turb) hipLaunchKernelGGL((k_moist<true, false>), gr, bl, 0, h->stream, h->g, p, qv_old, qc_old, qv_out, qc_out, dt, lin);
+        else hipLaunchKernelGGL((k_moist<false, false>), gr, bl, 0, h->stream, h->g, p, qv_old, qc_old, qv_out, qc_out, dt, lin);
     }
     return launch_check("k_moist");
 }
@@ -682,6 +692,7 @@ int dycore_create(const DycoreConfig *cfg, dycore_t **out)
     if (const char *e = getenv("DYCORE_LAZY")) h->lazy = atoi(e) != 0;
     if (const char *e = getenv("DYCORE_MOM_TJ")) h->mom_tj = atoi(e);
     if (const char *e = getenv("DYCORE_MOM_KS")) h->mom_ks = atoi(e);
+    if (const char *e = getenv("DYCORE_CELL_LINEAR")) h->cell_lin = atoi(e);
     {
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, cfg->device) == hipSuccess && prop.multiProcessorCount > 0) h->n_cu = prop.multiProcessorCount;

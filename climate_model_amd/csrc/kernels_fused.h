@@ -862,10 +862,10 @@ __global__ __launch_bounds__(2 * FNT) void k_momentum_split(Geo g, Ptrs p, int g
 // makes no round trip through HBM: 2 reads + 3 writes per cell, the compulsory minimum of
 // this stage.  FLXDIV itself is not stored (k_derive_flxdiv re-derives it on demand).
 template <int NZ>
-__global__ __launch_bounds__(TI *TJ) void k_continuity_reg(Geo g, Ptrs p, double dt)
+__global__ __launch_bounds__(TI *TJ) void k_continuity_reg(Geo g, Ptrs p, double dt, int lin)
 {
-    DYC_IJ(1, 1)
-    if (i > g.nx || j > g.ny) return;
+    int i, j;
+    if (!owned_cell(g, lin, i, j)) return;
     const size_t c = at2(g, i, j);
     const double colp = p.COLP[c];
     const double c_im1 = p.COLP[c - 1], c_ip1 = p.COLP[c + 1];
@@ -941,10 +941,10 @@ __global__ __launch_bounds__(TI *TJ) void k_derive_phivb(Geo g, Ptrs p)
 // value has been consumed by the vertical advection of levels k+1 and k.
 // Dry dycore only (the turbulence-coupled path uses the stage kernels).
 template <bool WRITE_PHIVB>
-__global__ __launch_bounds__(TI *TJ) void k_pott_fused(Geo g, Ptrs p, const double *pott_old, double *pott_out, double dt)
+__global__ __launch_bounds__(TI *TJ) void k_pott_fused(Geo g, Ptrs p, const double *pott_old, double *pott_out, double dt, int lin)
 {
-    DYC_IJ(1, 1)
-    if (i > g.nx || j > g.ny) return;
+    int i, j;
+    if (!owned_cell(g, lin, i, j)) return;
     const int P = g.P, nz = g.nz;
     const size_t c = at2(g, i, j);
     const double colp = p.COLP[c], cnew = p.COLP_NEW[c], cold = p.COLP_OLD[c];

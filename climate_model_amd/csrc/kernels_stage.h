@@ -27,6 +27,27 @@ constexpr int TJ = DYC_TJ;   // rows per workgroup
     const int i = blockIdx.x * TI + threadIdx.x + (i0);  \
     const int j = blockIdx.y * TJ + threadIdx.y + (j0);
 
+// Thread -> owned cell (i in [1,nx], j in [1,ny]) of the column kernels of the fused step.
+// lin = 0: 2-D launch of TI x TJ tiles.  lin != 0: 1-D launch over the nx*ny columns in row-major
+// order -- no idle lanes at the row ends, so a latitude band of 1440 x 90 columns is 507
+// workgroups instead of 540 and fits two per CU on 256 CUs (these kernels hold three and are
+// bound by instruction issue: a CU with a third workgroup sets the kernel time).  Used when nx
+// is a multiple of 32, so that a wavefront's row segment still starts on a 256-B boundary.
+__device__ __forceinline__ bool owned_cell(const Geo &g, int lin, int &i, int &j)
+{
+    if (lin) {
+        const long long t = (long long)blockIdx.x * (TI * TJ) + threadIdx.y * TI + threadIdx.x;
+        if (t >= (long long)g.nx * g.ny) return false;
+        j = (int)(t / g.nx);
+        i = (int)(t - (long long)j * g.nx) + 1;
+        j += 1;
+        return true;
+    }
+    i = blockIdx.x * TI + threadIdx.x + 1;
+    j = blockIdx.y * TJ + threadIdx.y + 1;
+    return i <= g.nx && j <= g.ny;
+}
+
 // ------------------------------------------------------------------------------------
 // continuity: dyn_continuity.py:170-232.  Owned cells i in [1,nx], j in [1,ny]; the lateral
 // halo of UFLX, VFLX, WWIND, COLP_NEW (dyn_org_discretizations.py:107-117) is refreshed by
@@ -482,10 +503,10 @@ __device__ __forceinline__ double turb_flux(double phi, double phi_kp1, double p
 // reference, multiplied by WWIND[nz] = 0: taken as 0 here.
 template <bool TURB, bool EULER>
 __global__ __launch_bounds__(TI *TJ) void k_moist(Geo g, Ptrs p, const double *qv_old, const double *qc_old,
-                                                  double *qv_out, double *qc_out, double dt)
+                                                  double *qv_out, double *qc_out, double dt, int lin)
 {
-    DYC_IJ(1, 1)
-    if (i > g.nx || j > g.ny) return;
+    int i, j;
+    if (!owned_cell(g, lin, i, j)) return;
     const int P = g.P, nz = g.nz;
     const size_t c = at2(g, i, j);
     const double colp = p.COLP[c], colp_new = p.COLP_NEW[c], colp_old = p.COLP_OLD[c];

@@ -309,3 +309,24 @@ def test_solver_loop_matches_oracle_and_reports():
     core.upload('UWIND', bad)
     with pytest.raises(ValueError, match='MODEL CRASH'):
         solver.print_ts_info(GR, F, 1, out=lambda s: None)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('case,i_moist', [('g4x8_dry', 0), ('g4x8_dry', 1), ('g10x4_dry', 1)])
+def test_linear_cell_launch_bitwise(case, i_moist, monkeypatch):
+    """The column kernels of the fused step (continuity, temperature, moisture) launch either as 2-D
+    tiles or 1-D over the owned cells (chosen by nx % 32): same arithmetic per cell, so bitwise equal."""
+    z = load_golden(case)
+    out = []
+    for lin in ('0', '1'):
+        monkeypatch.setenv('DYCORE_CELL_LINEAR', lin)
+        GR = grid_from_golden(z, i_moist=i_moist)
+        core = make_core(GR, i_moist=i_moist)
+        F = fields_from(GR, core, fields_of(z, 'ic'))
+        core.primary_diag()
+        core.step_matsuno(GR.dt, 3)
+        names = ['COLP', 'UWIND', 'VWIND', 'POTT', 'WWIND', 'PHI', 'POTTVB'] + (['QV', 'QC'] if i_moist else [])
+        out.append({n: core.download(n) for n in names})
+        core.close()
+    for n in out[0]:
+        np.testing.assert_array_equal(out[0][n], out[1][n], err_msg=n)

@@ -126,7 +126,7 @@ struct dycore {
     bool stale_flxdiv = false, stale_phivb = false;
     int n_cu = 256;                 // compute units of the device
     int mom_tj = 0;                 // DYCORE_MOM_TJ: force the rows per momentum workgroup (8, 9, 10)
-    int cell_lin = -1;              // DYCORE_CELL_LINEAR: force the 1-D (1) / 2-D (0) launch of the column kernels
+    int cell_lin = -1;              // DYCORE_CELL_LINEAR: column-kernel launch, bit 0 = cell runs, bit 1 = XCD-aware order (default 3 or 2)
     int mom_ks = 0;                 // DYCORE_MOM_KS: force the level chunks per momentum tile (1, 2, 4)
     int mom_dma = 1;                // momentum kernel: 1 = LDS-DMA (default); 2 = LDS-DMA, role-split; 0 = register-staged tiles (DYCORE_MOM_DMA)
     // profiler
@@ -185,11 +185,13 @@ struct Scope {          // brackets one launch with events when profiling is on
 
 dim3 grid_for(const Geo &g, int ni, int nj) { return dim3((ni + TI - 1) / TI, (nj + TJ - 1) / TJ, 1); }
 // launch geometry of the column kernels over the owned cells: see owned_cell (kernels_stage.h)
-int cells_linear(const dycore *h) { return h->cell_lin >= 0 ? h->cell_lin : (h->g.nx % 32 == 0); }
+int cells_linear(const dycore *h) { return h->cell_lin >= 0 ? h->cell_lin : ((h->g.nx % 32 == 0) ? 3 : 2); }
 dim3 grid_cells(const dycore *h)
 {
-    if (cells_linear(h)) return dim3((unsigned)(((long long)h->g.nx * h->g.ny + TI * TJ - 1) / (TI * TJ)));
-    return grid_for(h->g, h->g.nx, h->g.ny);
+    long long n;
+    if (cells_linear(h) & 1) n = ((long long)h->g.nx * h->g.ny + TI * TJ - 1) / (TI * TJ);
+    else n = (long long)((h->g.nx + TI - 1) / TI) * ((h->g.ny + TJ - 1) / TJ);
+    return dim3((unsigned)(8 * ((n + 7) / 8)));
 }
 
 int check_ready(dycore *h)

@@ -27,24 +27,33 @@ constexpr int TJ = DYC_TJ;   // rows per workgroup
     const int i = blockIdx.x * TI + threadIdx.x + (i0);  \
     const int j = blockIdx.y * TJ + threadIdx.y + (j0);
 
-// Thread -> owned cell (i in [1,nx], j in [1,ny]) of the column kernels of the fused step.
-// lin = 0: 2-D launch of TI x TJ tiles.  lin != 0: 1-D launch over the nx*ny columns in row-major
-// order -- no idle lanes at the row ends, so a latitude band of 1440 x 90 columns is 507
-// workgroups instead of 540 and fits two per CU on 256 CUs (these kernels hold three and are
-// bound by instruction issue: a CU with a third workgroup sets the kernel time).  Used when nx
-// is a multiple of 32, so that a wavefront's row segment still starts on a 256-B boundary.
+// Thread -> owned cell (i in [1,nx], j in [1,ny]) of the column kernels of the fused step
+// (1-D launch of 8*ceil(n/8) workgroups of TI x TJ threads, n from cells_blocks()).
+//  * XCD-aware order: hardware deals workgroup b to XCD b % 8; every XCD gets a contiguous run of
+//    the row-major block order, so the rows j-1 / j+1 a workgroup reads beyond its own are the
+//    ones its neighbours on the SAME XCD (same L2) fetch at about the same time.  Dealt round-robin
+//    those neighbours always sit on other XCDs and POTT / VFLX come from HBM two to three times.
+//  * lin = 0: blocks are TI x TJ tiles.  lin != 0: blocks are runs of TI*TJ cells of the row-major
+//    cell order -- no idle lanes at the row ends, so a latitude band of 1440 x 90 columns is 507
+//    workgroups instead of 540 and fits two per CU on 256 CUs.  Used when nx is a multiple of 32,
+//    so that a wavefront's row segment still starts on a 256-B boundary.
+// lin: bit 0 = cell runs instead of tiles, bit 1 = XCD-aware block order
 __device__ __forceinline__ bool owned_cell(const Geo &g, int lin, int &i, int &j)
 {
-    if (lin) {
-        const long long t = (long long)blockIdx.x * (TI * TJ) + threadIdx.y * TI + threadIdx.x;
+    const int chunk = gridDim.x / 8;
+    const int b = (lin & 2) ? (blockIdx.x % 8) * chunk + blockIdx.x / 8 : blockIdx.x;
+    if (lin & 1) {
+        const long long t = (long long)b * (TI * TJ) + threadIdx.y * TI + threadIdx.x;
         if (t >= (long long)g.nx * g.ny) return false;
         j = (int)(t / g.nx);
         i = (int)(t - (long long)j * g.nx) + 1;
         j += 1;
         return true;
     }
-    i = blockIdx.x * TI + threadIdx.x + 1;
-    j = blockIdx.y * TJ + threadIdx.y + 1;
+    const int gbx = (g.nx + TI - 1) / TI;
+    const int by = b / gbx, bx = b - by * gbx;
+    i = bx * TI + threadIdx.x + 1;
+    j = by * TJ + threadIdx.y + 1;
     return i <= g.nx && j <= g.ny;
 }
 

@@ -318,7 +318,7 @@ def test_linear_cell_launch_bitwise(case, i_moist, monkeypatch):
     tiles or 1-D over the owned cells (chosen by nx % 32): same arithmetic per cell, so bitwise equal."""
     z = load_golden(case)
     out = []
-    for lin in ('0', '1'):
+    for lin in ('0', '1', '2', '3'):
         monkeypatch.setenv('DYCORE_CELL_LINEAR', lin)
         GR = grid_from_golden(z, i_moist=i_moist)
         core = make_core(GR, i_moist=i_moist)
@@ -328,5 +328,6 @@ def test_linear_cell_launch_bitwise(case, i_moist, monkeypatch):
         names = ['COLP', 'UWIND', 'VWIND', 'POTT', 'WWIND', 'PHI', 'POTTVB'] + (['QV', 'QC'] if i_moist else [])
         out.append({n: core.download(n) for n in names})
         core.close()
-    for n in out[0]:
-        np.testing.assert_array_equal(out[0][n], out[1][n], err_msg=n)
+    for o in out[1:]:
+        for n in out[0]:
+            np.testing.assert_array_equal(out[0][n], o[n], err_msg=n)

@@ -122,3 +122,14 @@ def test_bench_two_ranks_rehearsal():
     j = json.loads(line)
     assert j['n_gpus'] == 2 and j['steps'] == 3 and j['value'] > 0 and j['scaling'] == 'strong'
     assert j['roofline'] and j['roofline']['frac'] > 0
+
+
+def test_rccl_transport_self_exchange():
+    """nccl (= RCCL) send/recv of the packed band buffers on the comm stream, one rank sending to itself
+    (tests/nccl_self_worker.py)."""
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
+               RANK='0', WORLD_SIZE='1', LOCAL_RANK='0')
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'tests', 'nccl_self_worker.py')], env=env, cwd=ROOT,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and 'NCCL_SELF_OK' in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]

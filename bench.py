@@ -39,6 +39,7 @@ KERNEL_PASSES = {
     'k_pott_tendency': 6, 'k_euler_forward': 9, 'k_primary_diag': 5, 'k_diag_rho': 6,
     'k_momentum_fused': 12.0,    # R UFLX,VFLX,UWIND,VWIND,WWIND,PHI,POTT,PVTF,PVTFVB (+2 old) W UWIND,VWIND
     'k_pott_fused': 10.5,        # R POTT,UFLX,VFLX,WWIND,POTTVB (+1 old) W POTT,PVTF,PVTFVB,PHI,POTTVB
+    'k_moist': 8.0,              # R QV,QC,UFLX,VFLX,WWIND (+2 old) W QV,QC
 }
 
 
@@ -49,6 +50,7 @@ def parse():
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--dlat', type=float, default=0.25, help='grid spacing in degrees (workload)')
     ap.add_argument('--nz', type=int, default=64)
+    ap.add_argument('--moist', action='store_true', help='also advect QV/QC (dyn_moist; BASELINE config 5 without radiation); not the headline workload')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-seconds', type=float, default=15.0, help='CPU baseline budget')
     return ap.parse_args()
@@ -123,7 +125,7 @@ def main():
     from climate_model_amd import Namelist, Grid, ModelFields, HipDycore
     from climate_model_amd.bands import BandLayout, DistributedBands, band_grid_arrays
     from climate_model_amd.fields import FIELD_TABLE
-    from climate_model_amd.synthetic import initialize_fields
+    from climate_model_amd.synthetic import initialize_fields, initialize_moisture
 
     # rehearsal switches (tests only): all ranks on one GPU, gloo instead of RCCL
     backend = os.environ.get('DYCORE_BANDS_BACKEND', 'nccl')
@@ -144,9 +146,12 @@ def main():
     F = ModelFields(GR)
     initialize_fields(GR, F)        # index-hash noise: identical on every rank
     names = ['HSURF', 'COLP', 'UWIND', 'VWIND', 'POTT', 'WWIND', 'POTTVB']
+    if args.moist:
+        initialize_moisture(GR, F)
+        names += ['QV', 'QC', 'SLHFLX']
     state = {n: F.host[n] for n in names}
     core = HipDycore(GR.nx, L.ny(rank), GR.nz, pair_top=GR.nl.pair_top, device=local_rank,
-                     ny_global=GR.ny, j_offset=L.j_offset(rank), stream=stream.cuda_stream)
+                     ny_global=GR.ny, j_offset=L.j_offset(rank), stream=stream.cuda_stream, i_moist=int(args.moist))
     core.set_grid(band_grid_arrays(GR.GRF['HIP'], L, rank))
     for n in names:
         core.upload(n, L.slice_rows(state[n], rank, FIELD_TABLE[n][1]))
@@ -245,12 +250,12 @@ def main():
         'value': value, 'unit': 'cell-updates/s', 'n_gpus': world, 'steps': args.steps,
         'warmup': args.warmup, 'ms_per_step': ms_per_step, 'higher_is_better': True,
         'scaling': 'strong', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
-        'config': {'workload': 'dry hydrostatic dycore, Matsuno step, %g deg lat-lon (%d x %d) x %d sigma levels, '
+        'config': {'workload': ('moist (QV, QC advected) ' if args.moist else 'dry ') + 'hydrostatic dycore, Matsuno step, %g deg lat-lon (%d x %d) x %d sigma levels, '
                                'dt=%.4g s' % (args.dlat, GR.nx, GR.ny, GR.nz, GR.dt),
                    'cells': cells, 'parallelism': 'latitude bands x%d' % world if world > 1 else 'single GPU'},
         'roofline': roof,
     }
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.moist:
         core.close()
         try:
             line['cpu_baseline'] = cpu_baseline(GR, state, args.cpu_seconds)

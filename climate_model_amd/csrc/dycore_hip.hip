@@ -125,10 +125,9 @@ struct dycore {
     bool lazy = true;               // fused step leaves FLXDIV / PHIVB to be derived on demand (DYCORE_LAZY=0: store them)
     bool stale_flxdiv = false, stale_phivb = false;
     int n_cu = 256;                 // compute units of the device
-    int mom_tj = 0;                 // DYCORE_MOM_TJ: force the rows per momentum workgroup (8, 9, 10)
     int cell_lin = -1;              // DYCORE_CELL_LINEAR: column-kernel launch, bit 0 = cell runs, bit 1 = XCD-aware order (default 3 or 2)
     int mom_ks = 0;                 // DYCORE_MOM_KS: force the level chunks per momentum tile (1, 2, 4)
-    int mom_dma = 1;                // momentum kernel: 1 = LDS-DMA (default); 2 = LDS-DMA, role-split; 0 = register-staged tiles (DYCORE_MOM_DMA)
+    int mom_dma = 1;                // momentum kernel: 1 = LDS-DMA (default); 0 = register-staged tiles (DYCORE_MOM_DMA)
     // profiler
     bool prof = false;
     std::vector<ProfRec> recs;
@@ -418,19 +417,12 @@ int do_momentum_fused(dycore *h, const Ptrs &p, const double *u_old, const doubl
     const int nblk = gbx * gby;
     const dim3 gr(8 * ((nblk + 7) / 8)), bl(FTI, FTJ);
     const int jv_lo = h->g.pole_s ? 2 : 1;
-    if (u_out && h->mom_dma == 2 && h->g.nz <= DMAXZ) {
-        const dim3 bl2(FTI, FTJ, 2);
-        if (u_old == p.UWIND)
-            hipLaunchKernelGGL(k_momentum_split<true>, gr, bl2, DMA_LDS_BYTES, h->stream, h->g, p, gbx, gby, jv_lo, u_old, v_old, u_out, v_out, dt);
-        else
-            hipLaunchKernelGGL(k_momentum_split<false>, gr, bl2, DMA_LDS_BYTES, h->stream, h->g, p, gbx, gby, jv_lo, u_old, v_old, u_out, v_out, dt);
-    } else if (dma) {
+    if (dma) {
         // rows per workgroup: 8 (8 wavefronts = 2 per SIMD, up to 256 VGPRs each).  Taller tiles
-        // (9, 10 rows: fewer halo rows, better fit of 90-row bands on 256 CUs) are compiled in for
-        // experiments (DYCORE_MOM_TJ) but need a third wavefront on one SIMD, which caps the
-        // kernel at 168 VGPRs and made it 2x slower on MI355X (profiles/r01_notes.md).
-        int tj = 8;
-        if (h->mom_tj) tj = h->mom_tj;
+        // (9, 10 rows: fewer halo rows, better fit of 90-row bands on 256 CUs) need a third
+        // wavefront on one SIMD, which caps the kernel at 168 VGPRs: 2x slower on MI355X
+        // (profiles/r01_notes.md).
+        constexpr int tj = FTJ;
         const int gby2 = (h->g.ny + tj - 1) / tj;
         // level chunks per tile: with one workgroup per CU, `tiles` workgroups of 64 levels take
         // ceil(tiles / CUs) rounds; ks chunks take ceil(tiles*ks / CUs) rounds of (64/ks + 1)
@@ -455,11 +447,8 @@ int do_momentum_fused(dycore *h, const Ptrs &p, const double *u_old, const doubl
         }
         const dim3 gr2(8 * ((gbx * trows.n * ks + 7) / 8)), blk(FTI, tj);
         const bool cur = (u_old == p.UWIND);
-#define DMA_LAUNCH(TJ_)                                                                                        \
-        if (cur) hipLaunchKernelGGL((k_momentum_dma<true, TJ_>), gr2, blk, dma_lds_bytes(TJ_), h->stream, h->g, p, gbx, trows, ks, jv_lo, u_old, v_old, u_out, v_out, dt); \
-        else hipLaunchKernelGGL((k_momentum_dma<false, TJ_>), gr2, blk, dma_lds_bytes(TJ_), h->stream, h->g, p, gbx, trows, ks, jv_lo, u_old, v_old, u_out, v_out, dt);
-        if (tj == 8) { DMA_LAUNCH(8) } else if (tj == 9) { DMA_LAUNCH(9) } else { DMA_LAUNCH(10) }
-#undef DMA_LAUNCH
+        if (cur) hipLaunchKernelGGL((k_momentum_dma<true, tj>), gr2, blk, dma_lds_bytes(tj), h->stream, h->g, p, gbx, trows, ks, jv_lo, u_old, v_old, u_out, v_out, dt);
+        else hipLaunchKernelGGL((k_momentum_dma<false, tj>), gr2, blk, dma_lds_bytes(tj), h->stream, h->g, p, gbx, trows, ks, jv_lo, u_old, v_old, u_out, v_out, dt);
     } else if (u_out)
         hipLaunchKernelGGL(k_momentum_fused<true>, gr, bl, 0, h->stream, h->g, p, gbx, gby, jv_lo, u_old, v_old, u_out, v_out, dt);
     else
@@ -692,7 +681,6 @@ int dycore_create(const DycoreConfig *cfg, dycore_t **out)
     if (const char *e = getenv("DYCORE_FUSED")) h->fused = atoi(e) != 0;
     if (const char *e = getenv("DYCORE_MOM_DMA")) h->mom_dma = atoi(e);
     if (const char *e = getenv("DYCORE_LAZY")) h->lazy = atoi(e) != 0;
-    if (const char *e = getenv("DYCORE_MOM_TJ")) h->mom_tj = atoi(e);
     if (const char *e = getenv("DYCORE_MOM_KS")) h->mom_ks = atoi(e);
     if (const char *e = getenv("DYCORE_CELL_LINEAR")) h->cell_lin = atoi(e);
     {
@@ -700,15 +688,9 @@ int dycore_create(const DycoreConfig *cfg, dycore_t **out)
         if (hipGetDeviceProperties(&prop, cfg->device) == hipSuccess && prop.multiProcessorCount > 0) h->n_cu = prop.multiProcessorCount;
     }
     {   // the LDS-DMA kernel double-buffers 122 KB of tiles: raise the dynamic-LDS limit once
-        hipError_t e1 = hipSuccess, e2 = hipSuccess;
-#define DMA_ATTR(TJ_)                                                                                                                                  \
-        if (e1 == hipSuccess) e1 = hipFuncSetAttribute((const void *)k_momentum_dma<true, TJ_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dma_lds_bytes(TJ_)); \
-        if (e2 == hipSuccess) e2 = hipFuncSetAttribute((const void *)k_momentum_dma<false, TJ_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dma_lds_bytes(TJ_));
-        DMA_ATTR(8) DMA_ATTR(9) DMA_ATTR(10)
-#undef DMA_ATTR
-        hipError_t e3 = hipFuncSetAttribute((const void *)k_momentum_split<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)DMA_LDS_BYTES);
-        hipError_t e4 = hipFuncSetAttribute((const void *)k_momentum_split<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)DMA_LDS_BYTES);
-        if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess || e4 != hipSuccess) { (void)hipGetLastError(); h->mom_dma = 0; }
+        hipError_t e1 = hipFuncSetAttribute((const void *)k_momentum_dma<true, FTJ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dma_lds_bytes(FTJ));
+        hipError_t e2 = hipFuncSetAttribute((const void *)k_momentum_dma<false, FTJ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dma_lds_bytes(FTJ));
+        if (e1 != hipSuccess || e2 != hipSuccess) { (void)hipGetLastError(); h->mom_dma = 0; }
     }
     if (cfg->stream) h->stream = (hipStream_t)cfg->stream;
     else {

@@ -310,14 +310,8 @@ __global__ __launch_bounds__(FNT) void k_momentum_fused(Geo g, Ptrs p, int gbx, 
 //     winds of levels k-1 and k, which closes the tendency of level k-1.
 // OLD_IS_CUR: predictor (u_old is the field the tendencies are evaluated on); otherwise the
 // step-start winds are staged as two more (interior-height) tiles.
-constexpr int DNCH = FTN / 2;                     // 16-byte chunks per full tile (374)
-constexpr int DOLD_H = FTJ;                       // rows of an "old" tile (j0 .. j0+FTJ-1)
-constexpr int DOLD_N = FTW * DOLD_H;              // 544 doubles
-constexpr int DOLD_NCH = DOLD_N / 2;              // 272 chunks
-constexpr int DBUF = FNF * FTN + 2 * DOLD_N;      // doubles per LDS buffer
 constexpr int DMAXZ = 160;                        // levels the LDS copy of the 1-D constants can hold
-constexpr size_t DMA_LDS_BYTES = (2 * (size_t)DBUF + 3 * DMAXZ + 2) * sizeof(double);
-
+// two buffers of 9 full tiles (tj+3 rows) + 2 step-start tiles (tj rows), then the 1-D constants
 constexpr size_t dma_lds_bytes(int tj) { return (2 * (size_t)(FNF * FTW * (tj + 3) + 2 * FTW * tj) + 3 * DMAXZ + 2) * sizeof(double); }
 
 typedef __attribute__((address_space(3))) void lds_void_t;
@@ -621,237 +615,6 @@ __global__ __launch_bounds__(FTI *TJ) void k_momentum_dma(Geo g, Ptrs p, int gbx
         }
         u_out[qm] = uo_km1 * cao_is / ca_is + dt * (tu_km1 + (wu_km1 - wu_k) / ds) / ca_is;
         if (v_on) v_out[qm] = vo_km1 * cao_js / ca_js + dt * (tv_km1 + (wv_km1 - wv_k) / ds) / ca_js;
-    }
-#undef SM
-}
-
-// ------------------------------------------------------------------------------------
-// k_momentum_split: k_momentum_dma with the two tendencies on different wavefronts.  A
-// workgroup is 64 x FTJ columns x 2 roles (threadIdx.z = 0: dUFLXdt + UWIND, 1: dVFLXdt +
-// VWIND) = 16 wavefronts that share one set of LDS tiles.  Each thread keeps only one
-// tendency's neighbourhood in registers (<= 128 VGPRs -> 4 waves per SIMD instead of 2).  HBM
-// traffic is unchanged; at 0.25 deg both variants run at the DMA/HBM rate (same time), on the
-// small bands of a multi-GPU run the split one has twice the wavefronts to fill the CUs.
-constexpr int SNW = 2 * FTJ;                       // wavefronts per workgroup (16)
-constexpr int SNSLOT = FNF * 6 + 2 * 5;            // 64 DMA wave-instructions per level
-
-template <bool OLD_IS_CUR>
-__global__ __launch_bounds__(2 * FNT) void k_momentum_split(Geo g, Ptrs p, int gbx, int gby, int jv_lo,
-                                                            const double *u_old, const double *v_old,
-                                                            double *u_out, double *v_out, double dt)
-{
-    extern __shared__ __attribute__((aligned(16))) double dsm[];
-    int bx, by;
-    if (!xcd_tile(gbx, gby, bx, by)) return;
-    const int tx = threadIdx.x, ty = threadIdx.y, role = threadIdx.z;
-    const int tid = (role * FTJ + ty) * FTI + tx;
-    const int wave = tid >> 6, lane = tid & 63;
-    const int i0 = bx * FTI + 1, j0 = by * FTJ + 1;
-    const int i = i0 + tx, j = j0 + ty;
-    const int P = g.P, nz = g.nz;
-    const bool active = (i <= g.nx) && (j <= g.ny);
-
-    // ---- DMA slots of this wave: slot s = wave + 16 q.  Slots 0..53: slice s%6 of full tile
-    // s/6; slots 54..63: slice (s-54)%5 of the step-start UWIND / VWIND tile ----
-    const double *sp[4];
-    int sgo[4], slo[4];
-    bool son[4];
-#pragma unroll
-    for (int q = 0; q < 4; q++) {
-        const int sl = wave + SNW * q;
-        sp[q] = p.UFLX; sgo[q] = 0; slo[q] = 0; son[q] = false;
-        if (sl < FNF * 6) {
-            const int f = sl / 6, sub = sl - f * 6;
-            const int ch = sub * 64 + lane;
-            son[q] = ch < DNCH;
-            const int e = 2 * (son[q] ? ch : 0), r = e / FTW, c2 = e - r * FTW;
-            sgo[q] = min(j0 - 1 + r, g.NJ - 1) * P + min(i0 - 2 + c2, P - 2);
-            slo[q] = f * FTN + sub * 128;
-            const double *b = f == 0 ? p.UFLX : f == 1 ? p.VFLX : f == 2 ? p.UWIND : f == 3 ? p.VWIND : f == 4 ? p.WWIND
-                              : f == 5 ? p.PHI : f == 6 ? p.POTT : f == 7 ? p.PVTF : p.PVTFVB;
-            sp[q] = b + ((f == 4 || f == 8) ? (size_t)g.plane : 0);       // WWIND, PVTFVB at interface k+1
-        } else if (!OLD_IS_CUR && sl < SNSLOT) {
-            const int o = sl - FNF * 6, t2 = o / 5, sub = o - t2 * 5;
-            const int ch = sub * 64 + lane;
-            son[q] = ch < DOLD_NCH;
-            const int e = 2 * (son[q] ? ch : 0), r = e / FTW, c2 = e - r * FTW;
-            sgo[q] = min(j0 + r, g.NJ - 1) * P + min(i0 - 2 + c2, P - 2);
-            slo[q] = FNF * FTN + t2 * DOLD_N + sub * 128;
-            sp[q] = t2 == 0 ? u_old : v_old;
-        }
-    }
-    auto issue = [&](int k, int b) {
-        double *buf = dsm + b * DBUF;
-#pragma unroll
-        for (int q = 0; q < 4; q++)
-            if (son[q])
-                __builtin_amdgcn_global_load_lds((gbl_void_t *)(sp[q] + (size_t)k * g.plane + sgo[q]),
-                                                 (lds_void_t *)(buf + slo[q]), 16, 0, 0);
-    };
-    enum { S_UF = 0, S_VF, S_UW, S_VW, S_W, S_PHI, S_POTT, S_PVTF, S_PVB };
-
-    // ---- per-column (2-D) quantities of this role ----
-    const size_t c = at2(g, active ? i : 1, active ? j : 1);
-    const int jg = j + g.joff;
-    const bool lo = (jg == 1), hi = (jg == g.ny_global);
-    const bool on = active && (role == 0 || j >= jv_lo);
-    // dn = offset to the "behind" neighbour in the direction of the wind component
-    const int dn = role == 0 ? -1 : -P;
-    const double colp = p.COLP[c], colp_d = p.COLP[c + dn];
-    const double dgrid = role == 0 ? p.dyis[c] : p.dxjs[c];
-    const double metric = CON_RE * p.dlon_rad[c] * p.dlat_rad[c] / 2.0;
-    double kc0, sn0, kc1 = 0.0, sn1 = 0.0;
-    if (role == 0) {
-        const double la = p.lat_is_rad[c];
-        kc0 = p.corf_is[c] * CON_RE * cos(la); sn0 = sin(la);
-    } else {
-        const double la = p.lat_rad[c], lb = p.lat_rad[c - P];
-        kc0 = p.corf[c] * CON_RE * cos(la); sn0 = sin(la);
-        kc1 = p.corf[c - P] * CON_RE * cos(lb); sn1 = sin(lb);
-    }
-    // six COLP_NEW*A (and COLP_OLD*A) weights of the 6-point average to the u- / v-point, in the
-    // order pp1_dm1, pp1, dm1, 0, pm1_dm1, pm1 of dyn_functions.py:211-270
-    int wo[6];
-    if (role == 0) { wo[0] = P - 1; wo[1] = P; wo[2] = -1; wo[3] = 0; wo[4] = -P - 1; wo[5] = -P; }
-    else           { wo[0] = -P + 1; wo[1] = 1; wo[2] = -P; wo[3] = 0; wo[4] = -P - 1; wo[5] = -1; }
-    double ca6[6], ca_x, cao_x;
-    {
-        double co6[6];
-#pragma unroll
-        for (int t = 0; t < 6; t++) {
-            ca6[t] = p.COLP_NEW[c + wo[t]] * p.A[c + wo[t]];
-            co6[t] = p.COLP_OLD[c + wo[t]] * p.A[c + wo[t]];
-        }
-        if (role == 0 && lo) {
-            ca_x = 1.0 / 4.0 * (ca6[0] + ca6[1] + ca6[2] + ca6[3]);
-            cao_x = 1.0 / 4.0 * (co6[0] + co6[1] + co6[2] + co6[3]);
-        } else if (role == 0 && hi) {
-            ca_x = 1.0 / 4.0 * (ca6[4] + ca6[5] + ca6[2] + ca6[3]);
-            cao_x = 1.0 / 4.0 * (co6[4] + co6[5] + co6[2] + co6[3]);
-        } else {
-            ca_x = 1.0 / 8.0 * (ca6[0] + ca6[1] + 2.0 * ca6[2] + 2.0 * ca6[3] + ca6[4] + ca6[5]);
-            cao_x = 1.0 / 8.0 * (co6[0] + co6[1] + 2.0 * co6[2] + 2.0 * co6[3] + co6[4] + co6[5]);
-        }
-    }
-    double pvb_k = p.PVTFVB[c], pvb_d_k = p.PVTFVB[c + dn];
-
-    const int lx = tx + 2, ly = ty + 1;
-    const int ldn = role == 0 ? -1 : -FTW;              // the same neighbour inside a tile
-    int lwo[6];
-    if (role == 0) { lwo[0] = FTW - 1; lwo[1] = FTW; lwo[2] = -1; lwo[3] = 0; lwo[4] = -FTW - 1; lwo[5] = -FTW; }
-    else           { lwo[0] = -FTW + 1; lwo[1] = 1; lwo[2] = -FTW; lwo[3] = 0; lwo[4] = -FTW - 1; lwo[5] = -1; }
-    const int lc = ly * FTW + lx;
-#define SM(f, a, b) buf[(f) * FTN + lc + (b) * FTW + (a)]
-
-    double s_k = 0.0, w_km1 = 0.0, x_km1 = 0.0, xo_km1 = 0.0, t_km1 = 0.0;
-    double *x_out = role == 0 ? u_out : v_out;
-
-    double *cst = dsm + 2 * DBUF;
-    double *c_ds = cst, *c_svb = cst + DMAXZ, *c_dif = cst + 2 * DMAXZ + 1;
-    for (int t = tid; t <= nz; t += 2 * FNT) {
-        c_svb[t] = p.sigma_vb[t];
-        if (t < nz) { c_ds[t] = p.dsigma[t]; c_dif[t] = p.UVFLX_dif_coef[t]; }
-    }
-    issue(0, 0);
-    __syncthreads();
-#pragma unroll 1
-    for (int k = 0; k < nz; k++) {
-        if (k + 1 < nz) issue(k + 1, (k + 1) & 1);
-        const double *buf = dsm + (k & 1) * DBUF;
-        if (on) {
-            const double ds = c_ds[k];
-            const double svb = c_svb[k], svb1 = c_svb[k + 1], dif = c_dif[k];
-            const double x = role == 0 ? SM(S_UW, 0, 0) : SM(S_VW, 0, 0);
-            double xo = x;
-            if (!OLD_IS_CUR) xo = buf[FNF * FTN + role * DOLD_N + ty * FTW + lx];
-            // ---- interface k closes level k-1 ----
-            if (k >= 1) {
-                const double ds_km1 = c_ds[k - 1];
-                const double w_k = s_k * ((ds * x_km1 + ds_km1 * x) / (ds + ds_km1));
-                const double t = t_km1 + (w_km1 - w_k) / ds_km1;
-                x_out[c + (size_t)(k - 1) * g.plane] = xo_km1 * cao_x / ca_x + dt * t / ca_x;
-                w_km1 = w_k;
-            }
-            // ---- six-point sum at interface k+1 ----
-            if (k + 1 < nz) {
-                const double *w = buf + S_W * FTN + lc;
-                if (role == 0 && lo) s_k = 0.25 * (ca6[0] * w[lwo[0]] + ca6[1] * w[lwo[1]] + ca6[2] * w[lwo[2]] + ca6[3] * w[lwo[3]]);
-                else if (role == 0 && hi) s_k = 0.25 * (ca6[2] * w[lwo[2]] + ca6[3] * w[lwo[3]] + ca6[4] * w[lwo[4]] + ca6[5] * w[lwo[5]]);
-                else s_k = 0.125 * (ca6[0] * w[lwo[0]] + ca6[1] * w[lwo[1]] + 2.0 * ca6[2] * w[lwo[2]] + 2.0 * ca6[3] * w[lwo[3]] +
-                                    ca6[4] * w[lwo[4]] + ca6[5] * w[lwo[5]]);
-            }
-            const double pvb_kp1 = SM(S_PVB, 0, 0), pvb_d_kp1 = buf[S_PVB * FTN + lc + ldn];
-            const double pg = pre_grad(SM(S_PHI, 0, 0), buf[S_PHI * FTN + lc + ldn], colp, colp_d,
-                                       SM(S_POTT, 0, 0), buf[S_POTT * FTN + lc + ldn],
-                                       SM(S_PVTF, 0, 0), buf[S_PVTF * FTN + lc + ldn],
-                                       pvb_k, pvb_d_k, pvb_d_kp1, pvb_kp1, ds, svb, svb1, dgrid);
-            double t = 0.0;
-#define UF(a, b) SM(S_UF, a, b)
-#define VF(a, b) SM(S_VF, a, b)
-#define U(a, b) SM(S_UW, a, b)
-#define V(a, b) SM(S_VW, a, b)
-            if (role == 0) {
-                const double uf_mm = UF(-1, -1), uf_0m = UF(0, -1), uf_pm = UF(1, -1);
-                const double uf_m0 = UF(-1, 0), uf_00 = UF(0, 0), uf_p0 = UF(1, 0);
-                const double uf_mp = UF(-1, 1), uf_0p = UF(0, 1), uf_pp = UF(1, 1);
-                const double vf_mm = VF(-1, -1), vf_0m = VF(0, -1), vf_m0 = VF(-1, 0), vf_00 = VF(0, 0);
-                const double vf_mp = VF(-1, 1), vf_0p = VF(0, 1), vf_m2 = VF(-1, 2), vf_02 = VF(0, 2);
-                double bflx = 1.0 / 12.0 * (uf_0m + uf_pm + 2.0 * (uf_00 + uf_p0) + uf_0p + uf_pp);
-                double bflx_im1 = 1.0 / 12.0 * (uf_mm + uf_0m + 2.0 * (uf_m0 + uf_00) + uf_mp + uf_0p);
-                double cflx = 1.0 / 12.0 * (vf_mm + vf_0m + 2.0 * (vf_m0 + vf_00) + vf_mp + vf_0p);
-                double cflx_jp1 = 1.0 / 12.0 * (vf_m0 + vf_00 + 2.0 * (vf_mp + vf_0p) + vf_m2 + vf_02);
-                double dflx_im1 = 1.0 / 24.0 * (vf_mm + 2.0 * vf_m0 + vf_mp + uf_mm + uf_m0 + uf_0m + uf_00);
-                double dflx_jp1 = 1.0 / 24.0 * (vf_00 + 2.0 * vf_0p + vf_02 + uf_00 + uf_0p + uf_p0 + uf_pp);
-                double eflx = 1.0 / 24.0 * (vf_0m + 2.0 * vf_00 + vf_0p - uf_0m - uf_00 - uf_pm - uf_p0);
-                double eflx_im1_jp1 = 1.0 / 24.0 * (vf_m0 + 2.0 * vf_mp + vf_m2 - uf_m0 - uf_mp - uf_00 - uf_0p);
-                if (lo) { dflx_im1 = 0.0; cflx = 0.0; eflx = 0.0; }
-                if (hi) { dflx_jp1 = 0.0; cflx_jp1 = 0.0; eflx_im1_jp1 = 0.0; }
-                const double u = x, u_im1 = U(-1, 0), u_ip1 = U(1, 0);
-                t = t + (+bflx_im1 * (u_im1 + u) / 2.0 - bflx * (u + u_ip1) / 2.0
-                         + cflx * (U(0, -1) + u) / 2.0 - cflx_jp1 * (u + U(0, 1)) / 2.0
-                         + dflx_im1 * (U(-1, -1) + u) / 2.0 - dflx_jp1 * (u + U(1, 1)) / 2.0
-                         + 1.0 * (+eflx * (U(1, -1) + u) / 2.0 - eflx_im1_jp1 * (u + U(-1, 1)) / 2.0));
-                t = t + metric * (colp_d * (V(-1, 0) + V(-1, 1)) / 2.0 * (kc0 + (u_im1 + u) / 2.0 * sn0) +
-                                  colp * (V(0, 0) + V(0, 1)) / 2.0 * (kc0 + (u + u_ip1) / 2.0 * sn0));
-                t = t + pg;
-                if (dif > 0.0) t = t + dif * (uf_m0 + uf_p0 + uf_0m + uf_0p - 4.0 * uf_00);
-            } else {
-                const double vf_mm = VF(-1, -1), vf_0m = VF(0, -1), vf_pm = VF(1, -1);
-                const double vf_m0 = VF(-1, 0), vf_00 = VF(0, 0), vf_p0 = VF(1, 0);
-                const double vf_mp = VF(-1, 1), vf_0p = VF(0, 1), vf_pp = VF(1, 1);
-                const double uf_mm = UF(-1, -1), uf_0m = UF(0, -1), uf_pm = UF(1, -1), uf_2m = UF(2, -1);
-                const double uf_m0 = UF(-1, 0), uf_00 = UF(0, 0), uf_p0 = UF(1, 0), uf_20 = UF(2, 0);
-                const double rflx = 1.0 / 12.0 * (vf_m0 + vf_mp + 2.0 * (vf_00 + vf_0p) + vf_p0 + vf_pp);
-                const double rflx_jm1 = 1.0 / 12.0 * (vf_mm + vf_m0 + 2.0 * (vf_0m + vf_00) + vf_pm + vf_p0);
-                const double qflx = 1.0 / 12.0 * (uf_mm + uf_m0 + 2.0 * (uf_0m + uf_00) + uf_pm + uf_p0);
-                const double qflx_ip1 = 1.0 / 12.0 * (uf_0m + uf_00 + 2.0 * (uf_pm + uf_p0) + uf_2m + uf_20);
-                const double sflx_jm1 = 1.0 / 24.0 * (vf_mm + vf_m0 + vf_0m + vf_00 + uf_mm + 2.0 * uf_0m + uf_pm);
-                const double sflx_ip1 = 1.0 / 24.0 * (vf_00 + vf_0p + vf_p0 + vf_pp + uf_00 + 2.0 * uf_p0 + uf_20);
-                const double tflx = 1.0 / 24.0 * (vf_m0 + vf_mp + vf_00 + vf_0p - uf_m0 - 2.0 * uf_00 - uf_p0);
-                const double tflx_ip1_jm1 = 1.0 / 24.0 * (vf_0m + vf_00 + vf_pm + vf_p0 - uf_0m - 2.0 * uf_pm - uf_2m);
-                const double v = x;
-                t = t + (+rflx_jm1 * (V(0, -1) + v) / 2.0 - rflx * (v + V(0, 1)) / 2.0
-                         + qflx * (V(-1, 0) + v) / 2.0 - qflx_ip1 * (v + V(1, 0)) / 2.0
-                         + sflx_jm1 * (V(-1, -1) + v) / 2.0 - sflx_ip1 * (v + V(1, 1)) / 2.0
-                         + -1.0 * (+tflx * (V(-1, 1) + v) / 2.0 - tflx_ip1_jm1 * (v + V(1, -1)) / 2.0));
-                const double ub_jm1 = (U(0, -1) + U(1, -1)) / 2.0, ub = (U(0, 0) + U(1, 0)) / 2.0;
-                t = t + -metric * (colp_d * ub_jm1 * (kc1 + ub_jm1 * sn1) + colp * ub * (kc0 + ub * sn0));
-                t = t + pg;
-                if (dif > 0.0) t = t + dif * (vf_m0 + vf_p0 + vf_0m + vf_0p - 4.0 * vf_00);
-            }
-#undef UF
-#undef VF
-#undef U
-#undef V
-            t_km1 = t;
-            x_km1 = x; xo_km1 = xo;
-            pvb_k = pvb_kp1; pvb_d_k = pvb_d_kp1;
-        }
-        __syncthreads();
-    }
-    if (on) {
-        const double ds = c_ds[nz - 1];
-        x_out[c + (size_t)(nz - 1) * g.plane] = xo_km1 * cao_x / ca_x + dt * (t_km1 + (w_km1 - 0.0) / ds) / ca_x;
     }
 #undef SM
 }

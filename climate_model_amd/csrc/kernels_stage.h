@@ -526,24 +526,45 @@ __global__ __launch_bounds__(TI *TJ) void k_moist(Geo g, Ptrs p, const double *q
     double qv_km1 = 0.0, qc_km1 = 0.0, phi_km1 = 0.0;
     double fv_k = 0.0, fc_k = 0.0;                 // W * interface value at interface k (0 at the top)
     double qv_k = p.QV[c], qc_k = p.QC[c];
+    // software pipeline as in k_pott_fused: the inputs of level k+1 are requested before level k is
+    // computed, so the HBM latency overlaps the two logarithms per interface
+    struct In { double uf, uf1, vf, vf1, w1, qv1, qc1, v_im1, v_ip1, v_jm1, v_jp1, c_im1, c_ip1, c_jm1, c_jp1, vo, co; };
+    auto load = [&](int k) {
+        In r;
+        const size_t q = c + (size_t)k * g.plane;
+        r.uf = p.UFLX[q]; r.uf1 = p.UFLX[q + 1]; r.vf = p.VFLX[q]; r.vf1 = p.VFLX[q + P];
+        const bool last = (k == nz - 1);
+        r.w1 = last ? 0.0 : p.WWIND[q + g.plane];
+        r.qv1 = last ? 0.0 : p.QV[q + g.plane];
+        r.qc1 = last ? 0.0 : p.QC[q + g.plane];
+        r.v_im1 = p.QV[q - 1]; r.v_ip1 = p.QV[q + 1]; r.v_jm1 = p.QV[q - P]; r.v_jp1 = p.QV[q + P];
+        r.c_im1 = p.QC[q - 1]; r.c_ip1 = p.QC[q + 1]; r.c_jm1 = p.QC[q - P]; r.c_jp1 = p.QC[q + P];
+        r.vo = 0.0; r.co = 0.0;
+        if (EULER) { r.vo = qv_old[q]; r.co = qc_old[q]; }
+        return r;
+    };
+    In nxt = load(0);
+#pragma unroll 1
     for (int k = 0; k < nz; k++) {
         const size_t q = c + (size_t)k * g.plane;
+        const In cur = nxt;
+        if (k + 1 < nz) nxt = load(k + 1);
         const double ds = p.dsigma[k], dif = p.moist_dif_coef[k];
-        const double uflx = p.UFLX[q], uflx_ip1 = p.UFLX[q + 1], vflx = p.VFLX[q], vflx_jp1 = p.VFLX[q + P];
+        const double uflx = cur.uf, uflx_ip1 = cur.uf1, vflx = cur.vf, vflx_jp1 = cur.vf1;
         const bool last = (k == nz - 1);
-        const double qv_kp1 = last ? 0.0 : p.QV[q + g.plane], qc_kp1 = last ? 0.0 : p.QC[q + g.plane];
+        const double qv_kp1 = cur.qv1, qc_kp1 = cur.qc1;
         double fv_kp1 = 0.0, fc_kp1 = 0.0;
         if (!last) {
-            const double w_kp1 = p.WWIND[q + g.plane];
+            const double w_kp1 = cur.w1;
             fv_kp1 = w_kp1 * varvb_log(qv_kp1, qv_k);
             fc_kp1 = w_kp1 * varvb_log(qc_kp1, qc_k);
         }
         double tq[2];
 #pragma unroll
         for (int s = 0; s < 2; s++) {
-            const double *Q = s == 0 ? p.QV : p.QC;
             const double x = s == 0 ? qv_k : qc_k;
-            const double x_im1 = Q[q - 1], x_ip1 = Q[q + 1], x_jm1 = Q[q - P], x_jp1 = Q[q + P];
+            const double x_im1 = s == 0 ? cur.v_im1 : cur.c_im1, x_ip1 = s == 0 ? cur.v_ip1 : cur.c_ip1;
+            const double x_jm1 = s == 0 ? cur.v_jm1 : cur.c_jm1, x_jp1 = s == 0 ? cur.v_jp1 : cur.c_jp1;
             const double f_k = s == 0 ? fv_k : fc_k, f_kp1 = s == 0 ? fv_kp1 : fc_kp1;
             double d = 0.0;
             d = d + (+uflx * (x_im1 + x) / 2.0 - uflx_ip1 * (x + x_ip1) / 2.0
@@ -563,8 +584,8 @@ __global__ __launch_bounds__(TI *TJ) void k_moist(Geo g, Ptrs p, const double *q
             tq[s] = d;
         }
         if (EULER) {
-            qv_out[q] = qv_old[q] * colp_old / colp_new + dt * tq[0] / colp_new;
-            qc_out[q] = qc_old[q] * colp_old / colp_new + dt * tq[1] / colp_new;
+            qv_out[q] = cur.vo * colp_old / colp_new + dt * tq[0] / colp_new;
+            qc_out[q] = cur.co * colp_old / colp_new + dt * tq[1] / colp_new;
         } else {
             p.dQVdt[q] = tq[0];
             p.dQCdt[q] = tq[1];

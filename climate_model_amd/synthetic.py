@@ -66,6 +66,21 @@ def initialize_fields(GR, F, seed=3, noise_wind=0.1, noise_pott=0.1, j_offset=0)
     return F
 
 
+def initialize_moisture(GR, F):
+    """A smooth specific-humidity / cloud-water field with structure in every direction (QV, QC on
+    the global grid, lateral BCs applied) and a constant surface latent heat flux: the inputs of
+    dyn_moist for synthetic runs (the reference starts from 60 % relative humidity, mic_main.py:63-71)."""
+    from .grid import exchange_BC_host
+    ii, jj = np.meshgrid(np.arange(GR.nx + 2), np.arange(GR.ny + 2), indexing='ij')
+    for k in range(GR.nz):
+        F.host['QV'][:, :, k] = 0.004 * (k + 1) / GR.nz * (1.2 + np.sin(2 * np.pi * ii / GR.nx) * np.cos(np.pi * jj / GR.ny))
+        F.host['QC'][:, :, k] = 1e-5 * (1.1 + np.cos(4 * np.pi * ii / GR.nx)) * (k + 1) / GR.nz
+    exchange_BC_host(F.host['QV'], GR.nx, GR.ny)
+    exchange_BC_host(F.host['QC'], GR.nx, GR.ny)
+    F.host['SLHFLX'][...] = 30.
+    return F
+
+
 def stable_dt(GR, safety=0.5):
     """A CFL-safe time step for grids where the reference's int() rule gives 0."""
     return safety * GR.nl.CFL * float(np.nanmin(GR.dx)) / 400.

@@ -34,15 +34,9 @@ def _initial_state(d, nz, i_turb, i_moist=0):
             F.host[n][...] = rng.uniform(lo, hi, F.host[n].shape)
     names = ['HSURF', 'COLP', 'UWIND', 'VWIND', 'POTT', 'WWIND', 'POTTVB', 'KMOM', 'KHEAT',
              'SSHFLX', 'SMOMXFLX', 'SMOMYFLX', 'dPOTTdt_RAD']
-    if i_moist:       # a smooth humidity field with structure in every direction
-        ii, jj = np.meshgrid(np.arange(GR.nx + 2), np.arange(GR.ny + 2), indexing='ij')
-        for k in range(GR.nz):
-            F.host['QV'][:, :, k] = 0.004 * (k + 1) / GR.nz * (1.2 + np.sin(2 * np.pi * ii / GR.nx) * np.cos(np.pi * jj / GR.ny))
-            F.host['QC'][:, :, k] = 1e-5 * (1.1 + np.cos(4 * np.pi * ii / GR.nx)) * (k + 1) / GR.nz
-        from climate_model_amd.grid import exchange_BC_host
-        exchange_BC_host(F.host['QV'], GR.nx, GR.ny)
-        exchange_BC_host(F.host['QC'], GR.nx, GR.ny)
-        F.host['SLHFLX'][...] = 30.
+    if i_moist:
+        from climate_model_amd.synthetic import initialize_moisture
+        initialize_moisture(GR, F)
         names += ['QV', 'QC', 'SLHFLX']
     return GR, {n: F.host[n] for n in names}
 

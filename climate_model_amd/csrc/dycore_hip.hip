@@ -129,7 +129,7 @@ struct dycore {
     int mom_ks = 0;                 // DYCORE_MOM_KS: force the level chunks per momentum tile (1, 2, 4)
     int mom_dma = 1;                // momentum kernel: 1 = LDS-DMA (default); 0 = register-staged tiles (DYCORE_MOM_DMA)
     // profiler
-    bool prof = false;
+    int prof = 0;                   // 0 off, 1 every launch, 2 dominant kernel only
     std::vector<ProfRec> recs;
     std::vector<hipEvent_t> ev_pool;
     int64_t launches[K_COUNT] = {0};
@@ -168,7 +168,7 @@ struct Scope {          // brackets one launch with events when profiling is on
     dycore *h; int kid; ProfRec r; bool on;
     Scope(dycore *h_, int kid_) : h(h_), kid(kid_), on(false)
     {
-        if (!h->prof) return;
+        if (!h->prof || (h->prof == 2 && kid != K_MOM_FUSED)) return;
         if (get_event(h, &r.a) || get_event(h, &r.b)) return;
         r.kid = kid;
         on = hipEventRecord(r.a, h->stream) == hipSuccess;
@@ -498,7 +498,7 @@ int do_diag_band_halo(dycore *h, const Ptrs &p)
     if (h->g.pole_s && h->g.pole_n) return 0;
     const int row_a = h->g.pole_s ? -1 : 0, row_b = h->g.pole_n ? -1 : h->g.ny + 1;
     const dim3 gr((h->g.nx + 2 + TI - 1) / TI, 2);
-    if (h->prof || !h->side) {      // profiling brackets launches on the main stream
+    if (h->prof == 1 || !h->side) { // full profiling brackets every launch on the main stream
         Scope s(h, K_DIAG_ROWS);
         hipLaunchKernelGGL(k_primary_diag_rows, gr, dim3(TI), 0, h->stream, h->g, p, row_a, row_b);
         return launch_check("k_primary_diag_rows");
@@ -1033,7 +1033,7 @@ int dycore_profile(dycore_t *h, int32_t enable)
 {
     if (!h) return fail(DYCORE_EINVAL, "null handle");
     int rc = prof_flush(h);
-    h->prof = enable != 0;
+    h->prof = enable < 0 ? 0 : (enable > 2 ? 1 : enable);
     if (enable) { memset(h->launches, 0, sizeof h->launches); memset(h->total_ms, 0, sizeof h->total_ms); }
     return rc;
 }

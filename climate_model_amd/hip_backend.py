@@ -278,7 +278,8 @@ class HipDycore:
         return ms.value
 
     def profile(self, enable=True):
-        self._check(self.lib.dycore_profile(self._h, int(bool(enable))))
+        """True / 1: HIP events around every launch; 2: around the dominant (momentum) kernel only."""
+        self._check(self.lib.dycore_profile(self._h, int(enable)))
 
     def kernel_stats(self):
         out = {}

@@ -171,7 +171,9 @@ int dycore_unpack_rows(dycore_t *h, int32_t n, const char *const *names, const i
  * the elapsed device time in milliseconds (synchronises). */
 int dycore_time_steps(dycore_t *h, double dt, int32_t nsteps, int32_t with_rho, double *ms);
 /* Per-kernel device time accumulated by HIP events since the last reset, for the kernel
- * with the given index (0 <= idx < dycore_n_kernels()); enable with dycore_profile(h,1). */
+ * with the given index (0 <= idx < dycore_n_kernels()); enable with dycore_profile(h,1).
+ * dycore_profile(h,2) brackets only the dominant kernel (momentum): two events per launch are
+ * a measurable share of a small latitude band's step, so timed multi-GPU runs use this level. */
 int dycore_profile(dycore_t *h, int32_t enable);
 int dycore_n_kernels(void);
 int dycore_kernel_stats(dycore_t *h, int32_t idx, const char **name,

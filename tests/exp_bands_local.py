@@ -40,9 +40,14 @@ for nb in [1, 2, 4, 8]:
     torch.cuda.synchronize(); t0 = time.perf_counter()
     lb.step_matsuno(GR.dt, steps)
     torch.cuda.synchronize(); wall = (time.perf_counter() - t0) / steps / nb * 1e3
+    for c in cores: c.profile(True)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    lb.step_matsuno(GR.dt, steps)
+    torch.cuda.synchronize(); wall_prof = (time.perf_counter() - t0) / steps / nb * 1e3
+    for c in cores: c.profile(False)
     per_gpu = sum(tot.values()) / nb / steps
     if base is None: base = per_gpu
-    print('bands=%d  wall %.3f ms/band-step  kernel ms/step per band: %.3f   compute-only speedup %.2fx (eff %.0f%%)  | %s' % (
-        nb, wall, per_gpu, base / per_gpu, 100 * base / per_gpu / nb,
+    print('bands=%d  wall %.3f (profiled %.3f) ms/band-step  kernel ms/step per band: %.3f   compute-only speedup %.2fx (eff %.0f%%)  | %s' % (
+        nb, wall, wall_prof, per_gpu, base / per_gpu, 100 * base / per_gpu / nb,
         '  '.join('%s=%.3f' % (k.replace('k_', ''), v / nb / steps) for k, v in tot.items() if v / nb / steps > 0.005)), flush=True)
     for c in cores: c.close()

@@ -106,3 +106,54 @@ def test_bands_equal_single_full_size(d, nz, nbands):
         np.testing.assert_array_equal(got, ref[n], err_msg='%s (%d bands)' % (n, nbands))
     for c in cores:
         c.close()
+
+
+def _setup_nxny(nx, ny, nz):
+    nl = Namelist(nz=nz, dlat_deg=180.0 / ny * (1 - 1e-12), dlon_deg=360.0 / nx * (1 - 1e-12), dt=1.0)
+    GR = Grid(nl)
+    assert (GR.nx, GR.ny) == (nx, ny)
+    from climate_model_amd.synthetic import stable_dt
+    GR.dt = stable_dt(GR)
+    F = ModelFields(GR)
+    initialize_fields(GR, F)
+    return GR, {n: F.host[n] for n in STATE}
+
+
+@pytest.mark.parametrize('nx,ny,nz', [(3, 2, 2), (5, 3, 2), (63, 7, 3), (64, 8, 4), (65, 9, 5), (67, 16, 8),
+                                      (130, 17, 16), (200, 33, 7), (96, 25, 64)])
+def test_ragged_sizes_vs_oracle(nx, ny, nz):
+    """Smallest legal grid, extents around the 64-lane / 8-row tile sizes, level counts with and
+    without the unrolled continuity kernel and the level-split momentum tiles: 3 steps against the
+    CPU oracle, tolerance 1e-9 (max-norm relative)."""
+    GR, state = _setup_nxny(nx, ny, nz)
+    got = _run_hip(GR, state, 3, PROGNOSTIC + ['PHI', 'WWIND', 'POTTVB'])
+    o = Oracle(nx, ny, nz, GR.GRF['CPU'], state, pair_top=GR.nl.pair_top, i_turb=0, fill_nan=False)
+    o.primary_diag()
+    o.step_matsuno(GR.dt, 3, with_rho=False)
+    for n in got:
+        err, ncmp, bad = rel_max_err(got[n], o.F[n], n, nx, ny)
+        assert bad == 0 and ncmp > 0 and err <= 1e-9, '%s at %dx%dx%d: rel err %.3e (%d bad)' % (n, nx, ny, nz, err, bad)
+
+
+@pytest.mark.parametrize('nx,ny,nz,nbands', [(65, 9, 5, 4), (96, 25, 64, 3), (130, 17, 16, 8)])
+def test_ragged_bands_equal_single(nx, ny, nz, nbands):
+    """Band heights of 2-9 rows (fewer rows than one momentum tile: no inner tiles at all)."""
+    import torch
+    GR, state = _setup_nxny(nx, ny, nz)
+    ref = _run_hip(GR, state, 2)
+    L = BandLayout(ny, nbands)
+    stream = torch.cuda.Stream()
+    cores = []
+    for r in range(nbands):
+        c = HipDycore(nx, L.ny(r), nz, ny_global=ny, j_offset=L.j_offset(r), stream=stream.cuda_stream)
+        c.set_grid(band_grid_arrays(GR.GRF['HIP'], L, r))
+        for n, a in state.items():
+            c.upload(n, L.slice_rows(a, r, FIELD_TABLE[n][1]))
+        c.primary_diag()
+        cores.append(c)
+    LocalBands(cores, L, torch.device('cuda:0')).step_matsuno(GR.dt, 2)
+    for n in PROGNOSTIC:
+        got = gather_global(L, [c.download(n) for c in cores], n)
+        np.testing.assert_array_equal(got, ref[n], err_msg='%s (%d bands)' % (n, nbands))
+    for c in cores:
+        c.close()

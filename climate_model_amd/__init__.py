@@ -7,8 +7,9 @@ from .hip_backend import HipDycore, DycoreError
 from .discretizations import TendencyFactory, DiagnosticsFactory, PrognosticsFactory
 from .matsuno import step_matsuno, step_matsuno_fused, compute_tendencies
 from .turbulence import Turbulence
+from .radiation import Radiation
 from . import solver
 
 __all__ = ['Namelist', 'Grid', 'ModelFields', 'FIELD_TABLE', 'CPU', 'HIP', 'HipDycore',
            'DycoreError', 'TendencyFactory', 'DiagnosticsFactory', 'PrognosticsFactory',
-           'step_matsuno', 'step_matsuno_fused', 'compute_tendencies', 'Turbulence']
+           'step_matsuno', 'step_matsuno_fused', 'compute_tendencies', 'Turbulence', 'Radiation']

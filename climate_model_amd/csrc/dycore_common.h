@@ -54,6 +54,10 @@ struct Ptrs {
     double *QV, *QV_OLD, *QC, *QC_OLD, *dQVdt, *dQCdt, *dQVdt_TURB, *SLHFLX, *QV_EST, *QC_EST;
     // full secondary diagnostics (dyn_diagnostics.py:199-222)
     double *TAIR, *TAIRVB, *PAIR, *PAIRVB, *WINDX, *WINDY, *WIND;
+    // radiation (rad_main.py:33-38); allocated only on handles created with i_radiation
+    double *SOILTEMP, *SURFALBEDLW, *SURFALBEDSW, *SOLZEN, *MYSUN, *SWINTOA;
+    double *LWFLXDO, *LWFLXUP, *SWDIFFLXDO, *SWDIRFLXDO, *SWFLXUP, *SWFLXDO, *LWFLXNET, *SWFLXNET;
+    double *SWFLXDIV, *LWFLXDIV, *TOTFLXDIV;
     // grid constants, 2-D
     const double *A, *dxjs, *dyis, *corf, *corf_is, *lat_rad, *lat_is_rad, *dlon_rad, *dlat_rad;
     // grid constants, vertical 1-D

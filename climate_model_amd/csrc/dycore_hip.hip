@@ -19,6 +19,7 @@
 #include "dycore_common.h"
 #include "kernels_stage.h"
 #include "kernels_fused.h"
+#include "kernels_radiation.h"
 
 using namespace dyc;
 
@@ -50,10 +51,12 @@ struct FieldDesc {
     int stgx, stgy;
     int nk;                         // 0 -> nz, -1 -> nz+1, 1 -> 1
     double *Ptrs::*member;
+    int rad;                        // 1: exists only on handles created with i_radiation
 };
 
 // main_fields.py:234-475
-#define F_(n, sx, sy, nk) {#n, sx, sy, nk, &Ptrs::n}
+#define F_(n, sx, sy, nk) {#n, sx, sy, nk, &Ptrs::n, 0}
+#define R_(n, nk) {#n, 0, 0, nk, &Ptrs::n, 1}
 const FieldDesc kFields[] = {
     F_(COLP, 0, 0, 1), F_(COLP_OLD, 0, 0, 1), F_(COLP_NEW, 0, 0, 1), F_(dCOLPdt, 0, 0, 1), F_(HSURF, 0, 0, 1),
     F_(UWIND, 1, 0, 0), F_(UWIND_OLD, 1, 0, 0), F_(VWIND, 0, 1, 0), F_(VWIND_OLD, 0, 1, 0), F_(WWIND, 0, 0, -1),
@@ -72,8 +75,13 @@ const FieldDesc kFields[] = {
     F_(dQVdt_TURB, 0, 0, 0), F_(SLHFLX, 0, 0, 1), F_(QV_EST, 0, 0, 0), F_(QC_EST, 0, 0, 0),
     F_(TAIR, 0, 0, 0), F_(TAIRVB, 0, 0, -1), F_(PAIR, 0, 0, 0), F_(PAIRVB, 0, 0, -1),
     F_(WINDX, 0, 0, 0), F_(WINDY, 0, 0, 0), F_(WIND, 0, 0, 0),
+    // radiation: rad_main.py:33-38 (SOILTEMP: the top soil level, the only one the scheme reads)
+    R_(SOILTEMP, 1), R_(SURFALBEDLW, 1), R_(SURFALBEDSW, 1), R_(SOLZEN, 1), R_(MYSUN, 1), R_(SWINTOA, 1),
+    R_(LWFLXDO, -1), R_(LWFLXUP, -1), R_(SWDIFFLXDO, -1), R_(SWDIRFLXDO, -1), R_(SWFLXUP, -1), R_(SWFLXDO, -1),
+    R_(LWFLXNET, -1), R_(SWFLXNET, -1), R_(SWFLXDIV, 0), R_(LWFLXDIV, 0), R_(TOTFLXDIV, 0),
 };
 #undef F_
+#undef R_
 constexpr int kNFields = sizeof(kFields) / sizeof(kFields[0]);
 
 struct GridDesc {
@@ -94,12 +102,12 @@ constexpr int kNGrid = sizeof(kGrid) / sizeof(kGrid[0]);
 
 // kernels tracked by the profiler
 enum KernelId {
-    K_CONTINUITY = 0, K_PREPARE, K_UFLX, K_VFLX, K_POTT, K_EULER, K_DIAG, K_RHO, K_EXCHANGE, K_COPY, K_HALO, K_MOM_FUSED, K_POTT_FUSED, K_DIAG_ROWS, K_HALO_MULTI, K_CONT_REG, K_DERIVE, K_MOIST, K_SECONDARY, K_TURB,
+    K_CONTINUITY = 0, K_PREPARE, K_UFLX, K_VFLX, K_POTT, K_EULER, K_DIAG, K_RHO, K_EXCHANGE, K_COPY, K_HALO, K_MOM_FUSED, K_POTT_FUSED, K_DIAG_ROWS, K_HALO_MULTI, K_CONT_REG, K_DERIVE, K_MOIST, K_SECONDARY, K_TURB, K_RAD,
     K_COUNT
 };
 const char *kKernelNames[K_COUNT] = {
     "k_continuity", "k_prepare", "k_uflx_tendency", "k_vflx_tendency", "k_pott_tendency",
-    "k_euler_forward", "k_primary_diag", "k_diag_rho", "k_exchange_bc", "copy_field", "k_rows", "k_momentum_fused", "k_pott_fused", "k_primary_diag_rows", "k_halo_multi", "k_continuity_reg", "k_derive", "k_moist", "k_diag_secondary", "k_turbulence",
+    "k_euler_forward", "k_primary_diag", "k_diag_rho", "k_exchange_bc", "copy_field", "k_rows", "k_momentum_fused", "k_pott_fused", "k_primary_diag_rows", "k_halo_multi", "k_continuity_reg", "k_derive", "k_moist", "k_diag_secondary", "k_turbulence", "k_radiation",
 };
 
 struct ProfRec { int kid; hipEvent_t a, b; };
@@ -118,6 +126,8 @@ struct dycore {
     bool side_pending = false;
     std::unordered_map<std::string, int> field_idx, grid_idx;
     std::vector<double *> allocs;
+    double *rad_ws = nullptr;       // workspace of the radiation columns, [element][column]
+    long long rad_ws_cols = 0;
     double *stage = nullptr;        // staging buffer for the layout adaptor
     size_t stage_elems = 0;
     int grid_set = 0;
@@ -727,9 +737,19 @@ int dycore_create(const DycoreConfig *cfg, dycore_t **out)
     int rc = 0;
     for (int f = 0; f < kNFields && !rc; f++) {
         double *d = nullptr;
-        rc = alloc(h->field_elems(kFields[f].nk), &d);
+        if (!kFields[f].rad || g.i_rad) rc = alloc(h->field_elems(kFields[f].nk), &d);
         h->p.*(kFields[f].member) = d;
         h->field_idx[kFields[f].name] = f;
+    }
+    if (!rc && g.i_rad) {           // columns per radiation launch: bounded workspace (<= 1 GiB)
+        const long long cols = (long long)g.nx * g.ny, per = (long long)rad_ws_per_column(g.nz);
+        long long chunk = ((1LL << 27) / per) / 256 * 256;
+        if (chunk < 256) chunk = 256;
+        if (chunk > cols) chunk = (cols + 255) / 256 * 256;
+        double *d = nullptr;
+        rc = alloc((size_t)(chunk * per), &d);
+        h->rad_ws = d;
+        h->rad_ws_cols = chunk;
     }
     for (int f = 0; f < kNGrid && !rc; f++) {
         double *d = nullptr;
@@ -816,6 +836,7 @@ static int find_field(dycore_t *h, const char *name, const FieldDesc **d)
     auto it = h->field_idx.find(name);
     if (it == h->field_idx.end()) return fail(DYCORE_EINVAL, "unknown field '%s'", name);
     *d = &kFields[it->second];
+    if (!(h->p.*((*d)->member))) return fail(DYCORE_ESTATE, "field '%s' exists only on handles created with i_radiation", name);
     return 0;
 }
 
@@ -917,6 +938,30 @@ int dycore_primary_diag(dycore_t *h) { int rc = ready_join(h); return rc ? rc : 
 int dycore_secondary_diag_rho(dycore_t *h) { int rc = ready_join(h); return rc ? rc : do_rho(h, h->p); }
 int dycore_secondary_diag(dycore_t *h) { int rc = ready_join(h); return rc ? rc : do_secondary(h, h->p); }
 int dycore_compute_turbulence(dycore_t *h) { int rc = ready_join(h); return rc ? rc : do_turbulence(h, h->p); }
+
+int dycore_radiation(dycore_t *h, double solar_constant, int32_t nbins, const double *lambdas_center, const double *dlambdas)
+{
+    if (!h) return fail(DYCORE_EINVAL, "null handle");
+    if (!h->g.i_rad) return fail(DYCORE_ESTATE, "handle created without i_radiation");
+    int rc = ready_join(h);
+    if (rc) return rc;
+    if (!lambdas_center || !dlambdas || nbins < 1 || nbins > RAD_MAX_BINS)
+        return fail(DYCORE_EINVAL, "need 1..%d spectral bins", RAD_MAX_BINS);
+    if (h->g.nz < 3) return fail(DYCORE_EINVAL, "the shortwave scheme needs nz >= 3 (rad_shortwave.py:99-100)");
+    RadParams rp;
+    rp.solar_constant = solar_constant;
+    rp.nbins = nbins;
+    for (int b = 0; b < RAD_MAX_BINS; b++) { rp.lam[b] = b < nbins ? lambdas_center[b] : 1.0; rp.dlam[b] = b < nbins ? dlambdas[b] : 0.0; }
+    Scope s(h, K_RAD);
+    const long long cols = (long long)h->g.nx * h->g.ny;
+    for (long long c0 = 0; c0 < cols; c0 += h->rad_ws_cols) {
+        const long long n = cols - c0 < h->rad_ws_cols ? cols - c0 : h->rad_ws_cols;
+        hipLaunchKernelGGL(k_radiation, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, h->g, h->p, rp,
+                           h->rad_ws, h->rad_ws_cols, c0, n);
+        if ((rc = launch_check("k_radiation"))) return rc;
+    }
+    return 0;
+}
 
 int dycore_step_matsuno(dycore_t *h, double dt, int32_t nsteps, int32_t with_rho)
 {

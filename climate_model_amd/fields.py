@@ -92,7 +92,29 @@ FIELD_TABLE = OrderedDict([
     ('WINDX',         (0, 0, 'nz')),
     ('WINDY',         (0, 0, 'nz')),
     ('WIND',          (0, 0, 'nz')),
+    # radiation (rad_main.py:33-38); on the device only with i_radiation.
+    # SOILTEMP: top soil level (the reference's array has nzsoil levels, radiation reads level 0)
+    ('SOILTEMP',      (0, 0, 1)),
+    ('SURFALBEDLW',   (0, 0, 1)),
+    ('SURFALBEDSW',   (0, 0, 1)),
+    ('SOLZEN',        (0, 0, 1)),
+    ('MYSUN',         (0, 0, 1)),
+    ('SWINTOA',       (0, 0, 1)),
+    ('LWFLXDO',       (0, 0, 'nzs')),
+    ('LWFLXUP',       (0, 0, 'nzs')),
+    ('SWDIFFLXDO',    (0, 0, 'nzs')),
+    ('SWDIRFLXDO',    (0, 0, 'nzs')),
+    ('SWFLXUP',       (0, 0, 'nzs')),
+    ('SWFLXDO',       (0, 0, 'nzs')),
+    ('LWFLXNET',      (0, 0, 'nzs')),
+    ('SWFLXNET',      (0, 0, 'nzs')),
+    ('SWFLXDIV',      (0, 0, 'nz')),
+    ('LWFLXDIV',      (0, 0, 'nz')),
+    ('TOTFLXDIV',     (0, 0, 'nz')),
 ])
+RADIATION_FIELDS = ('SOILTEMP', 'SURFALBEDLW', 'SURFALBEDSW', 'SOLZEN', 'MYSUN', 'SWINTOA', 'LWFLXDO', 'LWFLXUP',
+                    'SWDIFFLXDO', 'SWDIRFLXDO', 'SWFLXUP', 'SWFLXDO', 'LWFLXNET', 'SWFLXNET', 'SWFLXDIV', 'LWFLXDIV',
+                    'TOTFLXDIV')
 
 # fields the reference passes through a factory signature that the dycore does not own
 PASS_THROUGH_FIELDS = ()

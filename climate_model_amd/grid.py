@@ -118,6 +118,7 @@ class Grid:
         else:
             self.dt = nl.dt
         self.ts = 0
+        self.GMT = nl.GMT_initialization        # main_grid.py:273; advanced by the solver loop
         self.timer = Timer()
 
         # numerical diffusion per level (main_grid.py:275-294)
@@ -160,6 +161,7 @@ class Grid:
             setattr(self, name, np.array(grf[src], dtype=np.float64))
         self.dt = dt
         self.ts = 0
+        self.GMT = self.nl.GMT_initialization
         self.timer = Timer()
         self._build_GRF()
         return self

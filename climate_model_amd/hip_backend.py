@@ -33,7 +33,7 @@ ABI_SYMBOLS = [
     'dycore_continuity', 'dycore_momentum', 'dycore_momentum_prepare', 'dycore_uflx_tendency',
     'dycore_vflx_tendency', 'dycore_pott_tendency', 'dycore_moist_tendency', 'dycore_euler_forward',
     'dycore_primary_diag',
-    'dycore_secondary_diag_rho', 'dycore_secondary_diag', 'dycore_compute_turbulence',
+    'dycore_secondary_diag_rho', 'dycore_secondary_diag', 'dycore_compute_turbulence', 'dycore_radiation',
     'dycore_step_matsuno', 'dycore_time_steps',
     'dycore_step_begin', 'dycore_substep_part', 'dycore_use_stream', 'dycore_get_stream', 'dycore_overlap_parts', 'dycore_rows_size', 'dycore_pack_rows',
     'dycore_unpack_rows', 'dycore_substep_field',
@@ -73,6 +73,7 @@ def load_library(path=None):
               'dycore_vflx_tendency', 'dycore_pott_tendency', 'dycore_moist_tendency', 'dycore_primary_diag',
               'dycore_secondary_diag_rho', 'dycore_secondary_diag', 'dycore_compute_turbulence'):
         getattr(lib, n).argtypes = [hp]
+    lib.dycore_radiation.argtypes = [hp, C.c_double, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     lib.dycore_step_matsuno.argtypes = [hp, C.c_double, C.c_int32, C.c_int32]
     lib.dycore_time_steps.argtypes = [hp, C.c_double, C.c_int32, C.c_int32, C.POINTER(C.c_double)]
     lib.dycore_step_begin.argtypes = [hp, C.c_int32]
@@ -219,6 +220,16 @@ class HipDycore:
 
     def compute_turbulence(self):
         self._check(self.lib.dycore_compute_turbulence(self._h))
+
+    def radiation(self, solar_constant, lambdas_center, dlambdas):
+        """dycore_radiation: longwave / shortwave columns -> fluxes, divergences, dPOTTdt_RAD."""
+        lam = np.ascontiguousarray(lambdas_center, dtype=np.float64)
+        dlam = np.ascontiguousarray(dlambdas, dtype=np.float64)
+        if lam.shape != dlam.shape or lam.ndim != 1:
+            raise ValueError('lambdas_center and dlambdas must be 1-D arrays of one length')
+        dp = C.POINTER(C.c_double)
+        self._check(self.lib.dycore_radiation(self._h, float(solar_constant), int(lam.size),
+                                              lam.ctypes.data_as(dp), dlam.ctypes.data_as(dp)))
 
     def step_matsuno(self, dt, nsteps=1, with_rho=None):
         with_rho = self.i_turb if with_rho is None else with_rho

@@ -6,7 +6,8 @@ Here the same names live on a `Namelist` object that is handed to `Grid`; the
 values that reach the device travel in `DycoreConfig` (include/dycore.h).
 Only the entries the Matsuno step uses are kept.
 """
-from dataclasses import dataclass
+from dataclasses import dataclass, field
+from datetime import datetime
 
 
 # namelist.py:286-316: UVFLX diffusion coefficient by resolution, then doubled
@@ -41,6 +42,9 @@ class Namelist:
     i_POTT_vert_turb: int = 0
     i_POTT_radiation: int = 0
     i_moist_main_switch: int = 0        # dyn_moist: QV/QC advection (namelist.py:80)
+    i_radiation: int = 0                # radiation scheme (namelist.py:104); implies i_POTT_radiation
+    rad_nth_hour: float = 3.9           # namelist.py:117
+    GMT_initialization: datetime = field(default_factory=lambda: datetime(2019, 1, 1, 0, 0, 0))   # namelist.py:21
     # diffusion (namelist.py:281-316); None = table value for dlat_deg
     UVFLX_dif_coef: float = None
     POTT_dif_coef: float = 1E-5
@@ -59,6 +63,8 @@ class Namelist:
             raise NotImplementedError('the HIP dycore computes in float64')
         if bool(self.i_UVFLX_vert_turb) != bool(self.i_POTT_vert_turb):
             raise NotImplementedError('i_UVFLX_vert_turb and i_POTT_vert_turb must agree')
+        if self.i_radiation:
+            self.i_POTT_radiation = 1
         if self.moist_dif_coef is None:
             self.moist_dif_coef = self.POTT_dif_coef
         if self.UVFLX_dif_coef is None:

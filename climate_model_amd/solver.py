@@ -1,19 +1,23 @@
 """Time loop around the dycore step, the way the reference's `solver.py:82-226` runs it.
 
 Per time step: status line every `nth_ts_print_diag` steps (io_functions.py:93-134, with the
-"MODEL CRASH" test), secondary diagnostics, turbulence if switched on, then the Matsuno step.
-Microphysics, surface, radiation and NetCDF output of the reference's loop are outside the hot
-path (out of scope) and have no slot here.
+"MODEL CRASH" test), secondary diagnostics, turbulence and radiation if switched on, then the
+Matsuno step.  Microphysics, the surface scheme and NetCDF output of the reference's loop are
+outside the hot path (out of scope) and have no slot here; the fields they would
+produce (QC, SOILTEMP, surface albedos) are inputs.
 
 `fused_steps > 1` hands up to that many Matsuno steps to the library in one call
 (dycore_step_matsuno) when no per-step physics is active; chunks end at the status lines.
 """
+from datetime import timedelta
+
 import numpy as np
 
 from .fields import HIP
 from .discretizations import DiagnosticsFactory
 from .matsuno import step_matsuno, step_matsuno_fused
 from .turbulence import Turbulence
+from .radiation import Radiation
 
 Diagnostics = DiagnosticsFactory(target=HIP)
 
@@ -60,8 +64,9 @@ def run(GR, F, nts, nth_ts_print_diag=50, fused=True, fused_steps=1, out=print):
     diagnostics tuples."""
     core = F.core
     turb = Turbulence(GR) if GR.nl.i_turb else None
+    rad = Radiation(GR, GR.nl.rad_nth_hour) if GR.nl.i_radiation else None
     fused_steps = max(1, int(fused_steps))
-    if turb is not None or not fused:
+    if turb is not None or rad is not None or not fused:
         fused_steps = 1
     log = []
 
@@ -76,6 +81,7 @@ def run(GR, F, nts, nth_ts_print_diag=50, fused=True, fused_steps=1, out=print):
         step = GR.ts + 1                      # the reference counts the step before running it
         # a fused chunk may not run past the next status line
         n = min(fused_steps, end - GR.ts, (step // nth_ts_print_diag + 1) * nth_ts_print_diag - step)
+        GR.GMT += timedelta(seconds=GR.dt * n)           # solver.py:88-90: clock first, then physics and dynamics
 
         GR.timer.start('diag')
         Diagnostics.secondary_diag(**F.get(Diagnostics.fields_secondary_diag, target=Diagnostics.target))
@@ -91,6 +97,13 @@ def run(GR, F, nts, nth_ts_print_diag=50, fused=True, fused_steps=1, out=print):
             GR.timer.start('turb')
             turb.compute_turbulence(GR, **F.get(turb.fields_main, target=turb.target))
             GR.timer.stop('turb')
+
+        if rad is not None:                   # solver.py:146-160 (surface scheme and microphysics, the two
+            GR.ts = step                      # slots before it, are inputs here: SOILTEMP, albedos, QC)
+            try:
+                rad.launch_radiation_calc(GR, F)
+            finally:
+                GR.ts = step - 1
 
         if fused:
             step_matsuno_fused(GR, F, n)

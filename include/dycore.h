@@ -119,6 +119,13 @@ int dycore_secondary_diag(dycore_t *h);
 /* Turbulence.compute_turbulence (turb_main.py:36-48, turb_compute.py:191-208): KMOM, KHEAT from
  * PHIVB, HSURF, PHI, QV, WINDX, WINDY, POTTVB, POTT */
 int dycore_compute_turbulence(dycore_t *h);
+/* rad_main.py:121-205 (Radiation.simple_radiation) for every owned column: longwave and, where MYSUN > 0,
+ * shortwave two-stream fluxes, net fluxes, flux divergences and the heating rate dPOTTdt_RAD.  Reads
+ * PHIVB, TAIR, RHO, QC, SOILTEMP (top soil level), SURFALBEDLW, SURFALBEDSW, MYSUN, SWINTOA; the caller
+ * supplies the spectral bins of rad_main.py:50-65 and the current solar constant
+ * (rad_shortwave.calc_current_solar_constant).  Needs i_radiation at dycore_create and nz >= 3. */
+int dycore_radiation(dycore_t *h, double solar_constant, int32_t nbins, const double *lambdas_center,
+                     const double *dlambdas);
 
 /* ---- the whole hot loop body: dyn_matsuno.py:28-131, nsteps times ------------------- */
 /* with_rho != 0 re-diagnoses RHO/RHOVB before each step (solver.py:99-101); needed only

@@ -103,6 +103,16 @@ void oracle_stage_primary_diag(const oracle_cfg *c, const oracle_grid *g, oracle
 void oracle_step_matsuno(const oracle_cfg *c, const oracle_grid *g, oracle_fields *f,
                          double dt, int nsteps, int with_rho);
 
+/* radiation columns (radiation_oracle.c): rad_main.py:121-205.  3-D arrays (nx+2, ny+2, nz | nz+1),
+ * 2-D ones (nx+2, ny+2, 1); interior columns only. */
+void oracle_radiation(int nx, int ny, int nz, const double *PHIVB, const double *TAIR, const double *RHO,
+                      const double *SOILTEMP, const double *ALB_LW, const double *ALB_SW, const double *QC,
+                      const double *MYSUN, const double *SWINTOA, double solar_constant,
+                      int nb, const double *lam, const double *dlam,
+                      double *LWFLXDO, double *LWFLXUP, double *SWDIFFLXDO, double *SWDIRFLXDO, double *SWFLXUP,
+                      double *SWFLXDO, double *LWFLXNET, double *SWFLXNET, double *SWFLXDIV, double *LWFLXDIV,
+                      double *TOTFLXDIV, double *dPOTTdt_RAD);
+
 #ifdef __cplusplus
 }
 #endif

@@ -59,6 +59,9 @@ CASES = {
     # turbulence scheme of the reference switched on (turb_main.Turbulence): KMOM/KHEAT are
     # produced by compute_turbulence from the full secondary diagnostics every step
     'g10x4_phys': dict(d=10, nz=4, steps=5,  snaps=(1, 5),     stages=True,  turb=False, turbulence=True),
+    # radiation columns (rad_main.Radiation.simple_radiation) on the model state after two steps
+    'g10x4_rad':  dict(d=10, nz=4, steps=2,  snaps=(),         stages=False, turb=False, radiation=(2001, 3, 21, 9, 30, 0)),
+    'g4x8_rad':   dict(d=4,  nz=8, steps=2,  snaps=(),         stages=False, turb=False, radiation=(1999, 12, 30, 22, 15, 40)),
 }
 
 NUMBA_SHIM = r'''
@@ -367,6 +370,47 @@ def run_case(name):
         print('[%s] kernel-level turbulence vector: %.0f%% at min, %.0f%% at max, %.0f%% in between' % (
             name, 100 * np.mean(inner == 1e-6), 100 * np.mean(inner == 0.01),
             100 * np.mean((inner > 1e-6) & (inner < 0.01))))
+
+    if cfg.get('radiation'):
+        # rad_main.py:121-205 through the reference's own class; the cython helpers of
+        # rad_longwave are absent, so its pure-numpy branch (run_cython = 0) computes the Planck
+        # sums and the matrix; scipy.linalg.solve_banded (LAPACK gbsv / gtsv) solves the columns
+        import datetime
+        import rad_longwave
+        import rad_main
+        rad_longwave.run_cython = 0
+        Diagnostics.secondary_diag(**F.get(Diagnostics.fields_secondary_diag, target=CPU))
+        RAD = rad_main.Radiation(GR)
+        GR.GMT = datetime.datetime(*cfg['radiation'])
+        r3 = np.random.default_rng(31)
+        fin = {n: F.host[n] for n in RAD.fields_radiation}
+        lat = GR.lat_rad[:, :, 0]
+        fin['SOILTEMP'][:] = np.nan
+        fin['SOILTEMP'][:, :, 0] = 255. + 45. * np.cos(lat) + r3.uniform(-3., 3., lat.shape)
+        fin['SURFALBEDLW'][:, :, 0] = r3.uniform(0., 0.3, lat.shape)
+        fin['SURFALBEDSW'][:, :, 0] = r3.uniform(0.05, 0.8, lat.shape)
+        fin['QC'][:] = r3.uniform(0., 0.004, fin['QC'].shape) * (r3.uniform(size=fin['QC'].shape) < 0.5)   # half clear, some above the 0.002 cap
+        outs = ['LWFLXDO', 'LWFLXUP', 'SWDIFFLXDO', 'SWDIRFLXDO', 'SWFLXUP', 'SWFLXDO', 'LWFLXNET', 'SWFLXNET',
+                'SWFLXDIV', 'LWFLXDIV', 'TOTFLXDIV', 'dPOTTdt_RAD']
+        for n in outs:
+            fin[n][:] = np.nan
+        for n in ('PHIVB', 'TAIR', 'RHO', 'SOILTEMP', 'SURFALBEDLW', 'SURFALBEDSW', 'QC'):
+            out['rad_in/' + n] = fin[n].copy()
+        RAD.simple_radiation(GR, **fin)
+        out['rad_in/SOLZEN'] = fin['SOLZEN'].copy()            # written in place by rad_solar_zenith_angle
+        out['rad_in/MYSUN'] = np.cos(fin['SOLZEN'])            # locals of simple_radiation (rad_main.py:133-137)
+        out['rad_in/MYSUN'][GR.ii, GR.jj, 0][out['rad_in/MYSUN'][GR.ii, GR.jj, 0] < 0] = 0   # a no-op on a copy, as in the reference
+        out['rad_in/SWINTOA'] = RAD.solar_constant * np.cos(fin['SOLZEN'])
+        out['rad_meta/solar_constant'] = np.float64(RAD.solar_constant)
+        out['rad_meta/gmt'] = np.array(cfg['radiation'], dtype=np.int64)
+        out['rad_meta/planck_lambdas_center'] = np.array(RAD.planck_lambdas_center, dtype=np.float64)
+        out['rad_meta/planck_dlambdas'] = np.array(RAD.planck_dlambdas, dtype=np.float64)
+        out['rad_meta/lon_rad'] = np.array(GR.lon_rad)
+        for n in outs:
+            out['rad_out/' + n] = fin[n].copy()
+        sun = out['rad_in/MYSUN'][1:-1, 1:-1, 0]
+        print('[%s] radiation vector: %.0f%% of the columns sunlit; dPOTTdt_RAD in [%.3e, %.3e] K/s' % (
+            name, 100 * np.mean(sun > 0), np.nanmin(fin['dPOTTdt_RAD'][1:-1, 1:-1]), np.nanmax(fin['dPOTTdt_RAD'][1:-1, 1:-1])))
 
     os.makedirs(GOLDEN, exist_ok=True)
     path = os.path.join(GOLDEN, name + '.npz')

@@ -174,3 +174,26 @@ def oracle_from_golden(z, tag=None, i_turb=1, i_moist=0):
             fields[n] = z[prefix + n]
     o = Oracle(nx, ny, nz, grid, fields, pair_top=float(z['meta/pair_top']), i_turb=i_turb, i_moist=i_moist)
     return o
+
+
+RAD_INPUTS = ['PHIVB', 'TAIR', 'RHO', 'SOILTEMP', 'SURFALBEDLW', 'SURFALBEDSW', 'QC', 'MYSUN', 'SWINTOA']
+RAD_OUTPUTS = ['LWFLXDO', 'LWFLXUP', 'SWDIFFLXDO', 'SWDIRFLXDO', 'SWFLXUP', 'SWFLXDO', 'LWFLXNET', 'SWFLXNET',
+               'SWFLXDIV', 'LWFLXDIV', 'TOTFLXDIV', 'dPOTTdt_RAD']
+RAD_NZS = ('LWFLXDO', 'LWFLXUP', 'SWDIFFLXDO', 'SWDIRFLXDO', 'SWFLXUP', 'SWFLXDO', 'LWFLXNET', 'SWFLXNET')
+
+
+def oracle_radiation(nx, ny, nz, inputs, solar_constant, lambdas_center, dlambdas):
+    """radiation_oracle.c on reference-layout arrays; returns the 12 output arrays (NaN outside the
+    interior columns)."""
+    lib = load_oracle()
+    dp = C.POINTER(C.c_double)
+    lib.oracle_radiation.restype = None
+    lib.oracle_radiation.argtypes = [C.c_int] * 3 + [dp] * 9 + [C.c_double, C.c_int, dp, dp] + [dp] * 12
+    a = {n: np.ascontiguousarray(inputs[n], dtype=np.float64) for n in RAD_INPUTS}
+    lam = np.ascontiguousarray(lambdas_center, dtype=np.float64)
+    dlam = np.ascontiguousarray(dlambdas, dtype=np.float64)
+    out = {n: np.full((nx + 2, ny + 2, nz + 1 if n in RAD_NZS else nz), np.nan) for n in RAD_OUTPUTS}
+    lib.oracle_radiation(nx, ny, nz, *[a[n].ctypes.data_as(dp) for n in RAD_INPUTS], float(solar_constant),
+                         lam.size, lam.ctypes.data_as(dp), dlam.ctypes.data_as(dp),
+                         *[out[n].ctypes.data_as(dp) for n in RAD_OUTPUTS])
+    return out

@@ -152,3 +152,23 @@ def test_secondary_diag_and_turbulence_scheme():
         assert np.max(np.abs(o2.F[n][m] - ref[m]) / np.abs(ref[m])) <= 1e-12
     inner = z['kturb_out/KMOM'][:, :, 1:-1]
     assert 0.2 < np.mean((inner > 1e-6) & (inner < 0.01)) < 0.8      # the vector leaves the clamps
+
+
+@pytest.mark.parametrize('case', ['g10x4_rad', 'g4x8_rad'])
+def test_radiation_oracle_vs_reference(case):
+    """radiation_oracle.c against the reference's Radiation.simple_radiation (rad_main.py:121-205) on a
+    model state: all twelve outputs, interior columns, day and night.  1e-12 relative: the restated
+    LAPACK solvers differ from the library build scipy calls by BLAS-internal rounding only."""
+    from oracle_binding import oracle_radiation, RAD_INPUTS, RAD_OUTPUTS
+    z = load_golden(case)
+    nx, ny, nz = int(z['meta/nx']), int(z['meta/ny']), int(z['meta/nz'])
+    inp = {n: z['rad_in/' + n] for n in RAD_INPUTS}
+    got = oracle_radiation(nx, ny, nz, inp, float(z['rad_meta/solar_constant']),
+                           z['rad_meta/planck_lambdas_center'], z['rad_meta/planck_dlambdas'])
+    sun = inp['MYSUN'][1:-1, 1:-1, 0] > 0
+    assert 0.3 < sun.mean() < 0.7          # both branches of the shortwave scheme are exercised
+    for n in RAD_OUTPUTS:
+        ref, g = z['rad_out/' + n][1:-1, 1:-1], got[n][1:-1, 1:-1]
+        assert np.isfinite(g).all(), n
+        scale = np.max(np.abs(ref))
+        assert np.max(np.abs(g - ref)) <= 1e-12 * scale, (n, np.max(np.abs(g - ref)) / scale)

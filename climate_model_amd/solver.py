@@ -59,9 +59,12 @@ def print_ts_info(GR, F, nth_ts_print_diag=50, out=print):
     return vmax, mean_wind, mean_temp, mean_colp
 
 
-def run(GR, F, nts, nth_ts_print_diag=50, fused=True, fused_steps=1, out=print):
+def run(GR, F, nts, nth_ts_print_diag=50, fused=True, fused_steps=1, out=print,
+        output_path=None, i_out_nth_hour=None, restart_dir=None, i_restart_nth_day=None):
     """solver.py:70-226.  F.host must already be uploaded.  Returns the list of printed
-    diagnostics tuples."""
+    diagnostics tuples.  With `output_path`, history files out%04d.nc are written every
+    `i_out_nth_hour` simulated hours (and constants.nc at the start) as io_nc_output.py does; with
+    `restart_dir`, a restart archive every `i_restart_nth_day` days (solver.py:156-177)."""
     core = F.core
     turb = Turbulence(GR) if GR.nl.i_turb else None
     rad = Radiation(GR, GR.nl.rad_nth_hour) if GR.nl.i_radiation else None
@@ -74,6 +77,19 @@ def run(GR, F, nts, nth_ts_print_diag=50, fused=True, fused_steps=1, out=print):
     Diagnostics.primary_diag(GR.GRF[Diagnostics.target],
                              **F.get(Diagnostics.fields_primary_diag, target=Diagnostics.target))
     GR.timer.stop('diag')
+
+    out_nth_ts = rst_nth_ts = 0
+    if output_path is not None:
+        from . import io_output
+        out_nth_ts = max(1, int((i_out_nth_hour or 12.) * 3600 / GR.dt))          # main_grid.py:268
+        io_output.constant_fields_to_NC(GR, F, output_path)                      # solver.py:66
+        if not hasattr(GR, 'nc_output_count'):
+            GR.nc_output_count = 0
+    if restart_dir is not None:
+        from . import io_output
+        rst_nth_ts = max(1, int((i_restart_nth_day or 1.) * 24 * 3600 / GR.dt))
+    if out_nth_ts or rst_nth_ts:
+        fused_steps = 1
 
     end = GR.ts + int(nts)
     while GR.ts < end:
@@ -109,6 +125,15 @@ def run(GR, F, nts, nth_ts_print_diag=50, fused=True, fused_steps=1, out=print):
             step_matsuno_fused(GR, F, n)
         else:
             step_matsuno(GR, F)
+
+        if out_nth_ts and GR.ts % out_nth_ts == 0:      # solver.py:152-164: the counter first, then the file
+            GR.timer.start('IO')
+            io_output.output_to_NC(GR, F, output_path, count=GR.nc_output_count + 1)
+            GR.timer.stop('IO')
+        if rst_nth_ts and GR.ts % rst_nth_ts == 0:
+            GR.timer.start('IO')
+            io_output.write_restart(GR, F, restart_dir)
+            GR.timer.stop('IO')
         GR.timer.stop('total')
     core.sync()
     return log

@@ -1,5 +1,7 @@
 """HIP path (through the C ABI) against the golden vectors and the CPU oracle.
 Needs a real MI355X: run with  pytest -m gpu."""
+import os
+
 import numpy as np
 import pytest
 
@@ -331,3 +333,49 @@ def test_linear_cell_launch_bitwise(case, i_moist, monkeypatch):
     for o in out[1:]:
         for n in out[0]:
             np.testing.assert_array_equal(out[0][n], o[n], err_msg=n)
+
+
+@pytest.mark.gpu
+def test_solver_history_restart_and_testsuite_criterion(tmp_path):
+    """solver.run writes the reference's history files and a restart archive; a run continued from the
+    archive ends where the uninterrupted one does (1e-11: the diagnostics are rebuilt by the stage kernel
+    instead of the fused one) and passes the reference's testsuite.py comparison (1e-4) on the files."""
+    from climate_model_amd import solver, io_output, Namelist, Grid, ModelFields, HipDycore
+    from climate_model_amd.synthetic import initialize_fields, initialize_moisture
+
+    def fresh():
+        GR = Grid(Namelist(nz=8, dlat_deg=4, dlon_deg=4, i_moist_main_switch=1))
+        core = HipDycore(GR.nx, GR.ny, GR.nz, i_moist=1)
+        core.set_grid(GR.GRF['HIP'])
+        return GR, ModelFields(GR, core), core
+
+    GR, F, core = fresh()
+    initialize_fields(GR, F)
+    initialize_moisture(GR, F)
+    F.copy_host_to_device()
+    hours = 3 * GR.dt / 3600.
+    solver.run(GR, F, 6, nth_ts_print_diag=1000, output_path=str(tmp_path / 'a'), i_out_nth_hour=hours)
+    assert sorted(os.listdir(tmp_path / 'a')) == ['constants.nc', 'out0001.nc', 'out0002.nc']
+    end_a = {n: core.download(n) for n in ('COLP', 'UWIND', 'VWIND', 'POTT', 'QV', 'QC')}
+    core.close()
+
+    GR, F, core = fresh()
+    initialize_fields(GR, F)
+    initialize_moisture(GR, F)
+    F.copy_host_to_device()
+    solver.run(GR, F, 3, nth_ts_print_diag=1000, output_path=str(tmp_path / 'b'), i_out_nth_hour=hours,
+               restart_dir=str(tmp_path / 'rst'), i_restart_nth_day=3 * GR.dt / 86400.)
+    gmt3 = GR.GMT
+    core.close()
+    GR, F, core = fresh()
+    io_output.load_restart(GR, F, str(tmp_path / 'rst' / '04_04_8.npz'))
+    assert GR.ts == 3 and GR.GMT == gmt3 and GR.nc_output_count == 1
+    solver.run(GR, F, 3, nth_ts_print_diag=1000, output_path=str(tmp_path / 'b'), i_out_nth_hour=hours)
+    assert GR.ts == 6 and os.path.exists(tmp_path / 'b' / 'out0002.nc')
+    for n, a in end_a.items():
+        err, ncmp, bad = rel_max_err(core.download(n), a, n, GR.nx, GR.ny)
+        assert bad == 0 and ncmp > 0 and err < (1e-9 if n == 'QC' else 1e-11), (n, err)
+    failed, devs = io_output.compare_outputs(str(tmp_path / 'a' / 'out0002.nc'), str(tmp_path / 'b' / 'out0002.nc'),
+                                             out=lambda s: None)
+    assert not failed and len(devs) >= 7
+    core.close()

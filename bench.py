@@ -51,6 +51,7 @@ def parse():
     ap.add_argument('--dlat', type=float, default=0.25, help='grid spacing in degrees (workload)')
     ap.add_argument('--nz', type=int, default=64)
     ap.add_argument('--moist', action='store_true', help='also advect QV/QC (dyn_moist; BASELINE config 5 without radiation); not the headline workload')
+    ap.add_argument('--radiation', action='store_true', help='radiation heating in the temperature tendency (i_POTT_radiation) with one radiation call before the timed steps; with --moist this is BASELINE config 5')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-seconds', type=float, default=15.0, help='CPU baseline budget')
     return ap.parse_args()
@@ -149,13 +150,26 @@ def main():
     if args.moist:
         initialize_moisture(GR, F)
         names += ['QV', 'QC', 'SLHFLX']
+    if args.radiation:
+        F.host['SOILTEMP'][:, :, 0] = 295 - np.sin(GR.lat_rad[:, :, 0]) ** 2 * 30         # srfc_main.py:57
+        F.host['SURFALBEDLW'][...] = 0.
+        F.host['SURFALBEDSW'][...] = 0.2
+        if not args.moist:
+            F.host['QC'][...] = 0.
+            names += ['QC']
+        names += ['SOILTEMP', 'SURFALBEDLW', 'SURFALBEDSW']
     state = {n: F.host[n] for n in names}
     core = HipDycore(GR.nx, L.ny(rank), GR.nz, pair_top=GR.nl.pair_top, device=local_rank,
-                     ny_global=GR.ny, j_offset=L.j_offset(rank), stream=stream.cuda_stream, i_moist=int(args.moist))
+                     ny_global=GR.ny, j_offset=L.j_offset(rank), stream=stream.cuda_stream, i_moist=int(args.moist),
+                     i_radiation=int(args.radiation))
     core.set_grid(band_grid_arrays(GR.GRF['HIP'], L, rank))
     for n in names:
         core.upload(n, L.slice_rows(state[n], rank, FIELD_TABLE[n][1]))
     core.primary_diag()
+    if args.radiation:
+        from climate_model_amd.radiation import Radiation, band_radiation
+        core.secondary_diag()
+        band_radiation(Radiation(GR), GR, L, rank, core)
     core.sync()
     bands = DistributedBands(core, L, rank, torch.device('cuda', local_rank)) if world > 1 else None
 
@@ -258,12 +272,12 @@ def main():
         'value': value, 'unit': 'cell-updates/s', 'n_gpus': world, 'steps': args.steps,
         'warmup': args.warmup, 'ms_per_step': ms_per_step, 'higher_is_better': True,
         'scaling': 'strong', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
-        'config': {'workload': ('moist (QV, QC advected) ' if args.moist else 'dry ') + 'hydrostatic dycore, Matsuno step, %g deg lat-lon (%d x %d) x %d sigma levels, '
+        'config': {'workload': ('moist (QV, QC advected) ' if args.moist else 'dry ') + ('with radiative heating ' if args.radiation else '') + 'hydrostatic dycore, Matsuno step, %g deg lat-lon (%d x %d) x %d sigma levels, '
                                'dt=%.4g s' % (args.dlat, GR.nx, GR.ny, GR.nz, GR.dt),
                    'cells': cells, 'parallelism': 'latitude bands x%d' % world if world > 1 else 'single GPU'},
         'roofline': roof,
     }
-    if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.moist:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.moist and not args.radiation:
         core.close()
         try:
             line['cpu_baseline'] = cpu_baseline(GR, state, args.cpu_seconds)

@@ -121,3 +121,16 @@ class Radiation:
         core.upload('MYSUN', mysun)
         core.upload('SWINTOA', swintoa)
         core.radiation(self.solar_constant, self.planck_lambdas_center, self.planck_dlambdas)
+
+
+def band_radiation(RAD, GR, layout, rank, core, current_GMT=None):
+    """The radiation call of one latitude band (climate_model_amd.bands): the scheme is column-local,
+    so a band needs no neighbour rows -- the astronomy is evaluated on the global grid `GR` and this
+    band's rows (halo rows included) are uploaded to its handle."""
+    gmt = copy.copy(current_GMT if current_GMT is not None else GR.GMT)
+    solzen = rad_solar_zenith_angle(GR, gmt, np.full((GR.nx + 2, GR.ny + 2, 1), np.nan))
+    RAD.solar_constant = calc_current_solar_constant(gmt)
+    core.upload('SOLZEN', layout.slice_rows(solzen, rank, 0))
+    core.upload('MYSUN', layout.slice_rows(np.cos(solzen), rank, 0))
+    core.upload('SWINTOA', layout.slice_rows(RAD.solar_constant * np.cos(solzen), rank, 0))
+    core.radiation(RAD.solar_constant, RAD.planck_lambdas_center, RAD.planck_dlambdas)

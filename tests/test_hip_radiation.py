@@ -159,3 +159,56 @@ def rad_solar_zenith_angle_host(GR, gmt):
 def solar_constant_host(gmt):
     from climate_model_amd.radiation import calc_current_solar_constant
     return calc_current_solar_constant(gmt)
+
+
+@pytest.mark.parametrize('nbands', [2, 5])
+def test_band_radiation_equals_single(nbands):
+    """Latitude bands: moist step + radiation heating per band = the single-domain run, bit for bit."""
+    import torch
+    from climate_model_amd.bands import BandLayout, LocalBands, band_grid_arrays, gather_global
+    from climate_model_amd.radiation import band_radiation
+    from climate_model_amd.fields import FIELD_TABLE
+    GR = Grid(Namelist(nz=8, dlat_deg=4, dlon_deg=4, i_radiation=1, i_moist_main_switch=1))
+    F = ModelFields(GR)
+    initialize_fields(GR, F)
+    initialize_moisture(GR, F)
+    F.host['SOILTEMP'][:, :, 0] = 295 - np.sin(GR.lat_rad[:, :, 0]) ** 2 * 30
+    F.host['SURFALBEDLW'][...] = 0.
+    F.host['SURFALBEDSW'][...] = 0.2
+    names = ['HSURF', 'COLP', 'UWIND', 'VWIND', 'POTT', 'WWIND', 'POTTVB', 'QV', 'QC', 'SLHFLX',
+             'SOILTEMP', 'SURFALBEDLW', 'SURFALBEDSW']
+    gmt = datetime.datetime(2019, 3, 1, 6, 0, 0)
+    RAD = Radiation(GR)
+    check = ['COLP', 'UWIND', 'VWIND', 'POTT', 'QV', 'dPOTTdt_RAD', 'LWFLXNET', 'SWFLXNET']
+
+    def prepare(core, grf, sl):
+        core.set_grid(grf)
+        for n in names:
+            core.upload(n, sl(F.host[n], n))
+        core.primary_diag()
+
+    single = HipDycore(GR.nx, GR.ny, GR.nz, i_radiation=1, i_moist=1)
+    prepare(single, GR.GRF['HIP'], lambda a, n: a)
+    single.secondary_diag()
+    L1 = BandLayout(GR.ny, 1)
+    band_radiation(RAD, GR, L1, 0, single, gmt)
+    single.step_matsuno(GR.dt, 2)
+    ref = {n: single.download(n) for n in check}
+    single.close()
+
+    L = BandLayout(GR.ny, nbands)
+    stream = torch.cuda.Stream()
+    cores = []
+    for r in range(nbands):
+        c = HipDycore(GR.nx, L.ny(r), GR.nz, ny_global=GR.ny, j_offset=L.j_offset(r), i_radiation=1, i_moist=1,
+                      stream=stream.cuda_stream)
+        prepare(c, band_grid_arrays(GR.GRF['HIP'], L, r), lambda a, n, r=r: L.slice_rows(a, r, FIELD_TABLE[n][1]))
+        c.secondary_diag()
+        band_radiation(RAD, GR, L, r, c, gmt)
+        cores.append(c)
+    LocalBands(cores, L, torch.device('cuda:0')).step_matsuno(GR.dt, 2)
+    for n in check:
+        got = gather_global(L, [c.download(n) for c in cores], n)
+        np.testing.assert_array_equal(got[1:-1, 1:-1], ref[n][1:-1, 1:-1], err_msg='%s (%d bands)' % (n, nbands))
+    for c in cores:
+        c.close()

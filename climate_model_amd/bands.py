@@ -106,15 +106,26 @@ class BandHalo:
         self._resolved = {}
         self.plan = {}
         moist = bool(getattr(core, 'i_moist', False))       # QV, QC travel with the state (phase B)
+        # a core whose fused step re-forms the mass fluxes from the winds (flux_from_winds) needs the
+        # 2-D column pressures at the u- / v-points where the other needs UFLX, VFLX (same rows), and
+        # the second v-row beyond its northern edge with the winds
+        fw = bool(getattr(core, 'flux_from_winds', False))
+        swap = {'UFLX': 'UCOL', 'VFLX': 'VCOL'} if fw else {}
         for ph in PHASES:
             extra = [('QV', None), ('QC', None)] if (moist and ph in ('B', 'B2')) else []
-            sn = [f for f, _ in SEND_NORTH[ph]] + [f for f, _ in extra]
-            ss = [f for f, _ in SEND_SOUTH[ph]] + [f for f, _ in extra]
+            north = [(swap.get(f, f), r) for f, r in SEND_NORTH[ph]]
+            south = [(swap.get(f, f), r) for f, r in SEND_SOUTH[ph]]
+            rs, rn = list(RECV_FROM_SOUTH[ph]), list(RECV_FROM_NORTH[ph])
+            if fw and ph in ('B', 'B1'):
+                south.append(('VWIND', 2))
+                rn.append('N+2')
+            sn = [f for f, _ in north] + [f for f, _ in extra]
+            ss = [f for f, _ in south] + [f for f, _ in extra]
             self.plan[ph] = dict(
-                send_north=(sn, _resolve([r for _, r in SEND_NORTH[ph]] + ['N'] * len(extra), ny)),
-                send_south=(ss, _resolve([r for _, r in SEND_SOUTH[ph]] + [1] * len(extra), ny)),
-                recv_south=(sn, _resolve(RECV_FROM_SOUTH[ph] + [0] * len(extra), ny)),      # neighbour's send_north list
-                recv_north=(ss, _resolve(RECV_FROM_NORTH[ph] + ['N+1'] * len(extra), ny)),  # neighbour's send_south list
+                send_north=(sn, _resolve([r for _, r in north] + ['N'] * len(extra), ny)),
+                send_south=(ss, _resolve([r for _, r in south] + [1] * len(extra), ny)),
+                recv_south=(sn, _resolve(rs + [0] * len(extra), ny)),      # neighbour's send_north list
+                recv_north=(ss, _resolve(rn + ['N+1'] * len(extra), ny)),  # neighbour's send_south list
             )
 
     def sizes(self, ph):

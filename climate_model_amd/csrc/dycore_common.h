@@ -41,6 +41,7 @@ struct Ptrs {
     // 3-D
     double *UWIND, *UWIND_OLD, *VWIND, *VWIND_OLD, *WWIND;
     double *UWIND_EST, *VWIND_EST, *POTT_EST;   // predictor state of the fused step (library scratch)
+    double *UCOL, *VCOL;                        // 2-D: column pressure at the u- / v-point, (COLP[i-1]+COLP)/2, (COLP[j-1]+COLP)/2
     double *POTT, *POTT_OLD, *POTTVB;
     double *UFLX, *VFLX, *FLXDIV;
     double *BFLX, *CFLX, *DFLX, *EFLX, *RFLX, *QFLX, *SFLX, *TFLX;

@@ -61,7 +61,7 @@ const FieldDesc kFields[] = {
     F_(COLP, 0, 0, 1), F_(COLP_OLD, 0, 0, 1), F_(COLP_NEW, 0, 0, 1), F_(dCOLPdt, 0, 0, 1), F_(HSURF, 0, 0, 1),
     F_(UWIND, 1, 0, 0), F_(UWIND_OLD, 1, 0, 0), F_(VWIND, 0, 1, 0), F_(VWIND_OLD, 0, 1, 0), F_(WWIND, 0, 0, -1),
     F_(POTT, 0, 0, 0), F_(POTT_OLD, 0, 0, 0), F_(POTTVB, 0, 0, -1),
-    F_(UWIND_EST, 1, 0, 0), F_(VWIND_EST, 0, 1, 0), F_(POTT_EST, 0, 0, 0),
+    F_(UWIND_EST, 1, 0, 0), F_(VWIND_EST, 0, 1, 0), F_(POTT_EST, 0, 0, 0), F_(UCOL, 1, 0, 1), F_(VCOL, 0, 1, 1),
     F_(UFLX, 1, 0, 0), F_(VFLX, 0, 1, 0), F_(FLXDIV, 0, 0, 0),
     F_(BFLX, 0, 0, 0), F_(CFLX, 1, 1, 0), F_(DFLX, 0, 1, 0), F_(EFLX, 0, 1, 0),
     F_(RFLX, 0, 0, 0), F_(QFLX, 1, 1, 0), F_(SFLX, 1, 0, 0), F_(TFLX, 1, 0, 0),
@@ -133,7 +133,11 @@ struct dycore {
     int grid_set = 0;
     bool fused = true;              // production kernels in dycore_step_matsuno (DYCORE_FUSED=0: stage kernels)
     bool lazy = true;               // fused step leaves FLXDIV / PHIVB to be derived on demand (DYCORE_LAZY=0: store them)
-    bool stale_flxdiv = false, stale_phivb = false;
+    int fw_mask = 7;                // DYCORE_FW_MASK (debug): 1 continuity stores no fluxes, 2 momentum, 4 temperature/moisture re-form them
+    bool lazy_flx = true;           // ... nor UFLX / VFLX: consumers re-form them from the winds (DYCORE_LAZY_FLX=0: store them)
+    bool stale_flxdiv = false, stale_phivb = false, stale_uvflx = false;
+    const double *flx_u = nullptr, *flx_v = nullptr;   // winds the last fused continuity evaluated on
+    bool winds_bc_dirty = true;     // UWIND / VWIND came from the host: their lateral BC images (column nx+2!) may be unset
     int n_cu = 256;                 // compute units of the device
     int cell_lin = -1;              // DYCORE_CELL_LINEAR: column-kernel launch, bit 0 = cell runs, bit 1 = XCD-aware order (default 3 or 2)
     int mom_ks = 0;                 // DYCORE_MOM_KS: force the level chunks per momentum tile (1, 2, 4)
@@ -234,9 +238,14 @@ int launch_check(const char *what)
 
 // lateral halo (misc_boundaries.py:22-42) of up to 12 fields in one launch
 struct HaloSpec { double *ptr; int stgx, stgy, nk; };
+int do_halo_noscope(dycore *h, const std::vector<HaloSpec> &fields);
 int do_halo(dycore *h, const std::vector<HaloSpec> &fields)
 {
     Scope s(h, K_HALO_MULTI);
+    return do_halo_noscope(h, fields);
+}
+int do_halo_noscope(dycore *h, const std::vector<HaloSpec> &fields)
+{
     HaloList l;
     l.n = 0;
     int maxk = 1, maxcells = 0;
@@ -355,34 +364,64 @@ int do_copy(dycore *h, double *dst, const double *src, size_t elems)
     return 0;
 }
 
-// continuity of the fused step: running sums in registers, FLXDIV not stored
+bool fused_path(const dycore *h);
+// continuity of the fused step: running sums in registers, FLXDIV (and UFLX, VFLX) not stored
+bool flux_from_winds(const dycore *h)
+{
+    const int nz = h->g.nz;
+    return h->lazy && h->lazy_flx && h->mom_dma == 1 && nz <= DMAXZ && (nz == 8 || nz == 16 || nz == 32 || nz == 64);
+}
 int do_continuity_fused(dycore *h, const Ptrs &p, double dt)
 {
     const int nz = h->g.nz;
     if (!h->lazy || !(nz == 8 || nz == 16 || nz == 32 || nz == 64)) return do_continuity(h, p, dt);
+    const bool fw = flux_from_winds(h) && (h->fw_mask & 1);
+    if (flux_from_winds(h) && h->winds_bc_dirty) {
+        // Re-forming UFLX(nx+2), VFLX(ny+2) reads the winds' own boundary images.  The reference's host-side
+        // initialisation leaves column nx+2 of x-staggered arrays unset (main_grid.py:317-357) and reaches it
+        // only through the exchange of UFLX; apply the winds' lateral BC (misc_boundaries.py:22-42) once.
+        int rc = do_halo(h, {{const_cast<double *>(p.UWIND), 1, 0, nz}, {const_cast<double *>(p.VWIND), 0, 1, nz}});
+        if (rc) return rc;
+        h->winds_bc_dirty = false;
+    }
     {
         Scope s(h, K_CONT_REG);
         const dim3 gr = grid_cells(h), bl(TI, TJ);
         const int lin = cells_linear(h);
+#define CONT_LAUNCH(NZ_)                                                                                  \
+        if (fw) hipLaunchKernelGGL((k_continuity_reg<NZ_, false>), gr, bl, 0, h->stream, h->g, p, dt, lin); \
+        else hipLaunchKernelGGL((k_continuity_reg<NZ_, true>), gr, bl, 0, h->stream, h->g, p, dt, lin);
         switch (nz) {
-        case 8: hipLaunchKernelGGL(k_continuity_reg<8>, gr, bl, 0, h->stream, h->g, p, dt, lin); break;
-        case 16: hipLaunchKernelGGL(k_continuity_reg<16>, gr, bl, 0, h->stream, h->g, p, dt, lin); break;
-        case 32: hipLaunchKernelGGL(k_continuity_reg<32>, gr, bl, 0, h->stream, h->g, p, dt, lin); break;
-        default: hipLaunchKernelGGL(k_continuity_reg<64>, gr, bl, 0, h->stream, h->g, p, dt, lin); break;
+        case 8: CONT_LAUNCH(8) break;
+        case 16: CONT_LAUNCH(16) break;
+        case 32: CONT_LAUNCH(32) break;
+        default: CONT_LAUNCH(64) break;
         }
+#undef CONT_LAUNCH
         int rc = launch_check("k_continuity_reg");
         if (rc) return rc;
     }
     h->stale_flxdiv = true;
+    if (fw) {
+        h->stale_uvflx = true;
+        h->flx_u = p.UWIND; h->flx_v = p.VWIND;
+        return do_halo(h, {{p.UCOL, 1, 0, 1}, {p.VCOL, 0, 1, 1}, {p.WWIND, 0, 0, nz + 1}, {p.COLP_NEW, 0, 0, 1}});
+    }
     return do_halo(h, {{p.UFLX, 1, 0, nz}, {p.VFLX, 0, 1, nz}, {p.WWIND, 0, 0, nz + 1}, {p.COLP_NEW, 0, 0, 1}});
 }
 // bring the on-demand fields up to date (called wherever they can be observed)
 int refresh_lazy(dycore *h)
 {
-    if (!h->stale_flxdiv && !h->stale_phivb) return 0;
+    if (!h->stale_flxdiv && !h->stale_phivb && !h->stale_uvflx) return 0;
     int rc = join_side(h);
     if (rc) return rc;
     Scope s(h, K_DERIVE);
+    if (h->stale_uvflx) {
+        hipLaunchKernelGGL(k_derive_uvflx, grid_for(h->g, h->g.nx, h->g.ny), dim3(TI, TJ), 0, h->stream, h->g, h->p, h->flx_u, h->flx_v);
+        if ((rc = launch_check("k_derive_uvflx"))) return rc;
+        h->stale_uvflx = false;
+        if ((rc = do_halo_noscope(h, {{h->p.UFLX, 1, 0, h->g.nz}, {h->p.VFLX, 0, 1, h->g.nz}}))) return rc;
+    }
     if (h->stale_flxdiv) {
         hipLaunchKernelGGL(k_derive_flxdiv, grid_for(h->g, h->g.nx, h->g.ny), dim3(TI, TJ), 0, h->stream, h->g, h->p);
         if ((rc = launch_check("k_derive_flxdiv"))) return rc;
@@ -457,8 +496,11 @@ int do_momentum_fused(dycore *h, const Ptrs &p, const double *u_old, const doubl
         }
         const dim3 gr2(8 * ((gbx * trows.n * ks + 7) / 8)), blk(FTI, tj);
         const bool cur = (u_old == p.UWIND);
-        if (cur) hipLaunchKernelGGL((k_momentum_dma<true, tj>), gr2, blk, dma_lds_bytes(tj), h->stream, h->g, p, gbx, trows, ks, jv_lo, u_old, v_old, u_out, v_out, dt);
-        else hipLaunchKernelGGL((k_momentum_dma<false, tj>), gr2, blk, dma_lds_bytes(tj), h->stream, h->g, p, gbx, trows, ks, jv_lo, u_old, v_old, u_out, v_out, dt);
+        const bool fw = flux_from_winds(h) && (h->fw_mask & 2);
+#define MOM_LAUNCH(CUR_, FW_) hipLaunchKernelGGL((k_momentum_dma<CUR_, tj, FW_>), gr2, blk, dma_lds_bytes(tj, FW_), h->stream, h->g, p, gbx, trows, ks, jv_lo, u_old, v_old, u_out, v_out, dt)
+        if (cur) { if (fw) MOM_LAUNCH(true, true); else MOM_LAUNCH(true, false); }
+        else { if (fw) MOM_LAUNCH(false, true); else MOM_LAUNCH(false, false); }
+#undef MOM_LAUNCH
     } else if (u_out)
         hipLaunchKernelGGL(k_momentum_fused<true>, gr, bl, 0, h->stream, h->g, p, gbx, gby, jv_lo, u_old, v_old, u_out, v_out, dt);
     else
@@ -469,10 +511,13 @@ int do_pott_fused(dycore *h, const Ptrs &p, const double *pott_old, double *pott
 {
     Scope s(h, K_POTT_FUSED);
     if (h->lazy) {
-        hipLaunchKernelGGL(k_pott_fused<false>, grid_cells(h), dim3(TI, TJ), 0, h->stream, h->g, p, pott_old, pott_out, dt, cells_linear(h));
+        if (flux_from_winds(h) && (h->fw_mask & 4))
+            hipLaunchKernelGGL((k_pott_fused<false, true>), grid_cells(h), dim3(TI, TJ), 0, h->stream, h->g, p, pott_old, pott_out, dt, cells_linear(h));
+        else
+            hipLaunchKernelGGL((k_pott_fused<false, false>), grid_cells(h), dim3(TI, TJ), 0, h->stream, h->g, p, pott_old, pott_out, dt, cells_linear(h));
         h->stale_phivb = true;
     } else
-        hipLaunchKernelGGL(k_pott_fused<true>, grid_cells(h), dim3(TI, TJ), 0, h->stream, h->g, p, pott_old, pott_out, dt, cells_linear(h));
+        hipLaunchKernelGGL((k_pott_fused<true, false>), grid_cells(h), dim3(TI, TJ), 0, h->stream, h->g, p, pott_old, pott_out, dt, cells_linear(h));
     return launch_check("k_pott_fused");
 }
 // dQVdt, dQCdt (stage) or the new QV, QC directly (fused): dyn_moist.py
@@ -483,6 +528,7 @@ int do_moist(dycore *h, const Ptrs &p, const double *qv_old, const double *qc_ol
     const int lin = cells_linear(h);
     if (qv_out) {
         if (h->g.i_turb) hipLaunchKernelGGL((k_moist<true, true>), gr, bl, 0, h->stream, h->g, p, qv_old, qc_old, qv_out, qc_out, dt, lin);
+        else if (fused_path(h) && flux_from_winds(h) && (h->fw_mask & 4)) hipLaunchKernelGGL((k_moist<false, true, true>), gr, bl, 0, h->stream, h->g, p, qv_old, qc_old, qv_out, qc_out, dt, lin);
         else hipLaunchKernelGGL((k_moist<false, true>), gr, bl, 0, h->stream, h->g, p, qv_old, qc_old, qv_out, qc_out, dt, lin);
     } else {
         if (h->g.i_turb) hipLaunchKernelGGL((k_moist<true, false>), gr, bl, 0, h->stream, h->g, p, qv_old, qc_old, qv_out, qc_out, dt, lin);
@@ -691,6 +737,8 @@ int dycore_create(const DycoreConfig *cfg, dycore_t **out)
     if (const char *e = getenv("DYCORE_FUSED")) h->fused = atoi(e) != 0;
     if (const char *e = getenv("DYCORE_MOM_DMA")) h->mom_dma = atoi(e);
     if (const char *e = getenv("DYCORE_LAZY")) h->lazy = atoi(e) != 0;
+    if (const char *e = getenv("DYCORE_LAZY_FLX")) h->lazy_flx = atoi(e) != 0;
+    if (const char *e = getenv("DYCORE_FW_MASK")) h->fw_mask = atoi(e);
     if (const char *e = getenv("DYCORE_MOM_KS")) h->mom_ks = atoi(e);
     if (const char *e = getenv("DYCORE_CELL_LINEAR")) h->cell_lin = atoi(e);
     {
@@ -698,9 +746,12 @@ int dycore_create(const DycoreConfig *cfg, dycore_t **out)
         if (hipGetDeviceProperties(&prop, cfg->device) == hipSuccess && prop.multiProcessorCount > 0) h->n_cu = prop.multiProcessorCount;
     }
     {   // the LDS-DMA kernel double-buffers 122 KB of tiles: raise the dynamic-LDS limit once
-        hipError_t e1 = hipFuncSetAttribute((const void *)k_momentum_dma<true, FTJ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dma_lds_bytes(FTJ));
-        hipError_t e2 = hipFuncSetAttribute((const void *)k_momentum_dma<false, FTJ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dma_lds_bytes(FTJ));
+        hipError_t e1 = hipFuncSetAttribute((const void *)k_momentum_dma<true, FTJ, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dma_lds_bytes(FTJ, false));
+        hipError_t e2 = hipFuncSetAttribute((const void *)k_momentum_dma<false, FTJ, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dma_lds_bytes(FTJ, false));
+        hipError_t e3 = hipFuncSetAttribute((const void *)k_momentum_dma<true, FTJ, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dma_lds_bytes(FTJ, true));
+        hipError_t e4 = hipFuncSetAttribute((const void *)k_momentum_dma<false, FTJ, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dma_lds_bytes(FTJ, true));
         if (e1 != hipSuccess || e2 != hipSuccess) { (void)hipGetLastError(); h->mom_dma = 0; }
+        if (e3 != hipSuccess || e4 != hipSuccess) { (void)hipGetLastError(); h->lazy_flx = false; }
     }
     if (cfg->stream) h->stream = (hipStream_t)cfg->stream;
     else {
@@ -793,6 +844,7 @@ int dycore_use_stream(dycore_t *h, void *stream)
 }
 void *dycore_get_stream(dycore_t *h) { return h ? (void *)h->home : nullptr; }
 int dycore_overlap_parts(dycore_t *h) { return h && fused_path(h) ? 1 : 0; }
+int dycore_flux_from_winds(dycore_t *h) { return h && fused_path(h) && flux_from_winds(h) ? 1 : 0; }
 int dycore_sync(dycore_t *h)
 {
     if (!h) return fail(DYCORE_EINVAL, "null handle");
@@ -857,6 +909,9 @@ int dycore_upload(dycore_t *h, const char *name, const double *host)
     int rc = find_field(h, name, &d);
     if (rc) return rc;
     if (!host) return fail(DYCORE_EINVAL, "null host pointer");
+    if (d->member == &Ptrs::UWIND || d->member == &Ptrs::VWIND) h->winds_bc_dirty = true;
+    if (d->member == &Ptrs::UFLX || d->member == &Ptrs::VFLX || d->member == &Ptrs::FLXDIV || d->member == &Ptrs::PHIVB)
+        if ((rc = refresh_lazy(h))) return rc;      // a caller's value must not be overwritten by a later derivation
     const Geo &g = h->g;
     const int n0 = g.nx + 2 + d->stgx, n1 = g.ny + 2 + d->stgy, n2 = h->nk_of(d->nk);
     const size_t n = (size_t)n0 * n1 * n2;

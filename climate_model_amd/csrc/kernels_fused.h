@@ -312,12 +312,21 @@ __global__ __launch_bounds__(FNT) void k_momentum_fused(Geo g, Ptrs p, int gbx, 
 // step-start winds are staged as two more (interior-height) tiles.
 constexpr int DMAXZ = 160;                        // levels the LDS copy of the 1-D constants can hold
 // two buffers of 9 full tiles (tj+3 rows) + 2 step-start tiles (tj rows), then the 1-D constants
-constexpr size_t dma_lds_bytes(int tj) { return (2 * (size_t)(FNF * FTW * (tj + 3) + 2 * FTW * tj) + 3 * DMAXZ + 2) * sizeof(double); }
+// (+ four 2-D factor tiles when the fluxes are re-formed from the winds)
+constexpr size_t dma_lds_bytes(int tj, bool from_winds)
+{
+    return (2 * (size_t)(FNF * FTW * (tj + 3) + 2 * FTW * tj) + 3 * DMAXZ + 2 + (from_winds ? 4 * FTW * (tj + 3) : 0)) * sizeof(double);
+}
 
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef const __attribute__((address_space(1))) void gbl_void_t;
 
-template <bool OLD_IS_CUR, int TJ>
+// FROM_WINDS: UFLX and VFLX are not staged (k_continuity_reg<., false> does not store them); their
+// tiles are re-formed in LDS every level from the UWIND / VWIND tiles and four per-tile 2-D factor
+// tiles, UFLX = UCOL * UWIND * dyis and VFLX = VCOL * VWIND * dxjs (operand order of the continuity
+// kernel, so the values are the ones it would have stored): 7 instead of 9 fields through the DMA
+// for one more barrier per level.
+template <bool OLD_IS_CUR, int TJ, bool FROM_WINDS>
 __global__ __launch_bounds__(FTI *TJ) void k_momentum_dma(Geo g, Ptrs p, int gbx, RowSet trows, int ksplit, int jv_lo,
                                                       const double *u_old, const double *v_old,
                                                       double *u_out, double *v_out, double dt)
@@ -380,7 +389,8 @@ __global__ __launch_bounds__(FTI *TJ) void k_momentum_dma(Geo g, Ptrs p, int gbx
             if (dma_on) {
                 // rows a field really needs below j-1: UFLX, winds, WWIND j+1 (TJ+2 rows), VFLX j+2
                 // (all TJ+3), PHI/POTT/PVTF/PVTFVB only j-1 and j (TJ+1): skip the chunks beyond
-                constexpr int rows_f[FNF] = {TJ + 2, TJ + 3, TJ + 2, TJ + 2, TJ + 2, TJ + 1, TJ + 1, TJ + 1, TJ + 1};
+                constexpr int rows_f[FNF] = {FROM_WINDS ? 0 : TJ + 2, FROM_WINDS ? 0 : TJ + 3, TJ + 2, FROM_WINDS ? TJ + 3 : TJ + 2,
+                                             TJ + 2, TJ + 1, TJ + 1, TJ + 1, TJ + 1};
                 const int ch = wave * 64 + lane;
 #pragma unroll
                 for (int f = 0; f < FNF; f++) {
@@ -481,12 +491,38 @@ __global__ __launch_bounds__(FTI *TJ) void k_momentum_dma(Geo g, Ptrs p, int gbx
         c_svb[t] = p.sigma_vb[t];
         if (t < nz) { c_ds[t] = p.dsigma[t]; c_dif[t] = p.UVFLX_dif_coef[t]; }
     }
+    // 2-D factor tiles, same element -> grid cell map as the DMA chunks
+    double *fac = cst + 3 * DMAXZ + 2;
+    if (FROM_WINDS) {
+        for (int e = tid; e < TN; e += NT) {
+            const int r = e / FTW, cc = e - r * FTW, c2 = cc & ~1;
+            const int gi = min(i0 - 2 + c2, P - 2) + (cc - c2);
+            const int o = min(j0 - 1 + r, g.NJ - 1) * P + gi;
+            fac[e] = p.UCOL[o];
+            // the reference never fills column nx+2 of its x-staggered grid arrays (main_grid.py:317-357):
+            // take the periodic image the UFLX halo copy would have delivered
+            fac[TN + e] = p.dyis[gi == g.nx + 2 ? o - g.nx : o];
+            fac[2 * TN + e] = p.VCOL[o];
+            fac[3 * TN + e] = p.dxjs[o];
+        }
+    }
     issue(k0, k0 & 1);
     __syncthreads();
 #pragma unroll 1
     for (int k = k0; k < k1; k++) {
         if (k + 1 < k1) issue(k + 1, (k + 1) & 1);
-        const double *buf = dsm + (k & 1) * BUF;
+        double *wbuf = dsm + (k & 1) * BUF;
+        if (FROM_WINDS) {           // flux tiles of level k into the (unused) UFLX / VFLX slots of this buffer
+            for (int e = tid; e < TN; e += NT) {
+                if (e < (TJ + 2) * FTW) wbuf[S_UF * TN + e] = fac[e] * wbuf[S_UW * TN + e] * fac[TN + e];
+                wbuf[S_VF * TN + e] = fac[2 * TN + e] * wbuf[S_VW * TN + e] * fac[3 * TN + e];
+            }
+            // workgroup barrier on the LDS writes only: the DMA just issued must stay in flight
+            // (__syncthreads would wait vmcnt(0))
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        }
+        const double *buf = wbuf;
         if (active) {
             const double ds = c_ds[k];
             double uf[3][4], vf[4][3], uw[3][3], vw[3][3];
@@ -624,7 +660,11 @@ __global__ __launch_bounds__(FTI *TJ) void k_momentum_dma(Geo g, Ptrs p, int gbx
 // in registers (NZ is a compile-time constant, both level loops fully unrolled), so FLXDIV
 // makes no round trip through HBM: 2 reads + 3 writes per cell, the compulsory minimum of
 // this stage.  FLXDIV itself is not stored (k_derive_flxdiv re-derives it on demand).
-template <int NZ>
+// STORE_FLX = false: UFLX and VFLX are not written either -- every consumer of the fused step
+// re-forms them from the winds it reads anyway and the 2-D factors UCOL, VCOL written here
+// (UFLX = UCOL * UWIND * dyis, VFLX = VCOL * VWIND * dxjs, the same operations in the same order),
+// which leaves WWIND as the only 3-D output: 2 reads + 1 write per cell.
+template <int NZ, bool STORE_FLX>
 __global__ __launch_bounds__(TI *TJ) void k_continuity_reg(Geo g, Ptrs p, double dt, int lin)
 {
     int i, j;
@@ -651,8 +691,10 @@ __global__ __launch_bounds__(TI *TJ) void k_continuity_reg(Geo g, Ptrs p, double
         const double uflx_ip1 = (colp + c_ip1) / 2.0 * uw[q + 1] * dy_ip1;
         const double vflx_j = (c_jm1 + colp) / 2.0 * vw[q] * dx_j;
         const double vflx_jp1 = (colp + c_jp1) / 2.0 * vw[q + g.P] * dx_jp1;
-        uflx[q] = uflx_i;
-        vflx[q] = vflx_j;
+        if (STORE_FLX) {
+            uflx[q] = uflx_i;
+            vflx[q] = vflx_j;
+        }
         const double div = (uflx_ip1 - uflx_i + vflx_jp1 - vflx_j) * p.dsigma[k] / area;
         pre[k] = run;
         run += div;
@@ -661,6 +703,8 @@ __global__ __launch_bounds__(TI *TJ) void k_continuity_reg(Geo g, Ptrs p, double
     const double colp_new = p.COLP_OLD[c] + dt * dcolpdt;
     p.dCOLPdt[c] = dcolpdt;
     p.COLP_NEW[c] = colp_new;
+    p.UCOL[c] = (c_im1 + colp) / 2.0;
+    p.VCOL[c] = (c_jm1 + colp) / 2.0;
     p.WWIND[c] = 0.0;
     p.WWIND[c + (size_t)NZ * g.plane] = 0.0;
 #pragma unroll
@@ -669,8 +713,21 @@ __global__ __launch_bounds__(TI *TJ) void k_continuity_reg(Geo g, Ptrs p, double
 }
 
 // Fields the fused step does not store, re-derived when somebody asks for them:
+// UFLX, VFLX (dyn_continuity.py:40-45) from the winds the last continuity call read and UCOL, VCOL;
 // FLXDIV (dyn_continuity.py:46-47) from UFLX, VFLX;  PHIVB (dyn_diagnostics.py:160-174) from
 // PHI, POTT, PVTF, PVTFVB, HSURF -- whole array including halos, like diag_PHI.
+__global__ __launch_bounds__(TI *TJ) void k_derive_uvflx(Geo g, Ptrs p, const double *uw, const double *vw)
+{
+    DYC_IJ(1, 1)
+    if (i > g.nx || j > g.ny) return;
+    const size_t c = at2(g, i, j);
+    const double ucol = p.UCOL[c], vcol = p.VCOL[c], dy = p.dyis[c], dx = p.dxjs[c];
+    for (int k = 0; k < g.nz; k++) {
+        const size_t q = c + (size_t)k * g.plane;
+        p.UFLX[q] = ucol * uw[q] * dy;
+        p.VFLX[q] = vcol * vw[q] * dx;
+    }
+}
 __global__ __launch_bounds__(TI *TJ) void k_derive_flxdiv(Geo g, Ptrs p)
 {
     DYC_IJ(1, 1)
@@ -703,7 +760,10 @@ __global__ __launch_bounds__(TI *TJ) void k_derive_phivb(Geo g, Ptrs p)
 // cells; halos of every output by k_halo_multi afterwards).  POTTVB is updated in place: interface k+1 is rewritten only after its old
 // value has been consumed by the vertical advection of levels k+1 and k.
 // Dry dycore only (the turbulence-coupled path uses the stage kernels).
-template <bool WRITE_PHIVB>
+// FROM_WINDS: the mass fluxes are re-formed from UWIND, VWIND and the column pressures
+// (k_continuity_reg<., false> does not store UFLX, VFLX); the per-column metric factors live in
+// LDS so that the kernel keeps its three wavefronts per SIMD.
+template <bool WRITE_PHIVB, bool FROM_WINDS>
 __global__ __launch_bounds__(TI *TJ) void k_pott_fused(Geo g, Ptrs p, const double *pott_old, double *pott_out, double dt, int lin)
 {
     int i, j;
@@ -730,12 +790,18 @@ __global__ __launch_bounds__(TI *TJ) void k_pott_fused(Geo g, Ptrs p, const doub
     // enough: the kernel is bound by fp64 instruction issue (~250 instructions per level, pow and
     // five divisions), and rings of 2-4 levels in flight cost the third wave per SIMD and ran
     // 5-15 % slower (profiles/r01_notes.md)
+    __shared__ double s_met[FROM_WINDS ? 4 : 1][TI * TJ];
+    const int st = threadIdx.y * TI + threadIdx.x;
+    if (FROM_WINDS) {
+        s_met[0][st] = p.dyis[c]; s_met[1][st] = p.dyis[c + 1]; s_met[2][st] = p.dxjs[c]; s_met[3][st] = p.dxjs[c + P];
+    }
+    const double *fu = FROM_WINDS ? p.UWIND : p.UFLX, *fv = FROM_WINDS ? p.VWIND : p.VFLX;
     struct In { double pt, im1, ip1, jm1, jp1, uf, uf1, vf, vf1, w, pvb, po; };
     auto load = [&](int k) {
         In r;
         const size_t q = c + (size_t)k * g.plane;
         r.pt = p.POTT[q]; r.im1 = p.POTT[q - 1]; r.ip1 = p.POTT[q + 1]; r.jm1 = p.POTT[q - P]; r.jp1 = p.POTT[q + P];
-        r.uf = p.UFLX[q]; r.uf1 = p.UFLX[q + 1]; r.vf = p.VFLX[q]; r.vf1 = p.VFLX[q + P];
+        r.uf = fu[q]; r.uf1 = fu[q + 1]; r.vf = fv[q]; r.vf1 = fv[q + P];
         r.w = p.WWIND[q]; r.pvb = p.POTTVB[q]; r.po = pott_old[q];
         return r;
     };
@@ -743,8 +809,14 @@ __global__ __launch_bounds__(TI *TJ) void k_pott_fused(Geo g, Ptrs p, const doub
 #pragma unroll 1
     for (int k = nz - 1; k >= 0; k--) {
         const size_t q = c + (size_t)k * g.plane;
-        const In cur = nx_;
+        In cur = nx_;
         if (k > 0) nx_ = load(k - 1);
+        if (FROM_WINDS) {           // dyn_continuity.py:40-45, operand order of k_continuity_reg
+            cur.uf = (c_im1 + colp) / 2.0 * cur.uf * s_met[0][st];
+            cur.uf1 = (colp + c_ip1) / 2.0 * cur.uf1 * s_met[1][st];
+            cur.vf = (c_jm1 + colp) / 2.0 * cur.vf * s_met[2][st];
+            cur.vf1 = (colp + c_jp1) / 2.0 * cur.vf1 * s_met[3][st];
+        }
         const double pt = cur.pt;
         const double p_im1 = cur.im1, p_ip1 = cur.ip1, p_jm1 = cur.jm1, p_jp1 = cur.jp1;
         const double ds = p.dsigma[k];

@@ -510,7 +510,9 @@ __device__ __forceinline__ double turb_flux(double phi, double phi_kp1, double p
 // write the new QV/QC to q?_out instead of storing the tendencies (fused production path).
 // The interface value below the bottom level is an unchecked out-of-range read in the
 // reference, multiplied by WWIND[nz] = 0: taken as 0 here.
-template <bool TURB, bool EULER>
+// FROM_WINDS: UFLX, VFLX are re-formed from the winds (fused step without stored fluxes, see
+// k_continuity_reg).
+template <bool TURB, bool EULER, bool FROM_WINDS = false>
 __global__ __launch_bounds__(TI *TJ) void k_moist(Geo g, Ptrs p, const double *qv_old, const double *qc_old,
                                                   double *qv_out, double *qc_out, double dt, int lin)
 {
@@ -528,11 +530,17 @@ __global__ __launch_bounds__(TI *TJ) void k_moist(Geo g, Ptrs p, const double *q
     double qv_k = p.QV[c], qc_k = p.QC[c];
     // software pipeline as in k_pott_fused: the inputs of level k+1 are requested before level k is
     // computed, so the HBM latency overlaps the two logarithms per interface
+    __shared__ double s_met[FROM_WINDS ? 4 : 1][TI * TJ];
+    const int st = threadIdx.y * TI + threadIdx.x;
+    if (FROM_WINDS) {
+        s_met[0][st] = p.dyis[c]; s_met[1][st] = p.dyis[c + 1]; s_met[2][st] = p.dxjs[c]; s_met[3][st] = p.dxjs[c + P];
+    }
+    const double *fu = FROM_WINDS ? p.UWIND : p.UFLX, *fv = FROM_WINDS ? p.VWIND : p.VFLX;
     struct In { double uf, uf1, vf, vf1, w1, qv1, qc1, v_im1, v_ip1, v_jm1, v_jp1, c_im1, c_ip1, c_jm1, c_jp1, vo, co; };
     auto load = [&](int k) {
         In r;
         const size_t q = c + (size_t)k * g.plane;
-        r.uf = p.UFLX[q]; r.uf1 = p.UFLX[q + 1]; r.vf = p.VFLX[q]; r.vf1 = p.VFLX[q + P];
+        r.uf = fu[q]; r.uf1 = fu[q + 1]; r.vf = fv[q]; r.vf1 = fv[q + P];
         const bool last = (k == nz - 1);
         r.w1 = last ? 0.0 : p.WWIND[q + g.plane];
         r.qv1 = last ? 0.0 : p.QV[q + g.plane];
@@ -550,7 +558,13 @@ __global__ __launch_bounds__(TI *TJ) void k_moist(Geo g, Ptrs p, const double *q
         const In cur = nxt;
         if (k + 1 < nz) nxt = load(k + 1);
         const double ds = p.dsigma[k], dif = p.moist_dif_coef[k];
-        const double uflx = cur.uf, uflx_ip1 = cur.uf1, vflx = cur.vf, vflx_jp1 = cur.vf1;
+        double uflx = cur.uf, uflx_ip1 = cur.uf1, vflx = cur.vf, vflx_jp1 = cur.vf1;
+        if (FROM_WINDS) {           // dyn_continuity.py:40-45, operand order of k_continuity_reg
+            uflx = (c_im1 + colp) / 2.0 * uflx * s_met[0][st];
+            uflx_ip1 = (colp + c_ip1) / 2.0 * uflx_ip1 * s_met[1][st];
+            vflx = (c_jm1 + colp) / 2.0 * vflx * s_met[2][st];
+            vflx_jp1 = (colp + c_jp1) / 2.0 * vflx_jp1 * s_met[3][st];
+        }
         const bool last = (k == nz - 1);
         const double qv_kp1 = cur.qv1, qc_kp1 = cur.qc1;
         double fv_kp1 = 0.0, fc_kp1 = 0.0;

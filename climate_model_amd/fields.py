@@ -56,6 +56,9 @@ FIELD_TABLE = OrderedDict([
     ('UWIND_EST',     (1, 0, 'nz')),
     ('VWIND_EST',     (0, 1, 'nz')),
     ('POTT_EST',      (0, 0, 'nz')),
+    # column pressure at the u- / v-points (2-D factors of UFLX, VFLX; library scratch)
+    ('UCOL',          (1, 0, 1)),
+    ('VCOL',          (0, 1, 1)),
     # primary diagnostics
     ('PVTF',          (0, 0, 'nz')),
     ('PVTFVB',        (0, 0, 'nzs')),

@@ -35,7 +35,7 @@ ABI_SYMBOLS = [
     'dycore_primary_diag',
     'dycore_secondary_diag_rho', 'dycore_secondary_diag', 'dycore_compute_turbulence', 'dycore_radiation',
     'dycore_step_matsuno', 'dycore_time_steps',
-    'dycore_step_begin', 'dycore_substep_part', 'dycore_use_stream', 'dycore_get_stream', 'dycore_overlap_parts', 'dycore_rows_size', 'dycore_pack_rows',
+    'dycore_step_begin', 'dycore_substep_part', 'dycore_use_stream', 'dycore_get_stream', 'dycore_overlap_parts', 'dycore_flux_from_winds', 'dycore_rows_size', 'dycore_pack_rows',
     'dycore_unpack_rows', 'dycore_substep_field',
     'dycore_profile', 'dycore_n_kernels', 'dycore_kernel_stats',
 ]
@@ -80,6 +80,7 @@ def load_library(path=None):
     lib.dycore_substep_part.argtypes = [hp, C.c_double, C.c_int32, C.c_int32]
     lib.dycore_use_stream.argtypes = [hp, C.c_void_p]
     lib.dycore_overlap_parts.argtypes = [hp]
+    lib.dycore_flux_from_winds.argtypes = [hp]
     lib.dycore_get_stream.argtypes = [hp]
     lib.dycore_get_stream.restype = C.c_void_p
     lib.dycore_substep_field.argtypes = [hp, C.c_int32, C.c_char_p]
@@ -246,6 +247,12 @@ class HipDycore:
     @property
     def overlap_parts(self):
         return bool(self.lib.dycore_overlap_parts(self._h))
+
+    @property
+    def flux_from_winds(self):
+        """The fused step re-forms UFLX, VFLX from the winds (they are not stored): a band exchanges
+        rows of UCOL, VCOL instead."""
+        return bool(self.lib.dycore_flux_from_winds(self._h))
 
     def substep_part(self, dt, substep, part):
         self._check(self.lib.dycore_substep_part(self._h, float(dt), int(substep), int(part)))

@@ -163,6 +163,11 @@ int dycore_step_begin(dycore_t *h, int32_t with_rho);
 const char *dycore_substep_field(dycore_t *h, int32_t substep, const char *name);
 enum { DYCORE_PART_MOM_INNER = 10, DYCORE_PART_MOM_EDGE = 11, DYCORE_PART_TEMP = 12 };
 int dycore_overlap_parts(dycore_t *h);
+/* != 0: the fused step does not store UFLX / VFLX (its kernels re-form them from the winds and the
+ * 2-D column pressures UCOL, VCOL at the u- / v-points; dycore_download still returns them, derived on
+ * demand).  A band then exchanges rows of UCOL, VCOL (2-D) after part 0 instead of UFLX, VFLX, and row 2
+ * of VWIND with the winds. */
+int dycore_flux_from_winds(dycore_t *h);
 int dycore_substep_part(dycore_t *h, double dt, int32_t substep, int32_t part);
 int dycore_use_stream(dycore_t *h, void *stream);
 /* the handle's own stream (DycoreConfig.stream, or the one the library created) */

@@ -506,23 +506,29 @@ __global__ __launch_bounds__(FTI *TJ) void k_momentum_dma(Geo g, Ptrs p, int gbx
             fac[3 * TN + e] = p.dxjs[o];
         }
     }
+    // flux tiles of a level (FROM_WINDS): every DMA wavefront turns the chunks IT moved into UFLX / VFLX
+    // entries (the unused slots of that buffer) as soon as its own loads have landed -- no barrier
+    // between the DMA and this step, the one at the end of the level publishes both
+    auto flux_own = [&](int b) {
+        if (FROM_WINDS && wave < NSL && dma_on) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            double *nb = dsm + b * BUF;
+            const int e = 2 * (wave * 64 + lane);
+#pragma unroll
+            for (int d = 0; d < 2; d++) {
+                if (e + d < (TJ + 2) * FTW) nb[S_UF * TN + e + d] = fac[e + d] * nb[S_UW * TN + e + d] * fac[TN + e + d];
+                nb[S_VF * TN + e + d] = fac[2 * TN + e + d] * nb[S_VW * TN + e + d] * fac[3 * TN + e + d];
+            }
+        }
+    };
     issue(k0, k0 & 1);
+    __syncthreads();                    // factor tiles, constants (and level k0) visible
+    flux_own(k0 & 1);
     __syncthreads();
 #pragma unroll 1
     for (int k = k0; k < k1; k++) {
         if (k + 1 < k1) issue(k + 1, (k + 1) & 1);
-        double *wbuf = dsm + (k & 1) * BUF;
-        if (FROM_WINDS) {           // flux tiles of level k into the (unused) UFLX / VFLX slots of this buffer
-            for (int e = tid; e < TN; e += NT) {
-                if (e < (TJ + 2) * FTW) wbuf[S_UF * TN + e] = fac[e] * wbuf[S_UW * TN + e] * fac[TN + e];
-                wbuf[S_VF * TN + e] = fac[2 * TN + e] * wbuf[S_VW * TN + e] * fac[3 * TN + e];
-            }
-            // workgroup barrier on the LDS writes only: the DMA just issued must stay in flight
-            // (__syncthreads would wait vmcnt(0))
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-        }
-        const double *buf = wbuf;
+        const double *buf = dsm + (k & 1) * BUF;
         if (active) {
             const double ds = c_ds[k];
             double uf[3][4], vf[4][3], uw[3][3], vw[3][3];
@@ -637,6 +643,7 @@ __global__ __launch_bounds__(FTI *TJ) void k_momentum_dma(Geo g, Ptrs p, int gbx
             u_km1 = u; v_km1 = v; uo_km1 = uo; vo_km1 = vo;
             pvb_k = pvb_kp1; pvb_im1_k = pvb_im1_kp1; pvb_jm1_k = pvb_jm1_kp1;
         }
+        if (k + 1 < k1) flux_own((k + 1) & 1);
         __syncthreads();       // level k+1 has landed for every wave; buffer k&1 is free again
     }
     // ---- the last level of the chunk: its lower interface is k1 (WWIND*U = 0 at the surface) ----

@@ -768,8 +768,8 @@ __global__ __launch_bounds__(TI *TJ) void k_derive_phivb(Geo g, Ptrs p)
 // value has been consumed by the vertical advection of levels k+1 and k.
 // Dry dycore only (the turbulence-coupled path uses the stage kernels).
 // FROM_WINDS: the mass fluxes are re-formed from UWIND, VWIND and the column pressures
-// (k_continuity_reg<., false> does not store UFLX, VFLX); the per-column metric factors live in
-// LDS so that the kernel keeps its three wavefronts per SIMD.
+// (k_continuity_reg<., false> does not store UFLX, VFLX): 16 more fp64 instructions per level, which
+// cost this issue-bound kernel ~10 % (profiles/r01_notes.md) against 2 passes saved elsewhere.
 template <bool WRITE_PHIVB, bool FROM_WINDS>
 __global__ __launch_bounds__(TI *TJ) void k_pott_fused(Geo g, Ptrs p, const double *pott_old, double *pott_out, double dt, int lin)
 {
@@ -797,11 +797,8 @@ __global__ __launch_bounds__(TI *TJ) void k_pott_fused(Geo g, Ptrs p, const doub
     // enough: the kernel is bound by fp64 instruction issue (~250 instructions per level, pow and
     // five divisions), and rings of 2-4 levels in flight cost the third wave per SIMD and ran
     // 5-15 % slower (profiles/r01_notes.md)
-    __shared__ double s_met[FROM_WINDS ? 4 : 1][TI * TJ];
-    const int st = threadIdx.y * TI + threadIdx.x;
-    if (FROM_WINDS) {
-        s_met[0][st] = p.dyis[c]; s_met[1][st] = p.dyis[c + 1]; s_met[2][st] = p.dxjs[c]; s_met[3][st] = p.dxjs[c + P];
-    }
+    const double m_dy0 = FROM_WINDS ? p.dyis[c] : 0.0, m_dy1 = FROM_WINDS ? p.dyis[c + 1] : 0.0;
+    const double m_dx0 = FROM_WINDS ? p.dxjs[c] : 0.0, m_dx1 = FROM_WINDS ? p.dxjs[c + P] : 0.0;
     const double *fu = FROM_WINDS ? p.UWIND : p.UFLX, *fv = FROM_WINDS ? p.VWIND : p.VFLX;
     struct In { double pt, im1, ip1, jm1, jp1, uf, uf1, vf, vf1, w, pvb, po; };
     auto load = [&](int k) {
@@ -819,10 +816,10 @@ __global__ __launch_bounds__(TI *TJ) void k_pott_fused(Geo g, Ptrs p, const doub
         In cur = nx_;
         if (k > 0) nx_ = load(k - 1);
         if (FROM_WINDS) {           // dyn_continuity.py:40-45, operand order of k_continuity_reg
-            cur.uf = (c_im1 + colp) / 2.0 * cur.uf * s_met[0][st];
-            cur.uf1 = (colp + c_ip1) / 2.0 * cur.uf1 * s_met[1][st];
-            cur.vf = (c_jm1 + colp) / 2.0 * cur.vf * s_met[2][st];
-            cur.vf1 = (colp + c_jp1) / 2.0 * cur.vf1 * s_met[3][st];
+            cur.uf = (c_im1 + colp) / 2.0 * cur.uf * m_dy0;
+            cur.uf1 = (colp + c_ip1) / 2.0 * cur.uf1 * m_dy1;
+            cur.vf = (c_jm1 + colp) / 2.0 * cur.vf * m_dx0;
+            cur.vf1 = (colp + c_jp1) / 2.0 * cur.vf1 * m_dx1;
         }
         const double pt = cur.pt;
         const double p_im1 = cur.im1, p_ip1 = cur.ip1, p_jm1 = cur.jm1, p_jp1 = cur.jp1;

@@ -716,6 +716,8 @@ int dycore_create(const DycoreConfig *cfg, dycore_t **out)
         return fail(DYCORE_EINVAL, "extents too small: nx=%d ny=%d nz=%d (need nx>=3, ny>=2, nz>=2)", cfg->nx, cfg->ny, cfg->nz);
     if (cfg->ny_global < cfg->ny || cfg->j_offset < 0 || cfg->j_offset + cfg->ny > cfg->ny_global)
         return fail(DYCORE_EINVAL, "band [%d,%d] outside the global grid of %d rows", cfg->j_offset + 1, cfg->j_offset + cfg->ny, cfg->ny_global);
+    if ((double)(((cfg->nx + 3 + 63) / 64) * 64) * (cfg->ny + 3) * (cfg->nz + 1) * sizeof(double) >= 4294967296.0)
+        return fail(DYCORE_EINVAL, "a field of %d x %d x %d cells is 4 GiB or more: cut the grid into latitude bands", cfg->nx, cfg->ny, cfg->nz);
     int ndev = 0;
     HIP_TRY(hipGetDeviceCount(&ndev));
     if (cfg->device < 0 || cfg->device >= ndev) return fail(DYCORE_EINVAL, "device %d not present (%d visible)", cfg->device, ndev);

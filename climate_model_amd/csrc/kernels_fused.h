@@ -19,21 +19,6 @@
 
 namespace dyc {
 
-// (p / 1e5) ** kappa of dyn_diagnostics.py:146-153.  DYC_POW_VARIANT 0: pow() as written in the
-// reference; 1: exp(kappa * (log(p) - log(1e5))), the same value to ~2 ulp at less than half
-// the instruction count (k_pott_fused is bound by fp64 instruction issue, not by HBM).
-#ifndef DYC_POW_VARIANT
-#define DYC_POW_VARIANT 0
-#endif
-__device__ __forceinline__ double exner_vb(double p)
-{
-#if DYC_POW_VARIANT == 1
-    return exp(CON_KAPPA * (log(p) - 11.512925464970229));   // log(100000)
-#else
-    return pow(p / 100000.0, CON_KAPPA);
-#endif
-}
-
 constexpr int FTI = 64;                // lanes along i per workgroup (one wavefront per row)
 constexpr int FTJ = 8;                 // rows per workgroup
 constexpr int FTW = 68;                // tile width: i-1 .. i+2 for 64 lanes (67), padded
@@ -770,6 +755,13 @@ __global__ __launch_bounds__(TI *TJ) void k_derive_phivb(Geo g, Ptrs p)
 // FROM_WINDS: the mass fluxes are re-formed from UWIND, VWIND and the column pressures
 // (k_continuity_reg<., false> does not store UFLX, VFLX): 16 more fp64 instructions per level, which
 // cost this issue-bound kernel ~10 % (profiles/r01_notes.md) against 2 passes saved elsewhere.
+// Addressing: every field has the same geometry, so ONE 32-bit byte offset per level (plus two for
+// the rows j-1, j+1) serves all of them -- `base + zero-extended VGPR offset` is the native form
+// of global_load/global_store, where 64-bit pointer arithmetic per access was ~50 VALU
+// instructions per level.  (dycore_create refuses fields of 4 GiB and more.)
+__device__ __forceinline__ double ldb(const double *base, unsigned boff) { return *(const double *)((const char *)base + boff); }
+__device__ __forceinline__ void stb(double *base, unsigned boff, double v) { *(double *)((char *)base + boff) = v; }
+
 template <bool WRITE_PHIVB, bool FROM_WINDS>
 __global__ __launch_bounds__(TI *TJ) void k_pott_fused(Geo g, Ptrs p, const double *pott_old, double *pott_out, double dt, int lin)
 {
@@ -777,6 +769,7 @@ __global__ __launch_bounds__(TI *TJ) void k_pott_fused(Geo g, Ptrs p, const doub
     if (!owned_cell(g, lin, i, j)) return;
     const int P = g.P, nz = g.nz;
     const size_t c = at2(g, i, j);
+    const unsigned bc = (unsigned)(c * sizeof(double)), bpl = (unsigned)(g.plane * sizeof(double)), bP = (unsigned)(P * sizeof(double));
     const double colp = p.COLP[c], cnew = p.COLP_NEW[c], cold = p.COLP_OLD[c];
     const double c_im1 = p.COLP[c - 1], c_ip1 = p.COLP[c + 1], c_jm1 = p.COLP[c - P], c_jp1 = p.COLP[c + P];
     const double area = p.A[c];
@@ -784,37 +777,32 @@ __global__ __launch_bounds__(TI *TJ) void k_pott_fused(Geo g, Ptrs p, const doub
     const double r_area = 1.0 / area, r_cnew = 1.0 / cnew;
 #endif
     // surface interface of the new column
-    double p_kp12 = g.pair_top + p.sigma_vb[nz] * cnew;
+    double p_kp12 = interface_pressure(g.pair_top, p.sigma_vb[nz], cnew);
     double pvb_kp1 = exner_vb(p_kp12);
     double phivb_kp1 = p.HSURF[c] * CON_G;
-    p.PVTFVB[at(g, i, j, nz)] = pvb_kp1;
-    if (WRITE_PHIVB) p.PHIVB[at(g, i, j, nz)] = phivb_kp1;
-    double w_kp1 = p.WWIND[c + (size_t)nz * g.plane];
-    double pvbo_kp1 = p.POTTVB[c + (size_t)nz * g.plane];        // old interface values
+    stb(p.PVTFVB, bc + (unsigned)nz * bpl, pvb_kp1);
+    if (WRITE_PHIVB) stb(p.PHIVB, bc + (unsigned)nz * bpl, phivb_kp1);
+    double w_kp1 = ldb(p.WWIND, bc + (unsigned)nz * bpl);
+    double pvbo_kp1 = ldb(p.POTTVB, bc + (unsigned)nz * bpl);        // old interface values
     double pottn_kp1 = 0.0, pvtf_kp1 = 0.0, pottvb_first = 0.0;
     // software pipeline: the inputs of level k-1 are requested before level k is computed, so the
     // HBM latency overlaps the pow/division chain instead of preceding it.  One level ahead is
-    // enough: the kernel is bound by fp64 instruction issue (~250 instructions per level, pow and
-    // five divisions), and rings of 2-4 levels in flight cost the third wave per SIMD and ran
-    // 5-15 % slower (profiles/r01_notes.md)
+    // enough (rings of 2-4 levels cost the third wave per SIMD and ran 5-15 % slower,
+    // profiles/r01_notes.md); the two input sets alternate roles in a loop unrolled by two, so
+    // no register is copied from "next" to "current".
     const double m_dy0 = FROM_WINDS ? p.dyis[c] : 0.0, m_dy1 = FROM_WINDS ? p.dyis[c + 1] : 0.0;
     const double m_dx0 = FROM_WINDS ? p.dxjs[c] : 0.0, m_dx1 = FROM_WINDS ? p.dxjs[c + P] : 0.0;
     const double *fu = FROM_WINDS ? p.UWIND : p.UFLX, *fv = FROM_WINDS ? p.VWIND : p.VFLX;
     struct In { double pt, im1, ip1, jm1, jp1, uf, uf1, vf, vf1, w, pvb, po; };
-    auto load = [&](int k) {
-        In r;
-        const size_t q = c + (size_t)k * g.plane;
-        r.pt = p.POTT[q]; r.im1 = p.POTT[q - 1]; r.ip1 = p.POTT[q + 1]; r.jm1 = p.POTT[q - P]; r.jp1 = p.POTT[q + P];
-        r.uf = fu[q]; r.uf1 = fu[q + 1]; r.vf = fv[q]; r.vf1 = fv[q + P];
-        r.w = p.WWIND[q]; r.pvb = p.POTTVB[q]; r.po = pott_old[q];
-        return r;
+    auto load = [&](int k, In &r) {
+        const unsigned q = bc + (unsigned)k * bpl;
+        r.pt = ldb(p.POTT, q); r.im1 = ldb(p.POTT, q - 8); r.ip1 = ldb(p.POTT, q + 8);
+        r.jm1 = ldb(p.POTT, q - bP); r.jp1 = ldb(p.POTT, q + bP);
+        r.uf = ldb(fu, q); r.uf1 = ldb(fu, q + 8); r.vf = ldb(fv, q); r.vf1 = ldb(fv, q + bP);
+        r.w = ldb(p.WWIND, q); r.pvb = ldb(p.POTTVB, q); r.po = ldb(pott_old, q);
     };
-    In nx_ = load(nz - 1);
-#pragma unroll 1
-    for (int k = nz - 1; k >= 0; k--) {
-        const size_t q = c + (size_t)k * g.plane;
-        In cur = nx_;
-        if (k > 0) nx_ = load(k - 1);
+    auto level = [&](int k, In &cur) {
+        const unsigned q = bc + (unsigned)k * bpl;
         if (FROM_WINDS) {           // dyn_continuity.py:40-45, operand order of k_continuity_reg
             cur.uf = (c_im1 + colp) / 2.0 * cur.uf * m_dy0;
             cur.uf1 = (colp + c_ip1) / 2.0 * cur.uf1 * m_dy1;
@@ -843,35 +831,43 @@ __global__ __launch_bounds__(TI *TJ) void k_pott_fused(Geo g, Ptrs p, const doub
         const double dif = p.POTT_dif_coef[k];
         if (dif > 0.0)
             t = t + dif * (c_im1 * p_im1 + c_ip1 * p_ip1 + c_jm1 * p_jm1 + c_jp1 * p_jp1 - 4.0 * colp * pt);
-        if (g.i_rad) t = t + p.dPOTTdt_RAD[q] * colp;
+        if (g.i_rad) t = t + ldb(p.dPOTTdt_RAD, q) * colp;
         // Euler forward, pressure weighted
 #ifdef DYC_RCP
         const double pott = cur.po * cold * r_cnew + dt * t * r_cnew;
 #else
         const double pott = cur.po * cold / cnew + dt * t / cnew;
 #endif
-        pott_out[at(g, i, j, k)] = pott;
+        stb(pott_out, q, pott);
         // diagnostics of the new column, level k
-        const double p_km12 = g.pair_top + p.sigma_vb[k] * cnew;
-        const double pvb_k = exner_vb(p_km12);
-        const double pvtf = 1.0 / (1.0 + CON_KAPPA) * (pvb_kp1 * p_kp12 - pvb_k * p_km12) / (p_kp12 - p_km12);
-        const double phi = phivb_kp1 - CON_CP * (pott * (pvtf - pvb_kp1));
-        const double phivb = phi - CON_CP * (pott * (pvb_k - pvtf));
-        p.PVTF[at(g, i, j, k)] = pvtf;
-        p.PVTFVB[at(g, i, j, k)] = pvb_k;
-        p.PHI[at(g, i, j, k)] = phi;
-        if (WRITE_PHIVB) p.PHIVB[at(g, i, j, k)] = phivb;
+        const DiagLevel dl = diag_level(g.pair_top, p.sigma_vb[k], cnew, pott, p_kp12, pvb_kp1, phivb_kp1);
+        const double p_km12 = dl.p_km12, pvb_k = dl.pvb_k, pvtf = dl.pvtf, phi = dl.phi, phivb = dl.phivb;
+        stb(p.PVTF, q, pvtf);
+        stb(p.PVTFVB, q, pvb_k);
+        stb(p.PHI, q, phi);
+        if (WRITE_PHIVB) stb(p.PHIVB, q, phivb);
         if (k < nz - 1) {
-            const double vb = ((pvb_kp1 - pvtf) * pott + (pvtf_kp1 - pvb_kp1) * pottn_kp1) / (pvtf_kp1 - pvtf);
-            p.POTTVB[at(g, i, j, k + 1)] = vb;
-            if (k == nz - 2 && nz > 2) p.POTTVB[at(g, i, j, nz)] = pottn_kp1 - (vb - pottn_kp1);
+            const double vb = pottvb_between(pvb_kp1, pvtf, pott, pvtf_kp1, pottn_kp1);
+            stb(p.POTTVB, q + bpl, vb);
+            if (k == nz - 2 && nz > 2) stb(p.POTTVB, bc + (unsigned)nz * bpl, pottn_kp1 - (vb - pottn_kp1));
             if (k == 0) pottvb_first = vb;
         }
         p_kp12 = p_km12; pvb_kp1 = pvb_k; phivb_kp1 = phivb;
         pottn_kp1 = pott; pvtf_kp1 = pvtf;
         w_kp1 = w_k; pvbo_kp1 = pvbo_k;
+    };
+    In A, B;
+    load(nz - 1, A);
+    int k = nz - 1;
+#pragma unroll 1
+    for (; k >= 1; k -= 2) {
+        load(k - 1, B);
+        level(k, A);
+        if (k >= 2) load(k - 2, A);
+        level(k - 1, B);
     }
-    if (nz >= 2) p.POTTVB[at(g, i, j, 0)] = pottn_kp1 - (pottvb_first - pottn_kp1);
+    if (k == 0) level(0, A);
+    if (nz >= 2) stb(p.POTTVB, bc, pottn_kp1 - (pottvb_first - pottn_kp1));
 }
 
 }  // namespace dyc

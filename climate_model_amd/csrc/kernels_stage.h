@@ -673,6 +673,51 @@ __global__ __launch_bounds__(TI *TJ) void k_euler_forward(Geo g, Ptrs p, double 
 }
 
 // ------------------------------------------------------------------------------------
+// (p / 1e5) ** kappa of dyn_diagnostics.py:146-153.  DYC_POW_VARIANT 0: pow() as written in the
+// reference; 1: exp(kappa * (log(p) - log(1e5))), the same value to ~2 ulp at less than half
+// the instruction count (k_pott_fused is bound by fp64 instruction issue, not by HBM).
+#ifndef DYC_POW_VARIANT
+#define DYC_POW_VARIANT 0
+#endif
+__device__ __forceinline__ double exner_vb(double p)
+{
+#if DYC_POW_VARIANT == 1
+    return exp(CON_KAPPA * (log(p) - 11.512925464970229));   // log(100000)
+#else
+    return pow(p / 100000.0, CON_KAPPA);
+#endif
+}
+
+// One level of the primary diagnostics (dyn_diagnostics.py:139-195), shared by the stage kernel, the
+// halo-row kernel of a latitude band and the fused temperature kernel.  Contraction to FMA is
+// switched off inside: the compiler fuses a*b+c differently in different surroundings, and a band
+// recomputes the diagnostics of rows it received from its neighbour -- they must come out bit
+// for bit as the owner computed them.
+__device__ __forceinline__ double interface_pressure(double pair_top, double svb, double colp)
+{
+#pragma clang fp contract(off)
+    return pair_top + svb * colp;
+}
+struct DiagLevel { double p_km12, pvb_k, pvtf, phi, phivb; };
+__device__ __forceinline__ DiagLevel diag_level(double pair_top, double svb_k, double colp, double pott,
+                                                double p_kp12, double pvb_kp1, double phivb_kp1)
+{
+#pragma clang fp contract(off)
+    DiagLevel d;
+    d.p_km12 = pair_top + svb_k * colp;
+    d.pvb_k = exner_vb(d.p_km12);
+    d.pvtf = 1.0 / (1.0 + CON_KAPPA) * (pvb_kp1 * p_kp12 - d.pvb_k * d.p_km12) / (p_kp12 - d.p_km12);
+    d.phi = phivb_kp1 - CON_CP * (pott * (d.pvtf - pvb_kp1));
+    d.phivb = d.phi - CON_CP * (pott * (d.pvb_k - d.pvtf));
+    return d;
+}
+// interface value between levels k and k+1, dyn_diagnostics.py:183-186
+__device__ __forceinline__ double pottvb_between(double pvb_kp1, double pvtf, double pott, double pvtf_kp1, double pott_kp1)
+{
+#pragma clang fp contract(off)
+    return ((pvb_kp1 - pvtf) * pott + (pvtf_kp1 - pvb_kp1) * pott_kp1) / (pvtf_kp1 - pvtf);
+}
+
 // primary diagnostics: dyn_diagnostics.py:139-195 (diag_PVTF, diag_PHI, diag_POTTVB) in one
 // bottom-up sweep over the whole array incl. halos (i in [0,nx+1], j in [0,ny+1]).
 // One pow() per interface instead of the reference's two per cell: PVTFVB[k+1] is carried.
@@ -681,26 +726,23 @@ __device__ __forceinline__ void diag_column(const Geo &g, const Ptrs &p, int i, 
     const size_t c = at2(g, i, j);
     const int nz = g.nz;
     const double colp = p.COLP[c];
-    double p_kp12 = g.pair_top + p.sigma_vb[nz] * colp;
-    double pvb_kp1 = pow(p_kp12 / 100000.0, CON_KAPPA);
+    double p_kp12 = interface_pressure(g.pair_top, p.sigma_vb[nz], colp);
+    double pvb_kp1 = exner_vb(p_kp12);
     double phivb_kp1 = p.HSURF[c] * CON_G;
     p.PVTFVB[c + (size_t)nz * g.plane] = pvb_kp1;
     p.PHIVB[c + (size_t)nz * g.plane] = phivb_kp1;
     double pott_kp1 = 0.0, pvtf_kp1 = 0.0, pottvb_first = 0.0;
     for (int k = nz - 1; k >= 0; k--) {
         const size_t q = c + (size_t)k * g.plane;
-        const double p_km12 = g.pair_top + p.sigma_vb[k] * colp;
-        const double pvb_k = pow(p_km12 / 100000.0, CON_KAPPA);
-        const double pvtf = 1.0 / (1.0 + CON_KAPPA) * (pvb_kp1 * p_kp12 - pvb_k * p_km12) / (p_kp12 - p_km12);
         const double pott = p.POTT[q];
-        const double phi = phivb_kp1 - CON_CP * (pott * (pvtf - pvb_kp1));
-        const double phivb = phi - CON_CP * (pott * (pvb_k - pvtf));
+        const DiagLevel dl = diag_level(g.pair_top, p.sigma_vb[k], colp, pott, p_kp12, pvb_kp1, phivb_kp1);
+        const double p_km12 = dl.p_km12, pvb_k = dl.pvb_k, pvtf = dl.pvtf, phi = dl.phi, phivb = dl.phivb;
         p.PVTF[q] = pvtf;
         p.PVTFVB[q] = pvb_k;
         p.PHI[q] = phi;
         p.PHIVB[q] = phivb;
         if (k < nz - 1) {   // interface k+1 between levels k and k+1
-            const double vb = ((pvb_kp1 - pvtf) * pott + (pvtf_kp1 - pvb_kp1) * pott_kp1) / (pvtf_kp1 - pvtf);
+            const double vb = pottvb_between(pvb_kp1, pvtf, pott, pvtf_kp1, pott_kp1);
             p.POTTVB[q + g.plane] = vb;
             if (k == nz - 2 && nz > 2)   // surface extrapolation (elif branch, dyn_diagnostics.py:191-194)
                 p.POTTVB[c + (size_t)nz * g.plane] = pott_kp1 - (vb - pott_kp1);

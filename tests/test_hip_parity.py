@@ -161,7 +161,9 @@ def test_fused_momentum_equals_stage_kernels(monkeypatch):
     nx, ny = GR.nx, GR.ny
     for n in out['1']:
         err, ncmp, bad = rel_max_err(out['1'][n], out['0'][n], n, nx, ny)
-        assert bad == 0 and ncmp > 0 and err <= 1e-12, '%s: %.3e' % (n, err)
+        # WWIND, FLXDIV, dCOLPdt are sums of flux differences that nearly cancel: a few ulp of the fluxes
+        tol = 1e-11 if n in ('WWIND', 'FLXDIV', 'dCOLPdt') else 1e-12
+        assert bad == 0 and ncmp > 0 and err <= tol, '%s: %.3e' % (n, err)
         assert np.array_equal(np.isfinite(out['1'][n]), np.isfinite(out['0'][n])), n
 
 

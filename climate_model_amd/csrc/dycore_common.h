@@ -63,6 +63,7 @@ struct Ptrs {
     const double *A, *dxjs, *dyis, *corf, *corf_is, *lat_rad, *lat_is_rad, *dlon_rad, *dlat_rad;
     // grid constants, vertical 1-D
     const double *sigma_vb, *dsigma, *UVFLX_dif_coef, *POTT_dif_coef, *moist_dif_coef;
+    const double *rdsigma;      // 1 / dsigma, formed by the library when dsigma is set
 };
 
 __device__ __forceinline__ size_t at(const Geo &g, int i, int j, int k)

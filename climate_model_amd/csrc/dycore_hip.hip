@@ -812,6 +812,11 @@ int dycore_create(const DycoreConfig *cfg, dycore_t **out)
         h->grid_idx[kGrid[f].name] = f;
     }
     if (!rc) {
+        double *d = nullptr;
+        rc = alloc((size_t)(g.nz + 1), &d);
+        h->p.rdsigma = d;
+    }
+    if (!rc) {
         h->stage_elems = (size_t)(g.nx + 3) * (g.ny + 3) * (g.nz + 1);
         double *d = nullptr;
         rc = alloc(h->stage_elems, &d);
@@ -869,6 +874,12 @@ int dycore_set_grid(dycore_t *h, const char *name, const double *host, int32_t n
         if ((long long)n0 * n1 * n2 != n) return fail(DYCORE_EINVAL, "grid array '%s': expected %d elements, got %dx%dx%d", name, n, n0, n1, n2);
         HIP_TRY(hipMemcpyAsync(dev, host, n * sizeof(double), hipMemcpyHostToDevice, h->stream));
         HIP_TRY(hipStreamSynchronize(h->stream));
+        if (d.member == &Ptrs::dsigma) {
+            std::vector<double> r(n);
+            for (int k = 0; k < n; k++) r[k] = 1.0 / host[k];
+            HIP_TRY(hipMemcpyAsync(const_cast<double *>(h->p.rdsigma), r.data(), n * sizeof(double), hipMemcpyHostToDevice, h->stream));
+            HIP_TRY(hipStreamSynchronize(h->stream));
+        }
     } else {
         const int e0 = g.nx + 2 + d.stgx, e1 = g.ny + 2 + d.stgy;
         if (n0 != e0 || n1 != e1 || n2 != 1)

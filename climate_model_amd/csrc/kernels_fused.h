@@ -300,7 +300,7 @@ constexpr int DMAXZ = 160;                        // levels the LDS copy of the 
 // (+ four 2-D factor tiles when the fluxes are re-formed from the winds)
 constexpr size_t dma_lds_bytes(int tj, bool from_winds)
 {
-    return (2 * (size_t)(FNF * FTW * (tj + 3) + 2 * FTW * tj) + 3 * DMAXZ + 2 + (from_winds ? 4 * FTW * (tj + 3) : 0)) * sizeof(double);
+    return (2 * (size_t)(FNF * FTW * (tj + 3) + 2 * FTW * tj) + 5 * DMAXZ + 2 + (from_winds ? 4 * FTW * (tj + 3) : 0)) * sizeof(double);
 }
 
 typedef __attribute__((address_space(3))) void lds_void_t;
@@ -444,6 +444,10 @@ __global__ __launch_bounds__(FTI *TJ) void k_momentum_dma(Geo g, Ptrs p, int gbx
 #undef CA
 #undef CO
     }
+    // Divisions by per-column (ca_is, ca_js) and per-level (dsigma) quantities are multiplications by
+    // reciprocals formed once: <= 1 ulp from the reference's x / y per operation, 8 fp64 divisions
+    // (~80 instructions) less per level -- -9 % kernel time.  The stage kernels keep the divisions.
+    const double r_ca_is = 1.0 / ca_is, r_ca_js = 1.0 / ca_js;
     const size_t c0 = c + (size_t)k0 * g.plane;
     double pvb_k = p.PVTFVB[c0], pvb_im1_k = p.PVTFVB[c0 - 1], pvb_jm1_k = p.PVTFVB[c0 - P];
 
@@ -472,12 +476,17 @@ __global__ __launch_bounds__(FTI *TJ) void k_momentum_dma(Geo g, Ptrs p, int gbx
     // wait vmcnt(0) at its first use and drain the DMA prefetch (cdna_hip_programming.md, section 5)
     double *cst = dsm + 2 * BUF;
     double *c_ds = cst, *c_svb = cst + DMAXZ, *c_dif = cst + 2 * DMAXZ + 1;
+    double *c_rds = cst + 3 * DMAXZ + 2, *c_rsum = cst + 4 * DMAXZ + 2;     // 1/dsigma[k], 1/(dsigma[k]+dsigma[k-1])
     for (int t = tid; t <= nz; t += NT) {
         c_svb[t] = p.sigma_vb[t];
-        if (t < nz) { c_ds[t] = p.dsigma[t]; c_dif[t] = p.UVFLX_dif_coef[t]; }
+        if (t < nz) {
+            c_ds[t] = p.dsigma[t]; c_dif[t] = p.UVFLX_dif_coef[t];
+            c_rds[t] = 1.0 / p.dsigma[t];
+            c_rsum[t] = t > 0 ? 1.0 / (p.dsigma[t] + p.dsigma[t - 1]) : 0.0;
+        }
     }
     // 2-D factor tiles, same element -> grid cell map as the DMA chunks
-    double *fac = cst + 3 * DMAXZ + 2;
+    double *fac = cst + 5 * DMAXZ + 2;
     if (FROM_WINDS) {
         for (int e = tid; e < TN; e += NT) {
             const int r = e / FTW, cc = e - r * FTW, c2 = cc & ~1;
@@ -542,15 +551,17 @@ __global__ __launch_bounds__(FTI *TJ) void k_momentum_dma(Geo g, Ptrs p, int gbx
             // ---- interface k closes level k-1 ----
             if (k >= 1) {
                 const double ds_km1 = c_ds[k - 1];
-                const double wu_k = su_k * ((ds * u_km1 + ds_km1 * u) / (ds + ds_km1));
-                const double wv_k = sv_k * ((ds * v_km1 + ds_km1 * v) / (ds + ds_km1));
+                const double rsum = c_rsum[k];
+                const double wu_k = su_k * ((ds * u_km1 + ds_km1 * u) * rsum);
+                const double wv_k = sv_k * ((ds * v_km1 + ds_km1 * v) * rsum);
                 if (k > k0) {
                     const size_t qm = c + (size_t)(k - 1) * g.plane;
-                    const double tu = tu_km1 + (wu_km1 - wu_k) / ds_km1;
-                    u_out[qm] = uo_km1 * cao_is / ca_is + dt * tu / ca_is;
+                    const double rds1 = c_rds[k - 1];
+                    const double tu = tu_km1 + (wu_km1 - wu_k) * rds1;
+                    u_out[qm] = uo_km1 * cao_is * r_ca_is + dt * tu * r_ca_is;
                     if (v_on) {
-                        const double tv = tv_km1 + (wv_km1 - wv_k) / ds_km1;
-                        v_out[qm] = vo_km1 * cao_js / ca_js + dt * tv / ca_js;
+                        const double tv = tv_km1 + (wv_km1 - wv_k) * rds1;
+                        v_out[qm] = vo_km1 * cao_js * r_ca_js + dt * tv * r_ca_js;
                     }
                 }
                 wu_km1 = wu_k; wv_km1 = wv_k;
@@ -638,11 +649,11 @@ __global__ __launch_bounds__(FTI *TJ) void k_momentum_dma(Geo g, Ptrs p, int gbx
         double wu_k = 0.0, wv_k = 0.0;
         if (k1 < nz) {
             const double ds1 = c_ds[k1];
-            wu_k = su_k * ((ds1 * u_km1 + ds * p.UWIND[qm + g.plane]) / (ds1 + ds));
-            wv_k = sv_k * ((ds1 * v_km1 + ds * p.VWIND[qm + g.plane]) / (ds1 + ds));
+            wu_k = su_k * ((ds1 * u_km1 + ds * p.UWIND[qm + g.plane]) * c_rsum[k1]);
+            wv_k = sv_k * ((ds1 * v_km1 + ds * p.VWIND[qm + g.plane]) * c_rsum[k1]);
         }
-        u_out[qm] = uo_km1 * cao_is / ca_is + dt * (tu_km1 + (wu_km1 - wu_k) / ds) / ca_is;
-        if (v_on) v_out[qm] = vo_km1 * cao_js / ca_js + dt * (tv_km1 + (wv_km1 - wv_k) / ds) / ca_js;
+        u_out[qm] = uo_km1 * cao_is * r_ca_is + dt * (tu_km1 + (wu_km1 - wu_k) * c_rds[k1 - 1]) * r_ca_is;
+        if (v_on) v_out[qm] = vo_km1 * cao_js * r_ca_js + dt * (tv_km1 + (wv_km1 - wv_k) * c_rds[k1 - 1]) * r_ca_js;
     }
 #undef SM
 }
@@ -773,9 +784,9 @@ __global__ __launch_bounds__(TI *TJ) void k_pott_fused(Geo g, Ptrs p, const doub
     const double colp = p.COLP[c], cnew = p.COLP_NEW[c], cold = p.COLP_OLD[c];
     const double c_im1 = p.COLP[c - 1], c_ip1 = p.COLP[c + 1], c_jm1 = p.COLP[c - P], c_jp1 = p.COLP[c + P];
     const double area = p.A[c];
-#ifdef DYC_RCP
+    // as in k_momentum_dma: divisions by per-column / per-level quantities as multiplications by
+    // reciprocals formed once (<= 1 ulp per operation); the diagnostics below keep their divisions
     const double r_area = 1.0 / area, r_cnew = 1.0 / cnew;
-#endif
     // surface interface of the new column
     double p_kp12 = interface_pressure(g.pair_top, p.sigma_vb[nz], cnew);
     double pvb_kp1 = exner_vb(p_kp12);
@@ -811,33 +822,25 @@ __global__ __launch_bounds__(TI *TJ) void k_pott_fused(Geo g, Ptrs p, const doub
         }
         const double pt = cur.pt;
         const double p_im1 = cur.im1, p_ip1 = cur.ip1, p_jm1 = cur.jm1, p_jp1 = cur.jp1;
-        const double ds = p.dsigma[k];
+        const double rds = p.rdsigma[k];
         double t = 0.0;
         t = t + (+cur.uf * (p_im1 + pt) / 2.0 - cur.uf1 * (pt + p_ip1) / 2.0
                  + cur.vf * (p_jm1 + pt) / 2.0 - cur.vf1 * (pt + p_jp1) / 2.0)
-#ifdef DYC_RCP
                 * r_area;
-#else
-                / area;
-#endif
         double w_k = 0.0, pvbo_k = 0.0;
         if (k == 0) {
-            t = t + cnew * (-w_kp1 * pvbo_kp1) / ds;
+            t = t + cnew * (-w_kp1 * pvbo_kp1) * rds;
         } else {
             w_k = cur.w;
             pvbo_k = cur.pvb;
-            t = t + cnew * (+w_k * pvbo_k - w_kp1 * pvbo_kp1) / ds;
+            t = t + cnew * (+w_k * pvbo_k - w_kp1 * pvbo_kp1) * rds;
         }
         const double dif = p.POTT_dif_coef[k];
         if (dif > 0.0)
             t = t + dif * (c_im1 * p_im1 + c_ip1 * p_ip1 + c_jm1 * p_jm1 + c_jp1 * p_jp1 - 4.0 * colp * pt);
         if (g.i_rad) t = t + ldb(p.dPOTTdt_RAD, q) * colp;
         // Euler forward, pressure weighted
-#ifdef DYC_RCP
         const double pott = cur.po * cold * r_cnew + dt * t * r_cnew;
-#else
-        const double pott = cur.po * cold / cnew + dt * t / cnew;
-#endif
         stb(pott_out, q, pott);
         // diagnostics of the new column, level k
         const DiagLevel dl = diag_level(g.pair_top, p.sigma_vb[k], cnew, pott, p_kp12, pvb_kp1, phivb_kp1);

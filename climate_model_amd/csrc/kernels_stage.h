@@ -525,6 +525,7 @@ __global__ __launch_bounds__(TI *TJ) void k_moist(Geo g, Ptrs p, const double *q
     const double area = p.A[c];
     double surf = 0.0;
     if (TURB) surf = p.SLHFLX[c] / CON_LH;
+    const double r_area = 1.0 / area, r_cn = 1.0 / colp_new;
     double qv_km1 = 0.0, qc_km1 = 0.0, phi_km1 = 0.0;
     double fv_k = 0.0, fc_k = 0.0;                 // W * interface value at interface k (0 at the top)
     double qv_k = p.QV[c], qc_k = p.QC[c];
@@ -558,6 +559,7 @@ __global__ __launch_bounds__(TI *TJ) void k_moist(Geo g, Ptrs p, const double *q
         const In cur = nxt;
         if (k + 1 < nz) nxt = load(k + 1);
         const double ds = p.dsigma[k], dif = p.moist_dif_coef[k];
+        const double rds = EULER ? p.rdsigma[k] : 0.0;
         double uflx = cur.uf, uflx_ip1 = cur.uf1, vflx = cur.vf, vflx_jp1 = cur.vf1;
         if (FROM_WINDS) {           // dyn_continuity.py:40-45, operand order of k_continuity_reg
             uflx = (c_im1 + colp) / 2.0 * uflx * s_met[0][st];
@@ -581,10 +583,12 @@ __global__ __launch_bounds__(TI *TJ) void k_moist(Geo g, Ptrs p, const double *q
             const double x_jm1 = s == 0 ? cur.v_jm1 : cur.c_jm1, x_jp1 = s == 0 ? cur.v_jp1 : cur.c_jp1;
             const double f_k = s == 0 ? fv_k : fc_k, f_kp1 = s == 0 ? fv_kp1 : fc_kp1;
             double d = 0.0;
-            d = d + (+uflx * (x_im1 + x) / 2.0 - uflx_ip1 * (x + x_ip1) / 2.0
-                     + vflx * (x_jm1 + x) / 2.0 - vflx_jp1 * (x + x_jp1) / 2.0) / area;
-            if (k == 0) d = d + colp_new * (-f_kp1) / ds;
-            else d = d + colp_new * (+f_k - f_kp1) / ds;
+            const double adv = (+uflx * (x_im1 + x) / 2.0 - uflx_ip1 * (x + x_ip1) / 2.0
+                                + vflx * (x_jm1 + x) / 2.0 - vflx_jp1 * (x + x_jp1) / 2.0);
+            // fused step (EULER): per-column / per-level divisors as reciprocals, as in k_pott_fused
+            d = d + (EULER ? adv * r_area : adv / area);
+            if (k == 0) d = d + (EULER ? colp_new * (-f_kp1) * rds : colp_new * (-f_kp1) / ds);
+            else d = d + (EULER ? colp_new * (+f_k - f_kp1) * rds : colp_new * (+f_k - f_kp1) / ds);
             if (TURB) {
                 const double tb = turb_flux(p.PHI[q], last ? 0.0 : p.PHI[q + g.plane], phi_km1, p.PHIVB[q], p.PHIVB[q + g.plane],
                                             x, s == 0 ? qv_kp1 : qc_kp1, s == 0 ? qv_km1 : qc_km1,
@@ -598,8 +602,8 @@ __global__ __launch_bounds__(TI *TJ) void k_moist(Geo g, Ptrs p, const double *q
             tq[s] = d;
         }
         if (EULER) {
-            qv_out[q] = cur.vo * colp_old / colp_new + dt * tq[0] / colp_new;
-            qc_out[q] = cur.co * colp_old / colp_new + dt * tq[1] / colp_new;
+            qv_out[q] = cur.vo * colp_old * r_cn + dt * tq[0] * r_cn;
+            qc_out[q] = cur.co * colp_old * r_cn + dt * tq[1] * r_cn;
         } else {
             p.dQVdt[q] = tq[0];
             p.dQCdt[q] = tq[1];

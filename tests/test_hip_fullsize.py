@@ -157,3 +157,21 @@ def test_ragged_bands_equal_single(nx, ny, nz, nbands):
         np.testing.assert_array_equal(got, ref[n], err_msg='%s (%d bands)' % (n, nbands))
     for c in cores:
         c.close()
+
+
+def test_long_run_tracks_oracle():
+    """300 Matsuno steps at 1 deg x 32 (BASELINE config 1): the fused production step stays with the
+    CPU oracle (rounding differences grow, they do not blow up) and conserves mass."""
+    GR, state = _setup(1.0, 32)
+    nsteps = 300
+    got = _run_hip(GR, state, nsteps)
+    o = Oracle(GR.nx, GR.ny, GR.nz, GR.GRF['CPU'], state, pair_top=GR.nl.pair_top, i_turb=0, fill_nan=False)
+    o.primary_diag()
+    o.step_matsuno(GR.dt, nsteps, with_rho=False)
+    for n in PROGNOSTIC:
+        err, ncmp, bad = rel_max_err(got[n], o.F[n], n, GR.nx, GR.ny)
+        assert bad == 0 and ncmp > 0 and err <= 1e-7, '%s after %d steps: rel err %.3e' % (n, nsteps, err)
+    A = GR.A[1:-1, 1:-1, 0]
+    m0, m1 = np.sum(state['COLP'][1:-1, 1:-1, 0] * A), np.sum(got['COLP'][1:-1, 1:-1, 0] * A)
+    assert abs(m1 - m0) / m0 < 1e-12
+    assert np.max(np.abs(got['UWIND'][1:GR.nx + 1, 1:-1])) < 200.

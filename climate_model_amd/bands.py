@@ -9,9 +9,10 @@ y-staggered VFLX) and refreshes those rows from its neighbours twice per Matsuno
   phase 'A' after continuity : UFLX, VFLX, WWIND, COLP_NEW   (feed the 3x3 momentum fluxes)
   phase 'B' after Euler step : UWIND, VWIND, POTT            (the new state)
 
-The overlapped schedule (_overlapped_step) sends phase B in two pieces, 'B1' = UWIND, VWIND as
-soon as the momentum kernel is done and 'B2' = POTT (QV, QC) after the temperature kernel, so
-that every message travels behind a kernel that does not need it.
+The overlapped schedule (_overlapped_step) sends phase B in two pieces: 'B1' = UWIND, VWIND as
+soon as the momentum kernel is done, and the POTT (QV, QC) rows together with phase A of the NEXT
+substep ('AB2'), so that every message travels behind a kernel that does not need it and a
+substep costs two exchanges, not three ('B2' alone is the flush at the end of a call).
 
 Ownership: band r owns mass rows j in [j0, j0+ny) and the v-rows (js) on the southern edge
 of each of them; the northernmost band also owns js = ny_global+1 (the pole).  Every
@@ -33,18 +34,22 @@ SEND_NORTH = {
     'B': [('UWIND', 'N'), ('VWIND', 'N'), ('POTT', 'N')],
     'B1': [('UWIND', 'N'), ('VWIND', 'N')],
     'B2': [('POTT', 'N')],
+    'AB2': [('UFLX', 'N'), ('VFLX', 'N'), ('WWIND', 'N'), ('COLP_NEW', 'N'), ('POTT', 'N')],
 }
 SEND_SOUTH = {
     'A': [('UFLX', 1), ('VFLX', 1), ('VFLX', 2), ('WWIND', 1), ('COLP_NEW', 1)],
     'B': [('UWIND', 1), ('VWIND', 1), ('POTT', 1)],
     'B1': [('UWIND', 1), ('VWIND', 1)],
     'B2': [('POTT', 1)],
+    'AB2': [('UFLX', 1), ('VFLX', 1), ('VFLX', 2), ('WWIND', 1), ('COLP_NEW', 1), ('POTT', 1)],
 }
-PHASES = ('A', 'B', 'B1', 'B2')
+PHASES = ('A', 'B', 'B1', 'B2', 'AB2')
+STATE_FIELDS = ('UWIND', 'VWIND', 'POTT', 'QV', 'QC')
 # rows at which the RECEIVER stores what its southern / northern neighbour sent
 # (offsets relative to the receiver's own ny: 'N+1' = north halo row, 'N+2' = second one)
-RECV_FROM_SOUTH = {'A': [0, 0, 0, 0], 'B': [0, 0, 0], 'B1': [0, 0], 'B2': [0]}
-RECV_FROM_NORTH = {'A': ['N+1', 'N+1', 'N+2', 'N+1', 'N+1'], 'B': ['N+1', 'N+1', 'N+1'], 'B1': ['N+1', 'N+1'], 'B2': ['N+1']}
+RECV_FROM_SOUTH = {'A': [0, 0, 0, 0], 'B': [0, 0, 0], 'B1': [0, 0], 'B2': [0], 'AB2': [0, 0, 0, 0, 0]}
+RECV_FROM_NORTH = {'A': ['N+1', 'N+1', 'N+2', 'N+1', 'N+1'], 'B': ['N+1', 'N+1', 'N+1'], 'B1': ['N+1', 'N+1'], 'B2': ['N+1'],
+                   'AB2': ['N+1', 'N+1', 'N+2', 'N+1', 'N+1', 'N+1']}
 
 
 class BandLayout:
@@ -112,7 +117,7 @@ class BandHalo:
         fw = bool(getattr(core, 'flux_from_winds', False))
         swap = {'UFLX': 'UCOL', 'VFLX': 'VCOL'} if fw else {}
         for ph in PHASES:
-            extra = [('QV', None), ('QC', None)] if (moist and ph in ('B', 'B2')) else []
+            extra = [('QV', None), ('QC', None)] if (moist and ph in ('B', 'B2', 'AB2')) else []
             north = [(swap.get(f, f), r) for f, r in SEND_NORTH[ph]]
             south = [(swap.get(f, f), r) for f, r in SEND_SOUTH[ph]]
             rs, rn = list(RECV_FROM_SOUTH[ph]), list(RECV_FROM_NORTH[ph])
@@ -133,14 +138,16 @@ class BandHalo:
         return {k: self.core.rows_size(p[k][0]) for k in p}
 
     def resolved(self, ph, sub):
-        """The plan with state-field names mapped to the buffer the given substep wrote
-        (the fused library step keeps the predictor state in *_EST scratch fields)."""
+        """The plan with state-field names mapped to the buffer that holds them (the fused library
+        step keeps the predictor state in *_EST scratch fields): for 'B*' the state substep `sub`
+        wrote, for 'AB2' the state substep `sub` evaluates on = what the previous substep wrote."""
         key = (ph, sub)
         if key not in self._resolved:
             fn = getattr(self.core, 'substep_field', None)
+            src = 1 - sub if ph == 'AB2' else sub
             out = {}
             for k, (names, rows) in self.plan[ph].items():
-                out[k] = ([fn(sub, n) if (fn and ph != 'A') else n for n in names], rows)
+                out[k] = ([fn(src, n) if (fn and n in STATE_FIELDS) else n for n in names], rows)
             self._resolved[key] = out
         return self._resolved[key]
 
@@ -204,15 +211,16 @@ def _overlapped_step(cores, streams, deliver, dt, nsteps, with_rho):
     """One schedule for one band per process (DistributedBands) and for several bands in one
     process (LocalBands).  Per substep, on the main stream (| = point where it waits):
 
-        |B1  continuity                          pack A
-             momentum, inner tiles
-        |A |B2  momentum, edge tiles             pack B1
-             temperature (+ moisture), halos     pack B2
+        |B1   continuity                          pack AB2 (fluxes' factors, WWIND, COLP_NEW + POTT rows
+              momentum, inner tiles                         of the state this substep evaluates on)
+        |AB2  momentum, edge tiles                pack B1  (new winds)
+              temperature (+ moisture), halos
 
-    and on the comm stream, behind each pack: transport, unpack (after B2: primary diagnostics
-    of the received rows).  A travels behind the inner momentum tiles, B1 (winds) behind the
-    temperature kernel, B2 (POTT) behind the continuity kernel of the NEXT substep, which needs
-    the wind rows only.  deliver(ph, sub) issues transport + unpack on the current stream."""
+    and on the comm stream, behind each pack: transport, unpack (after AB2: primary diagnostics
+    of the received rows).  AB2 travels behind the inner momentum tiles, B1 behind the temperature
+    kernel and the continuity kernel of the next substep's start.  The POTT rows written by the
+    last substep of a call go out alone ('B2') before it returns.
+    deliver(ph, sub) issues transport + unpack on the current stream."""
     torch = streams.torch
     C0 = cores[0]
 
@@ -225,9 +233,9 @@ def _overlapped_step(cores, streams, deliver, dt, nsteps, with_rho):
                 c.use_stream(streams.comm.cuda_stream)
             try:
                 deliver(ph, sub)
-                if ph == 'B2':
+                if ph in ('AB2', 'B2'):     # diagnostics of the received POTT rows: the substep that wrote them
                     for c in cores:
-                        c.substep_part(dt, sub, 2)
+                        c.substep_part(dt, 1 - sub if ph == 'AB2' else sub, 2)
             finally:
                 for c in cores:
                     c.use_stream(None)
@@ -239,20 +247,20 @@ def _overlapped_step(cores, streams, deliver, dt, nsteps, with_rho):
             c.step_begin(with_rho)
         for sub in (0, 1):
             streams.wait('B1')
+            streams.wait('B2')
             for c in cores:
                 c.substep_part(dt, sub, 0)
-            on_comm('A', sub)
+            on_comm('AB2', sub)
             for c in cores:
                 c.substep_part(dt, sub, C0.PART_MOM_INNER)
-            streams.wait('A')
-            streams.wait('B2')
+            streams.wait('AB2')
             for c in cores:
                 c.substep_part(dt, sub, C0.PART_MOM_EDGE)
             on_comm('B1', sub)
             for c in cores:
                 c.substep_part(dt, sub, C0.PART_TEMP)
-            on_comm('B2', sub)
-    streams.wait('B1')      # leave with every stream joined into main
+    on_comm('B2', 1)        # leave with the halo rows of the final state in place and every stream joined
+    streams.wait('B1')
     streams.wait('B2')
 
 

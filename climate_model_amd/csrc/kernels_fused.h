@@ -1,12 +1,16 @@
-// kernels_fused.h -- the production kernels of dycore_step_matsuno (dry dycore).
+// kernels_fused.h -- the production kernels of dycore_step_matsuno (dry / moist dycore).
 //
-// k_momentum_fused : dyn_UVFLX_prepare.py:249-439 + dyn_UFLX.py:339-434 + dyn_VFLX.py:322-408
-//                    in one pass.  The eight Arakawa-C fluxes B,C,D,E,R,Q,S,T and the
-//                    interface products WWIND*U, WWIND*V are never written to HBM: they are
-//                    re-derived per thread from UFLX/VFLX/WWIND tiles that the workgroup
-//                    stages through LDS once per level (3x3 halo, and one more column /
-//                    row for the radius-2 composite stencil).  HBM traffic per launch:
-//                    9 reads + 2 writes instead of the 41 passes of the three stage kernels.
+// k_momentum_dma   : dyn_UVFLX_prepare.py:249-439 + dyn_UFLX.py:339-434 + dyn_VFLX.py:322-408 + the
+//                    wind part of dyn_timestep.py:212-297 in one pass (k_momentum_fused is its
+//                    register-staged predecessor, kept as the fallback for nz > DMAXZ).  The eight
+//                    Arakawa-C fluxes B,C,D,E,R,Q,S,T and the interface products WWIND*U, WWIND*V are
+//                    never written to HBM: they are re-derived per thread from UFLX/VFLX/WWIND tiles
+//                    in LDS (3x3 halo, and one more column / row for the radius-2 composite
+//                    stencil); the UFLX/VFLX tiles themselves are formed in LDS from the wind tiles.
+//                    HBM traffic per launch: 7-9 reads + 2 writes instead of the 41 passes of the
+//                    three stage kernels.
+// k_continuity_reg : dyn_continuity.py:170-232, vertical sums in registers, WWIND the only 3-D output.
+// k_pott_fused     : dyn_POTT.py + POTT part of dyn_timestep.py + dyn_diagnostics.py:139-195.
 //
 // Mapping: lane <-> longitude i (64 per wavefront), threadIdx.y <-> latitude row, k loop in
 // the thread; one workgroup = 64 x FTJ columns.  Tiles are (FTJ+3) rows x 68 columns of
@@ -309,8 +313,9 @@ typedef const __attribute__((address_space(1))) void gbl_void_t;
 // FROM_WINDS: UFLX and VFLX are not staged (k_continuity_reg<., false> does not store them); their
 // tiles are re-formed in LDS every level from the UWIND / VWIND tiles and four per-tile 2-D factor
 // tiles, UFLX = UCOL * UWIND * dyis and VFLX = VCOL * VWIND * dxjs (operand order of the continuity
-// kernel, so the values are the ones it would have stored): 7 instead of 9 fields through the DMA
-// for one more barrier per level.
+// kernel, so the values are the ones it would have stored): 7 instead of 9 fields through the DMA.
+// Each DMA wavefront converts the chunks it moved itself once its own loads have landed (flux_own),
+// so the one barrier per level publishes the DMA data and the flux tiles together.
 template <bool OLD_IS_CUR, int TJ, bool FROM_WINDS>
 __global__ __launch_bounds__(FTI *TJ) void k_momentum_dma(Geo g, Ptrs p, int gbx, RowSet trows, int ksplit, int jv_lo,
                                                       const double *u_old, const double *v_old,

@@ -238,15 +238,16 @@ int launch_check(const char *what)
 
 // lateral halo (misc_boundaries.py:22-42) of up to 12 fields in one launch
 struct HaloSpec { double *ptr; int stgx, stgy, nk; };
-int do_halo_noscope(dycore *h, const std::vector<HaloSpec> &fields);
-int do_halo(dycore *h, const std::vector<HaloSpec> &fields)
+int do_halo_noscope(dycore *h, const std::vector<HaloSpec> &fields, double *copy_dst = nullptr, const double *copy_src = nullptr, size_t copy_n = 0);
+int do_halo(dycore *h, const std::vector<HaloSpec> &fields, double *copy_dst = nullptr, const double *copy_src = nullptr, size_t copy_n = 0)
 {
     Scope s(h, K_HALO_MULTI);
-    return do_halo_noscope(h, fields);
+    return do_halo_noscope(h, fields, copy_dst, copy_src, copy_n);
 }
-int do_halo_noscope(dycore *h, const std::vector<HaloSpec> &fields)
+int do_halo_noscope(dycore *h, const std::vector<HaloSpec> &fields, double *copy_dst, const double *copy_src, size_t copy_n)
 {
     HaloList l;
+    l.copy_dst = copy_dst; l.copy_src = copy_src; l.copy_n = (long long)copy_n;
     l.n = 0;
     int maxk = 1, maxcells = 0;
     for (const HaloSpec &f : fields) {
@@ -257,7 +258,7 @@ int do_halo_noscope(dycore *h, const std::vector<HaloSpec> &fields)
         if (cells > maxcells) maxcells = cells;
     }
     if (!l.n) return 0;
-    hipLaunchKernelGGL(k_halo_multi, dim3((maxcells + 255) / 256, maxk, l.n), dim3(256), 0, h->stream, h->g, l);
+    hipLaunchKernelGGL(k_halo_multi, dim3((maxcells + 255) / 256, maxk, l.n + (copy_dst ? 1 : 0)), dim3(256), 0, h->stream, h->g, l);
     return launch_check("k_halo_multi");
 }
 
@@ -659,8 +660,8 @@ int substep_part(dycore *h, double dt, int sub, int part)
                 hl.push_back({u_out, 1, 0, nz});
                 hl.push_back({v_out, 0, 1, nz});
             }
-            if ((rc = do_halo(h, hl))) return rc;
-            return do_copy(h, p.COLP, p.COLP_NEW, (size_t)h->g.plane);   // -> winds, POTT halo rows
+            // + COLP <- COLP_NEW (dyn_matsuno.py:64-67) as a rider of the same launch  -> winds, POTT halo rows
+            return do_halo(h, hl, p.COLP, p.COLP_NEW, (size_t)h->g.plane);
         }
         case 2: {
             Ptrs d = p;

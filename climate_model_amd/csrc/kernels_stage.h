@@ -891,10 +891,23 @@ struct HaloList {
     int n;
     double *base[12];
     int stgx[12], stgy[12], nk[12];
+    // optional rider: a plain copy of one 2-D plane (COLP <- COLP_NEW of dyn_matsuno.py:64-67) on the
+    // z-slice after the last field, so that the step does not pay a launch for it
+    const double *copy_src;
+    double *copy_dst;
+    long long copy_n;
 };
 __global__ void k_halo_multi(Geo g, HaloList l)
 {
     const int e = blockIdx.z, k = blockIdx.y;
+    if (e == l.n) {
+        if (l.copy_dst) {
+            const long long stride = (long long)gridDim.x * gridDim.y * blockDim.x;
+            for (long long t = ((long long)k * gridDim.x + blockIdx.x) * blockDim.x + threadIdx.x; t < l.copy_n; t += stride)
+                l.copy_dst[t] = l.copy_src[t];
+        }
+        return;
+    }
     if (e >= l.n || k >= l.nk[e]) return;
     int t = blockIdx.x * blockDim.x + threadIdx.x;
     const int stgx = l.stgx[e], stgy = l.stgy[e];

@@ -640,8 +640,9 @@ int substep_part(dycore *h, double dt, int sub, int part)
             return do_momentum_fused(h, q, p.UWIND, p.VWIND, u_out, v_out, dt, ROWS_INNER);
         case DYCORE_PART_MOM_EDGE:  // -> new winds complete: their rows can travel while part TEMP runs
             if ((rc = join_side(h))) return rc;
-            if ((rc = do_momentum_fused(h, q, p.UWIND, p.VWIND, u_out, v_out, dt, ROWS_EDGE))) return rc;
-            return do_halo(h, {{u_out, 1, 0, h->g.nz}, {v_out, 0, 1, h->g.nz}});
+            // the rows that leave now are packed with their periodic images (k_rows); the lateral halo of
+            // the new winds is refreshed with everything else at the end of part TEMP
+            return do_momentum_fused(h, q, p.UWIND, p.VWIND, u_out, v_out, dt, ROWS_EDGE);
         case 1:
         case DYCORE_PART_TEMP: {    // momentum reads the old diagnostics, so it runs first
             if (part == 1) {
@@ -656,10 +657,8 @@ int substep_part(dycore *h, double dt, int sub, int part)
             std::vector<HaloSpec> hl = {{t_out, 0, 0, nz}, {p.PVTF, 0, 0, nz}, {p.PVTFVB, 0, 0, nz + 1},
                                         {p.PHI, 0, 0, nz}, {p.POTTVB, 0, 0, nz + 1}};
             if (!h->lazy) hl.push_back({p.PHIVB, 0, 0, nz + 1});
-            if (part == 1) {            // after MOM_EDGE the winds are done (their rows may be travelling)
-                hl.push_back({u_out, 1, 0, nz});
-                hl.push_back({v_out, 0, 1, nz});
-            }
+            hl.push_back({u_out, 1, 0, nz});   // owned rows and pole rows only: rows in flight from a neighbour are not touched
+            hl.push_back({v_out, 0, 1, nz});
             // + COLP <- COLP_NEW (dyn_matsuno.py:64-67) as a rider of the same launch  -> winds, POTT halo rows
             return do_halo(h, hl, p.COLP, p.COLP_NEW, (size_t)h->g.plane);
         }

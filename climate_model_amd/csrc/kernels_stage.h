@@ -989,10 +989,13 @@ __global__ void k_rows(Geo g, RowList rl, double *buf, int unpack)
     const int e = blockIdx.z, k = blockIdx.y;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= rl.n || k >= rl.nk[e] || i > g.nx + 2) return;
-    double *f = rl.base[e] + (size_t)k * g.plane + (size_t)rl.row[e] * g.P + i;
+    double *f = rl.base[e] + (size_t)k * g.plane + (size_t)rl.row[e] * g.P;
     double *b = buf + rl.off[e] + (size_t)k * (g.nx + 3) + i;
-    if (unpack) *f = *b;
-    else *b = *f;
+    if (unpack) { f[i] = *b; return; }
+    // a packed row carries the periodic images of its interior columns (misc_boundaries.py:22-31), so a
+    // sender need not refresh the lateral halo of a field before its rows leave
+    const int si = i == 0 ? g.nx : (i == g.nx + 1 ? 1 : (i == g.nx + 2 ? 2 : i));
+    *b = f[si];
 }
 
 __global__ void k_fill(double *dst, size_t n, double v)

@@ -156,7 +156,8 @@ int dycore_step_matsuno(dycore_t *h, double dt, int32_t nsteps, int32_t with_rho
  * transport runs on; ordering between the streams is the caller's (events).
  * pack/unpack move whole rows (columns 0..nx+2, all
  * levels) of the named fields between the field buffers and one contiguous device buffer,
- * entry e at offset sum_{e'<e} levels(e')*(nx+3) doubles. */
+ * entry e at offset sum_{e'<e} levels(e')*(nx+3) doubles; packed columns 0, nx+1, nx+2 are the periodic
+ * images of columns nx, 1, 2 of the same row. */
 int dycore_step_begin(dycore_t *h, int32_t with_rho);
 /* name of the registered field that holds `name` (UWIND, VWIND or POTT) right after part 1 of
  * the given substep: the fused step writes the predictor state into *_EST scratch fields */

@@ -64,7 +64,11 @@ def main():
         for send, recv in (('send_south', 'recv_north'), ('send_north', 'recv_south')):
             for n, srow, rrow in zip(plan[send][0], plan[send][1], plan[recv][1]):
                 assert plan[recv][0] == plan[send][0]
-                np.testing.assert_array_equal(got[n][:, rrow], host[n][:, srow], err_msg='%s row %d -> %d' % (n, srow, rrow))
+                want = host[n][:, srow].copy()          # a packed row carries the periodic images of its interior columns
+                want[0], want[nx + 1] = want[nx], want[1]
+                if want.shape[0] > nx + 2:
+                    want[nx + 2] = want[2]
+                np.testing.assert_array_equal(got[n][:, rrow], want, err_msg='%s row %d -> %d' % (n, srow, rrow))
                 checked += 1
     assert checked >= 14
     for n in names:

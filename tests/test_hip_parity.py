@@ -381,3 +381,42 @@ def test_solver_history_restart_and_testsuite_criterion(tmp_path):
                                              out=lambda s: None)
     assert not failed and len(devs) >= 7
     core.close()
+
+
+@pytest.mark.gpu
+def test_abi_error_reporting():
+    """Misuse comes back as an error code + message (the reference has no error path): unknown names,
+    wrong shapes, missing grid constants, out-of-range parts / rows, oversized fields."""
+    from climate_model_amd import HipDycore, DycoreError
+    core = HipDycore(36, 18, 4)
+    with pytest.raises(DycoreError, match='unknown field'):
+        core.upload('NOPE', np.zeros((38, 20, 4)))
+    with pytest.raises(DycoreError, match='grid constants missing'):
+        core.step_matsuno(10., 1)
+    import ctypes as C
+    dp = C.POINTER(C.c_double)
+    a = np.zeros((37, 20, 1))
+    with pytest.raises(DycoreError, match='unknown grid array'):
+        core._check(core.lib.dycore_set_grid(core._h, b'nope', a.ctypes.data_as(dp), 37, 20, 1))
+    with pytest.raises(DycoreError, match='expected shape'):
+        core._check(core.lib.dycore_set_grid(core._h, b'A', a.ctypes.data_as(dp), 37, 20, 1))
+    z = load_golden('g10x4_dry')
+    GR = grid_from_golden(z)
+    core.set_grid(GR.GRF['HIP'])
+    with pytest.raises(DycoreError, match='out of range'):
+        core.substep_part(10., 0, 7)
+    import torch
+    buf = torch.empty(8 * 39, dtype=torch.float64, device='cuda')
+    with pytest.raises(DycoreError, match='outside field'):
+        core.pack_rows(['UWIND'], [99], buf.data_ptr())
+    with pytest.raises(DycoreError, match='null buffer'):
+        core.pack_rows(['UWIND'], [1], 0)
+    with pytest.raises((DycoreError, ValueError)):
+        core.upload('UWIND', np.zeros((38, 20, 4)))          # x-staggered field needs 39 columns
+    core.close()
+    with pytest.raises(DycoreError, match='4 GiB'):
+        HipDycore(4000, 2000, 128)
+    with pytest.raises(DycoreError, match='too small'):
+        HipDycore(2, 2, 2)
+    with pytest.raises(DycoreError, match='outside the global grid'):
+        HipDycore(36, 10, 4, ny_global=18, j_offset=12)

@@ -120,7 +120,7 @@ def _setup_nxny(nx, ny, nz):
 
 
 @pytest.mark.parametrize('nx,ny,nz', [(3, 2, 2), (5, 3, 2), (63, 7, 3), (64, 8, 4), (65, 9, 5), (67, 16, 8),
-                                      (130, 17, 16), (200, 33, 7), (96, 25, 64)])
+                                      (130, 17, 16), (200, 33, 7), (96, 25, 64), (70, 12, 96), (40, 10, 200)])
 def test_ragged_sizes_vs_oracle(nx, ny, nz):
     """Smallest legal grid, extents around the 64-lane / 8-row tile sizes, level counts with and
     without the unrolled continuity kernel and the level-split momentum tiles: 3 steps against the

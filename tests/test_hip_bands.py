@@ -84,12 +84,14 @@ def test_local_bands_bitwise_equal_single(nbands, i_turb, i_moist, overlap):
         c.close()
 
 
-def test_two_process_gloo_bands_equal_single(tmp_path):
-    """bench.py-style launch: 2 ranks share the one GPU, exchange through torch.distributed."""
+@pytest.mark.parametrize('nproc', [2, 4])
+def test_multi_process_gloo_bands_equal_single(tmp_path, nproc):
+    """bench.py-style launch: the ranks share the one GPU and exchange through torch.distributed (gloo with
+    host staging); with 4 ranks two bands have a neighbour on both sides."""
     s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
     out = tmp_path / 'bands.npz'
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0', DYCORE_BANDS_BACKEND='gloo', DYCORE_BANDS_ONE_GPU='1')
-    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(nproc),
            '--master-addr', '127.0.0.1', '--master-port', str(port),
            os.path.join(ROOT, 'tests', 'band_worker.py'), str(out)]
     r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)

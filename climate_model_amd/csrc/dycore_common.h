@@ -41,6 +41,8 @@ struct Ptrs {
     // 3-D
     double *UWIND, *UWIND_OLD, *VWIND, *VWIND_OLD, *WWIND;
     double *UWIND_EST, *VWIND_EST, *POTT_EST;   // predictor state of the fused step (library scratch)
+    // raw turbulent tendencies of the fused turbulence-coupled step (library scratch; only with i_turb)
+    double *TURB_U, *TURB_V, *TURB_T, *TURB_QV, *TURB_QC;
     double *UCOL, *VCOL;                        // 2-D: column pressure at the u- / v-point, (COLP[i-1]+COLP)/2, (COLP[j-1]+COLP)/2
     double *POTT, *POTT_OLD, *POTTVB;
     double *UFLX, *VFLX, *FLXDIV;

@@ -51,12 +51,13 @@ struct FieldDesc {
     int stgx, stgy;
     int nk;                         // 0 -> nz, -1 -> nz+1, 1 -> 1
     double *Ptrs::*member;
-    int rad;                        // 1: exists only on handles created with i_radiation
+    int rad;                        // 1: exists only on handles created with i_radiation; 2: only with i_turb
 };
 
 // main_fields.py:234-475
 #define F_(n, sx, sy, nk) {#n, sx, sy, nk, &Ptrs::n, 0}
 #define R_(n, nk) {#n, 0, 0, nk, &Ptrs::n, 1}
+#define T_(n, sx, sy) {#n, sx, sy, 0, &Ptrs::n, 2}
 const FieldDesc kFields[] = {
     F_(COLP, 0, 0, 1), F_(COLP_OLD, 0, 0, 1), F_(COLP_NEW, 0, 0, 1), F_(dCOLPdt, 0, 0, 1), F_(HSURF, 0, 0, 1),
     F_(UWIND, 1, 0, 0), F_(UWIND_OLD, 1, 0, 0), F_(VWIND, 0, 1, 0), F_(VWIND_OLD, 0, 1, 0), F_(WWIND, 0, 0, -1),
@@ -79,9 +80,12 @@ const FieldDesc kFields[] = {
     R_(SOILTEMP, 1), R_(SURFALBEDLW, 1), R_(SURFALBEDSW, 1), R_(SOLZEN, 1), R_(MYSUN, 1), R_(SWINTOA, 1),
     R_(LWFLXDO, -1), R_(LWFLXUP, -1), R_(SWDIFFLXDO, -1), R_(SWDIRFLXDO, -1), R_(SWFLXUP, -1), R_(SWFLXDO, -1),
     R_(LWFLXNET, -1), R_(SWFLXNET, -1), R_(SWFLXDIV, 0), R_(LWFLXDIV, 0), R_(TOTFLXDIV, 0),
+    // raw turbulent tendencies of the fused turbulence-coupled step
+    T_(TURB_U, 1, 0), T_(TURB_V, 0, 1), T_(TURB_T, 0, 0), T_(TURB_QV, 0, 0), T_(TURB_QC, 0, 0),
 };
 #undef F_
 #undef R_
+#undef T_
 constexpr int kNFields = sizeof(kFields) / sizeof(kFields[0]);
 
 struct GridDesc {
@@ -102,12 +106,12 @@ constexpr int kNGrid = sizeof(kGrid) / sizeof(kGrid[0]);
 
 // kernels tracked by the profiler
 enum KernelId {
-    K_CONTINUITY = 0, K_PREPARE, K_UFLX, K_VFLX, K_POTT, K_EULER, K_DIAG, K_RHO, K_EXCHANGE, K_COPY, K_HALO, K_MOM_FUSED, K_POTT_FUSED, K_DIAG_ROWS, K_HALO_MULTI, K_CONT_REG, K_DERIVE, K_MOIST, K_SECONDARY, K_TURB, K_RAD,
+    K_CONTINUITY = 0, K_PREPARE, K_UFLX, K_VFLX, K_POTT, K_EULER, K_DIAG, K_RHO, K_EXCHANGE, K_COPY, K_HALO, K_MOM_FUSED, K_POTT_FUSED, K_DIAG_ROWS, K_HALO_MULTI, K_CONT_REG, K_DERIVE, K_MOIST, K_SECONDARY, K_TURB, K_RAD, K_TURB_TEND,
     K_COUNT
 };
 const char *kKernelNames[K_COUNT] = {
     "k_continuity", "k_prepare", "k_uflx_tendency", "k_vflx_tendency", "k_pott_tendency",
-    "k_euler_forward", "k_primary_diag", "k_diag_rho", "k_exchange_bc", "copy_field", "k_rows", "k_momentum_fused", "k_pott_fused", "k_primary_diag_rows", "k_halo_multi", "k_continuity_reg", "k_derive", "k_moist", "k_diag_secondary", "k_turbulence", "k_radiation",
+    "k_euler_forward", "k_primary_diag", "k_diag_rho", "k_exchange_bc", "copy_field", "k_rows", "k_momentum_fused", "k_pott_fused", "k_primary_diag_rows", "k_halo_multi", "k_continuity_reg", "k_derive", "k_moist", "k_diag_secondary", "k_turbulence", "k_radiation", "k_turb_tendencies",
 };
 
 struct ProfRec { int kid; hipEvent_t a, b; };
@@ -133,6 +137,7 @@ struct dycore {
     int grid_set = 0;
     bool fused = true;              // production kernels in dycore_step_matsuno (DYCORE_FUSED=0: stage kernels)
     bool lazy = true;               // fused step leaves FLXDIV / PHIVB to be derived on demand (DYCORE_LAZY=0: store them)
+    bool fused_turb = true;         // DYCORE_FUSED_TURB=0: a turbulence-coupled handle steps on the stage kernels
     int fw_mask = 7;                // DYCORE_FW_MASK (debug): 1 continuity stores no fluxes, 2 momentum, 4 temperature/moisture re-form them
     bool lazy_flx = true;           // ... nor UFLX / VFLX: consumers re-form them from the winds (DYCORE_LAZY_FLX=0: store them)
     bool stale_flxdiv = false, stale_phivb = false, stale_uvflx = false;
@@ -498,9 +503,10 @@ int do_momentum_fused(dycore *h, const Ptrs &p, const double *u_old, const doubl
         const dim3 gr2(8 * ((gbx * trows.n * ks + 7) / 8)), blk(FTI, tj);
         const bool cur = (u_old == p.UWIND);
         const bool fw = flux_from_winds(h) && (h->fw_mask & 2);
-#define MOM_LAUNCH(CUR_, FW_) hipLaunchKernelGGL((k_momentum_dma<CUR_, tj, FW_>), gr2, blk, dma_lds_bytes(tj, FW_), h->stream, h->g, p, gbx, trows, ks, jv_lo, u_old, v_old, u_out, v_out, dt)
-        if (cur) { if (fw) MOM_LAUNCH(true, true); else MOM_LAUNCH(true, false); }
-        else { if (fw) MOM_LAUNCH(false, true); else MOM_LAUNCH(false, false); }
+#define MOM_LAUNCH(CUR_, FW_, TB_) hipLaunchKernelGGL((k_momentum_dma<CUR_, tj, FW_, TB_>), gr2, blk, dma_lds_bytes(tj, FW_), h->stream, h->g, p, gbx, trows, ks, jv_lo, u_old, v_old, u_out, v_out, dt)
+        if (h->g.i_turb) { if (cur) MOM_LAUNCH(true, true, true); else MOM_LAUNCH(false, true, true); }
+        else if (cur) { if (fw) MOM_LAUNCH(true, true, false); else MOM_LAUNCH(true, false, false); }
+        else { if (fw) MOM_LAUNCH(false, true, false); else MOM_LAUNCH(false, false, false); }
 #undef MOM_LAUNCH
     } else if (u_out)
         hipLaunchKernelGGL(k_momentum_fused<true>, gr, bl, 0, h->stream, h->g, p, gbx, gby, jv_lo, u_old, v_old, u_out, v_out, dt);
@@ -511,15 +517,34 @@ int do_momentum_fused(dycore *h, const Ptrs &p, const double *u_old, const doubl
 int do_pott_fused(dycore *h, const Ptrs &p, const double *pott_old, double *pott_out, double dt)
 {
     Scope s(h, K_POTT_FUSED);
-    if (h->lazy) {
-        if (flux_from_winds(h) && (h->fw_mask & 4))
-            hipLaunchKernelGGL((k_pott_fused<false, true>), grid_cells(h), dim3(TI, TJ), 0, h->stream, h->g, p, pott_old, pott_out, dt, cells_linear(h));
-        else
-            hipLaunchKernelGGL((k_pott_fused<false, false>), grid_cells(h), dim3(TI, TJ), 0, h->stream, h->g, p, pott_old, pott_out, dt, cells_linear(h));
+    const dim3 gr = grid_cells(h), bl(TI, TJ);
+    const int lin = cells_linear(h);
+#define POTT_LAUNCH(W_, F_, T_) hipLaunchKernelGGL((k_pott_fused<W_, F_, T_>), gr, bl, 0, h->stream, h->g, p, pott_old, pott_out, dt, lin)
+    if (h->g.i_turb) {                  // fused turbulence-coupled step: PHIVB is an input of k_turb_tendencies, so it is stored
+        POTT_LAUNCH(true, true, true);
+    } else if (h->lazy) {
+        if (flux_from_winds(h) && (h->fw_mask & 4)) POTT_LAUNCH(false, true, false);
+        else POTT_LAUNCH(false, false, false);
         h->stale_phivb = true;
     } else
-        hipLaunchKernelGGL((k_pott_fused<true, false>), grid_cells(h), dim3(TI, TJ), 0, h->stream, h->g, p, pott_old, pott_out, dt, cells_linear(h));
+        POTT_LAUNCH(true, false, false);
+#undef POTT_LAUNCH
     return launch_check("k_pott_fused");
+}
+// the turbulent tendencies of the fused turbulence-coupled step (one launch per substep)
+int do_turb_tendencies(dycore *h, const Ptrs &p)
+{
+    int rc;
+    const int nz = h->g.nz;
+    // dyn_org_discretizations.py:195-196, 212-216: lateral BC of the K field and the surface momentum fluxes
+    // (whole-field exchange as in the staged step: these inputs are never exchanged between bands, so the
+    // periodic columns of a band's halo rows are refreshed here too)
+    if ((rc = do_exchange(h, p.KMOM, 0, 0, nz + 1))) return rc;
+    if ((rc = do_exchange(h, p.SMOMXFLX, 0, 0, 1))) return rc;
+    if ((rc = do_exchange(h, p.SMOMYFLX, 0, 0, 1))) return rc;
+    Scope s(h, K_TURB_TEND);
+    hipLaunchKernelGGL(k_turb_tendencies, grid_cells(h), dim3(TI, TJ), 0, h->stream, h->g, p, h->g.pole_s ? 2 : 1, cells_linear(h));
+    return launch_check("k_turb_tendencies");
 }
 // dQVdt, dQCdt (stage) or the new QV, QC directly (fused): dyn_moist.py
 int do_moist(dycore *h, const Ptrs &p, const double *qv_old, const double *qc_old, double *qv_out, double *qc_out, double dt)
@@ -528,7 +553,8 @@ int do_moist(dycore *h, const Ptrs &p, const double *qv_old, const double *qc_ol
     const dim3 gr = grid_cells(h), bl(TI, TJ);
     const int lin = cells_linear(h);
     if (qv_out) {
-        if (h->g.i_turb) hipLaunchKernelGGL((k_moist<true, true>), gr, bl, 0, h->stream, h->g, p, qv_old, qc_old, qv_out, qc_out, dt, lin);
+        if (h->g.i_turb && fused_path(h)) hipLaunchKernelGGL((k_moist<false, true, true, true>), gr, bl, 0, h->stream, h->g, p, qv_old, qc_old, qv_out, qc_out, dt, lin);
+        else if (h->g.i_turb) hipLaunchKernelGGL((k_moist<true, true>), gr, bl, 0, h->stream, h->g, p, qv_old, qc_old, qv_out, qc_out, dt, lin);
         else if (fused_path(h) && flux_from_winds(h) && (h->fw_mask & 4)) hipLaunchKernelGGL((k_moist<false, true, true>), gr, bl, 0, h->stream, h->g, p, qv_old, qc_old, qv_out, qc_out, dt, lin);
         else hipLaunchKernelGGL((k_moist<false, true>), gr, bl, 0, h->stream, h->g, p, qv_old, qc_old, qv_out, qc_out, dt, lin);
     } else {
@@ -591,7 +617,9 @@ int do_momentum(dycore *h, const Ptrs &p)
 // (k_euler_forward reads X_OLD and the tendency at the written cell only).
 // The step is cut into parts at the two points where a latitude band needs rows from its
 // neighbours (after continuity, after the Euler step); a single band runs them back to back.
-bool fused_path(const dycore *h) { return h->fused && !h->g.i_turb; }
+// the turbulence-coupled fused step needs the kernels that re-form the fluxes from the winds (LDS-DMA
+// momentum, register continuity); otherwise an i_turb handle steps on the stage kernels
+bool fused_path(const dycore *h) { return h->fused && (!h->g.i_turb || (h->fused_turb && flux_from_winds(h) && h->fw_mask == 7)); }
 
 // Fused (production, dry) scheme -- no time-level swaps: X holds the state S0 at step start
 // through the predictor, X_EST receives the estimate S1, the corrector evaluates on X_EST and
@@ -637,8 +665,10 @@ int substep_part(dycore *h, double dt, int sub, int part)
         case 0:                     // -> UFLX, VFLX, WWIND, COLP_NEW halo rows
             return do_continuity_fused(h, q, dt);
         case DYCORE_PART_MOM_INNER:
+            if (h->g.i_turb) return fail(DYCORE_ESTATE, "split parts are not available on a turbulence-coupled handle (dycore_overlap_parts)");
             return do_momentum_fused(h, q, p.UWIND, p.VWIND, u_out, v_out, dt, ROWS_INNER);
         case DYCORE_PART_MOM_EDGE:  // -> new winds complete: their rows can travel while part TEMP runs
+            if (h->g.i_turb) return fail(DYCORE_ESTATE, "split parts are not available on a turbulence-coupled handle (dycore_overlap_parts)");
             if ((rc = join_side(h))) return rc;
             // the rows that leave now are packed with their periodic images (k_rows); the lateral halo of
             // the new winds is refreshed with everything else at the end of part TEMP
@@ -647,8 +677,10 @@ int substep_part(dycore *h, double dt, int sub, int part)
         case DYCORE_PART_TEMP: {    // momentum reads the old diagnostics, so it runs first
             if (part == 1) {
                 if ((rc = join_side(h))) return rc;
+                if (h->g.i_turb && (rc = do_turb_tendencies(h, q))) return rc;
                 if ((rc = do_momentum_fused(h, q, p.UWIND, p.VWIND, u_out, v_out, dt))) return rc;
-            }
+            } else if (h->g.i_turb)
+                return fail(DYCORE_ESTATE, "split parts are not available on a turbulence-coupled handle (dycore_overlap_parts)");
             if ((rc = do_pott_fused(h, q, p.POTT, t_out, dt))) return rc;
             double *qv_out = sub == 0 ? p.QV_EST : p.QV, *qc_out = sub == 0 ? p.QC_EST : p.QC;
             if (h->g.i_moist && (rc = do_moist(h, q, p.QV, p.QC, qv_out, qc_out, dt))) return rc;
@@ -656,7 +688,7 @@ int substep_part(dycore *h, double dt, int sub, int part)
             if (h->g.i_moist && (rc = do_halo(h, {{qv_out, 0, 0, nz}, {qc_out, 0, 0, nz}}))) return rc;
             std::vector<HaloSpec> hl = {{t_out, 0, 0, nz}, {p.PVTF, 0, 0, nz}, {p.PVTFVB, 0, 0, nz + 1},
                                         {p.PHI, 0, 0, nz}, {p.POTTVB, 0, 0, nz + 1}};
-            if (!h->lazy) hl.push_back({p.PHIVB, 0, 0, nz + 1});
+            if (!h->lazy || h->g.i_turb) hl.push_back({p.PHIVB, 0, 0, nz + 1});
             hl.push_back({u_out, 1, 0, nz});   // owned rows and pole rows only: rows in flight from a neighbour are not touched
             hl.push_back({v_out, 0, 1, nz});
             // + COLP <- COLP_NEW (dyn_matsuno.py:64-67) as a rider of the same launch  -> winds, POTT halo rows
@@ -740,6 +772,7 @@ int dycore_create(const DycoreConfig *cfg, dycore_t **out)
     if (const char *e = getenv("DYCORE_MOM_DMA")) h->mom_dma = atoi(e);
     if (const char *e = getenv("DYCORE_LAZY")) h->lazy = atoi(e) != 0;
     if (const char *e = getenv("DYCORE_LAZY_FLX")) h->lazy_flx = atoi(e) != 0;
+    if (const char *e = getenv("DYCORE_FUSED_TURB")) h->fused_turb = atoi(e) != 0;
     if (const char *e = getenv("DYCORE_FW_MASK")) h->fw_mask = atoi(e);
     if (const char *e = getenv("DYCORE_MOM_KS")) h->mom_ks = atoi(e);
     if (const char *e = getenv("DYCORE_CELL_LINEAR")) h->cell_lin = atoi(e);
@@ -752,6 +785,8 @@ int dycore_create(const DycoreConfig *cfg, dycore_t **out)
         hipError_t e2 = hipFuncSetAttribute((const void *)k_momentum_dma<false, FTJ, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dma_lds_bytes(FTJ, false));
         hipError_t e3 = hipFuncSetAttribute((const void *)k_momentum_dma<true, FTJ, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dma_lds_bytes(FTJ, true));
         hipError_t e4 = hipFuncSetAttribute((const void *)k_momentum_dma<false, FTJ, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dma_lds_bytes(FTJ, true));
+        if (e3 == hipSuccess) e3 = hipFuncSetAttribute((const void *)k_momentum_dma<true, FTJ, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dma_lds_bytes(FTJ, true));
+        if (e4 == hipSuccess) e4 = hipFuncSetAttribute((const void *)k_momentum_dma<false, FTJ, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dma_lds_bytes(FTJ, true));
         if (e1 != hipSuccess || e2 != hipSuccess) { (void)hipGetLastError(); h->mom_dma = 0; }
         if (e3 != hipSuccess || e4 != hipSuccess) { (void)hipGetLastError(); h->lazy_flx = false; }
     }
@@ -790,7 +825,7 @@ int dycore_create(const DycoreConfig *cfg, dycore_t **out)
     int rc = 0;
     for (int f = 0; f < kNFields && !rc; f++) {
         double *d = nullptr;
-        if (!kFields[f].rad || g.i_rad) rc = alloc(h->field_elems(kFields[f].nk), &d);
+        if (!kFields[f].rad || (kFields[f].rad == 1 && g.i_rad) || (kFields[f].rad == 2 && g.i_turb)) rc = alloc(h->field_elems(kFields[f].nk), &d);
         h->p.*(kFields[f].member) = d;
         h->field_idx[kFields[f].name] = f;
     }
@@ -850,7 +885,7 @@ int dycore_use_stream(dycore_t *h, void *stream)
     return 0;
 }
 void *dycore_get_stream(dycore_t *h) { return h ? (void *)h->home : nullptr; }
-int dycore_overlap_parts(dycore_t *h) { return h && fused_path(h) ? 1 : 0; }
+int dycore_overlap_parts(dycore_t *h) { return h && fused_path(h) && !h->g.i_turb ? 1 : 0; }
 int dycore_flux_from_winds(dycore_t *h) { return h && fused_path(h) && flux_from_winds(h) ? 1 : 0; }
 int dycore_sync(dycore_t *h)
 {
@@ -901,7 +936,8 @@ static int find_field(dycore_t *h, const char *name, const FieldDesc **d)
     auto it = h->field_idx.find(name);
     if (it == h->field_idx.end()) return fail(DYCORE_EINVAL, "unknown field '%s'", name);
     *d = &kFields[it->second];
-    if (!(h->p.*((*d)->member))) return fail(DYCORE_ESTATE, "field '%s' exists only on handles created with i_radiation", name);
+    if (!(h->p.*((*d)->member)))
+        return fail(DYCORE_ESTATE, "field '%s' exists only on handles created with %s", name, (*d)->rad == 2 ? "i_turb" : "i_radiation");
     return 0;
 }
 

@@ -316,7 +316,9 @@ typedef const __attribute__((address_space(1))) void gbl_void_t;
 // kernel, so the values are the ones it would have stored): 7 instead of 9 fields through the DMA.
 // Each DMA wavefront converts the chunks it moved itself once its own loads have landed (flux_own),
 // so the one barrier per level publishes the DMA data and the flux tiles together.
-template <bool OLD_IS_CUR, int TJ, bool FROM_WINDS>
+// TURB: the turbulent tendencies of k_turb_tendencies (own cell, fetched one level ahead into
+// registers) join the sums.
+template <bool OLD_IS_CUR, int TJ, bool FROM_WINDS, bool TURB = false>
 __global__ __launch_bounds__(FTI *TJ) void k_momentum_dma(Geo g, Ptrs p, int gbx, RowSet trows, int ksplit, int jv_lo,
                                                       const double *u_old, const double *v_old,
                                                       double *u_out, double *v_out, double dt)
@@ -521,12 +523,16 @@ __global__ __launch_bounds__(FTI *TJ) void k_momentum_dma(Geo g, Ptrs p, int gbx
         }
     };
     issue(k0, k0 & 1);
+    double tbu_nx = 0.0, tbv_nx = 0.0;  // turbulent tendencies of the next level
+    if (TURB) { tbu_nx = p.TURB_U[c + (size_t)k0 * g.plane]; tbv_nx = v_on ? p.TURB_V[c + (size_t)k0 * g.plane] : 0.0; }
     __syncthreads();                    // factor tiles, constants (and level k0) visible
     flux_own(k0 & 1);
     __syncthreads();
 #pragma unroll 1
     for (int k = k0; k < k1; k++) {
         if (k + 1 < k1) issue(k + 1, (k + 1) & 1);
+        const double tbu = tbu_nx, tbv = tbv_nx;
+        if (TURB && k + 1 < k1) { tbu_nx = p.TURB_U[c + (size_t)(k + 1) * g.plane]; tbv_nx = v_on ? p.TURB_V[c + (size_t)(k + 1) * g.plane] : 0.0; }
         const double *buf = dsm + (k & 1) * BUF;
         if (active) {
             const double ds = c_ds[k];
@@ -611,6 +617,7 @@ __global__ __launch_bounds__(FTI *TJ) void k_momentum_dma(Geo g, Ptrs p, int gbx
                                  ds, svb, svb1, dyis);
                 if (dif > 0.0)
                     t = t + dif * (UF(-1, 0) + UF(1, 0) + UF(0, -1) + UF(0, 1) - 4.0 * UF(0, 0));
+                if (TURB) t = t + tbu;
                 tu_km1 = t;
             }
             // =============================== dVFLXdt ===============================
@@ -635,6 +642,7 @@ __global__ __launch_bounds__(FTI *TJ) void k_momentum_dma(Geo g, Ptrs p, int gbx
                                  ds, svb, svb1, dxjs);
                 if (dif > 0.0)
                     t = t + dif * (VF(-1, 0) + VF(1, 0) + VF(0, -1) + VF(0, 1) - 4.0 * VF(0, 0));
+                if (TURB) t = t + tbv;
                 tv_km1 = t;
             }
 #undef UF
@@ -661,6 +669,113 @@ __global__ __launch_bounds__(FTI *TJ) void k_momentum_dma(Geo g, Ptrs p, int gbx
         if (v_on) v_out[qm] = vo_km1 * cao_js * r_ca_js + dt * (tv_km1 + (wv_km1 - wv_k) * c_rds[k1 - 1]) * r_ca_js;
     }
 #undef SM
+}
+
+// ------------------------------------------------------------------------------------
+// k_turb_tendencies: the vertical-turbulence terms of the momentum, temperature and moisture
+// tendencies for the fused step of a turbulence-coupled handle (i_turb), evaluated once per substep
+// on the state the tendencies are taken at and kept as five raw 3-D fields that the fused kernels
+// add at their own cell:
+//   TURB_U, TURB_V : dyn_UVFLX_prepare.py:318-439 (KMOM_dUWINDdz, KMOM_dVWINDdz; dyn_functions.py:276-377)
+//                    + dyn_UFLX.py:158-167 / dyn_VFLX.py:157-166 -- the expressions of k_prepare<true> and
+//                    k_uflx/vflx_tendency<true>, the interface values carried instead of stored
+//   TURB_T, TURB_QV, TURB_QC : dyn_functions.py:26-67 (turb_flux) as in k_pott_tendency<true>, k_moist<true>
+// One thread per owned column, levels top-down.
+__global__ __launch_bounds__(TI *TJ) void k_turb_tendencies(Geo g, Ptrs p, int jv_lo, int lin)
+{
+    int i, j;
+    if (!owned_cell(g, lin, i, j)) return;
+    const int P = g.P, nz = g.nz;
+    const size_t c = at2(g, i, j), pl = (size_t)g.plane;
+    const int jg = j + g.joff;
+    const bool lo = (jg == 1), hi = (jg == g.ny_global);
+    const bool v_on = j >= jv_lo;
+    const double colp = p.COLP[c];
+    // COLP * A at the points of the two six-point stencils
+#define CAo(a, b) (p.COLP[c + (b) * P + (a)] * p.A[c + (b) * P + (a)])
+    // ---- u-point (i-1/2, j): columns i-1, i; rows j-1 .. j+1 ----
+#define KT(a, b, q) (p.RHOVB[(q) + (b) * P + (a)] * p.COLP[c + (b) * P + (a)] * p.A[c + (b) * P + (a)] * p.KMOM[(q) + (b) * P + (a)])
+#define KT2(a, b, q) (2.0 * p.RHOVB[(q) + (b) * P + (a)] * p.COLP[c + (b) * P + (a)] * p.A[c + (b) * P + (a)] * p.KMOM[(q) + (b) * P + (a)])
+#define PH(a, b, q) p.PHI[(q) + (b) * P + (a)]
+    auto k6u = [&](size_t q) {
+        if (lo) return 0.25 * (KT(-1, 1, q) + KT(0, 1, q) + KT(-1, 0, q) + KT(0, 0, q));
+        if (hi) return 0.25 * (KT(-1, 0, q) + KT(0, 0, q) + KT(-1, -1, q) + KT(0, -1, q));
+        return 0.125 * (KT(-1, 1, q) + KT(0, 1, q) + KT2(-1, 0, q) + KT2(0, 0, q) + KT(-1, -1, q) + KT(0, -1, q));
+    };
+    auto altu = [&](size_t q) {
+        if (lo) return 0.25 * (PH(-1, 1, q) + PH(0, 1, q) + PH(-1, 0, q) + PH(0, 0, q)) / CON_G;
+        if (hi) return 0.25 * (PH(-1, 0, q) + PH(0, 0, q) + PH(-1, -1, q) + PH(0, -1, q)) / CON_G;
+        return 0.125 * (PH(-1, 1, q) + PH(0, 1, q) + 2.0 * PH(-1, 0, q) + 2.0 * PH(0, 0, q) + PH(-1, -1, q) + PH(0, -1, q)) / CON_G;
+    };
+    // ---- v-point (i, j-1/2): rows j-1, j; columns i-1 .. i+1 ----
+    auto k6v = [&](size_t q) {
+        return 0.125 * (KT(1, -1, q) + KT(1, 0, q) + KT2(0, -1, q) + KT2(0, 0, q) + KT(-1, -1, q) + KT(-1, 0, q));
+    };
+    auto altv = [&](size_t q) {
+        return 0.125 * (PH(1, -1, q) + PH(1, 0, q) + 2.0 * PH(0, -1, q) + 2.0 * PH(0, 0, q) + PH(-1, -1, q) + PH(-1, 0, q)) / CON_G;
+    };
+#undef CAo
+    // interp_VAR_ds (dyn_functions.py:383-424) of an interface / level field to the u- and the v-point
+    auto ds_u = [&](const double *F, size_t q) {
+        return var_ds(F[q], F[q - 1], F[q - P], F[q + P], F[q - P - 1], F[q + P - 1], lo, hi);
+    };
+    auto ds_v = [&](const double *F, size_t q) {
+        return var_ds(F[q], F[q - P], F[q - 1], F[q + 1], F[q - P - 1], F[q - P + 1], false, false);
+    };
+    const double smom_is = ds_u(p.SMOMXFLX, c), smom_js = ds_v(p.SMOMYFLX, c);
+    const double surf_t = p.SSHFLX[c] / CON_CP, surf_q = g.i_moist ? p.SLHFLX[c] / CON_LH : 0.0;
+
+    double kdu_k = 0.0, kdv_k = 0.0;                         // K dU/dz, K dV/dz at interface k (0 at the top)
+    double u_k = p.UWIND[c], v_k = p.VWIND[c];
+    double altu_k = altu(c), altv_k = altv(c);
+    double avu_k = ds_u(p.PHIVB, c) / CON_G, avv_k = ds_v(p.PHIVB, c) / CON_G;   // ALTVB at the u- / v-point (g twice: dyn_UFLX.py:141)
+    double pott_km1 = 0.0, qv_km1 = 0.0, qc_km1 = 0.0, phi_km1 = 0.0;
+    for (int k = 0; k < nz; k++) {
+        const size_t q = c + (size_t)k * pl, q1 = q + pl;
+        const bool last = (k == nz - 1);
+        // ---- momentum ----
+        double kdu_kp1 = 0.0, kdv_kp1 = 0.0, u_kp1 = 0.0, v_kp1 = 0.0, altu_kp1 = 0.0, altv_kp1 = 0.0;
+        if (!last) {
+            u_kp1 = p.UWIND[q1]; v_kp1 = p.VWIND[q1];
+            altu_kp1 = altu(q1); altv_kp1 = altv(q1);
+            kdu_kp1 = k6u(q1) * ((u_k - u_kp1) / (altu_k - altu_kp1));
+            kdv_kp1 = k6v(q1) * ((v_k - v_kp1) / (altv_k - altv_kp1));
+        }
+        const double avu_kp1 = ds_u(p.PHIVB, q1) / CON_G, avv_kp1 = ds_v(p.PHIVB, q1) / CON_G;
+        const double rho_is = ds_u(p.RHO, q), rho_js = ds_v(p.RHO, q);
+        double tu, tv;
+        if (k == 0) {
+            tu = (0.0 - kdu_kp1) / ((avu_k - avu_kp1) * rho_is);
+            tv = (0.0 - kdv_kp1) / ((avv_k - avv_kp1) * rho_js);
+        } else if (last) {
+            tu = (kdu_k + smom_is) / ((avu_k - avu_kp1) * rho_is);
+            tv = (kdv_k + smom_js) / ((avv_k - avv_kp1) * rho_js);
+        } else {
+            tu = (kdu_k - kdu_kp1) / ((avu_k - avu_kp1) * rho_is);
+            tv = (kdv_k - kdv_kp1) / ((avv_k - avv_kp1) * rho_js);
+        }
+        p.TURB_U[q] = tu;
+        if (v_on) p.TURB_V[q] = tv;
+        kdu_k = kdu_kp1; kdv_k = kdv_kp1; u_k = u_kp1; v_k = v_kp1;
+        altu_k = altu_kp1; altv_k = altv_kp1; avu_k = avu_kp1; avv_k = avv_kp1;
+        // ---- scalars ----
+        const double phi = p.PHI[q], phi_kp1 = last ? 0.0 : p.PHI[q1];
+        const double phivb = p.PHIVB[q], phivb_kp1 = p.PHIVB[q1];
+        const double kh = p.KHEAT[q], kh_kp1 = p.KHEAT[q1], rho = p.RHO[q], rvb = p.RHOVB[q], rvb_kp1 = p.RHOVB[q1];
+        const double pt = p.POTT[q], pt_kp1 = last ? 0.0 : p.POTT[q1];
+        p.TURB_T[q] = turb_flux(phi, phi_kp1, phi_km1, phivb, phivb_kp1, pt, pt_kp1, pott_km1, kh, kh_kp1, rho, rvb, rvb_kp1, colp, surf_t, k, nz);
+        pott_km1 = pt;
+        if (g.i_moist) {
+            const double qv = p.QV[q], qv_kp1 = last ? 0.0 : p.QV[q1], qc = p.QC[q], qc_kp1 = last ? 0.0 : p.QC[q1];
+            p.TURB_QV[q] = turb_flux(phi, phi_kp1, phi_km1, phivb, phivb_kp1, qv, qv_kp1, qv_km1, kh, kh_kp1, rho, rvb, rvb_kp1, colp, surf_q, k, nz);
+            p.TURB_QC[q] = turb_flux(phi, phi_kp1, phi_km1, phivb, phivb_kp1, qc, qc_kp1, qc_km1, kh, kh_kp1, rho, rvb, rvb_kp1, colp, 0.0, k, nz);
+            qv_km1 = qv; qc_km1 = qc;
+        }
+        phi_km1 = phi;
+    }
+#undef KT
+#undef KT2
+#undef PH
 }
 
 // ------------------------------------------------------------------------------------
@@ -778,7 +893,7 @@ __global__ __launch_bounds__(TI *TJ) void k_derive_phivb(Geo g, Ptrs p)
 __device__ __forceinline__ double ldb(const double *base, unsigned boff) { return *(const double *)((const char *)base + boff); }
 __device__ __forceinline__ void stb(double *base, unsigned boff, double v) { *(double *)((char *)base + boff) = v; }
 
-template <bool WRITE_PHIVB, bool FROM_WINDS>
+template <bool WRITE_PHIVB, bool FROM_WINDS, bool TURB = false>
 __global__ __launch_bounds__(TI *TJ) void k_pott_fused(Geo g, Ptrs p, const double *pott_old, double *pott_out, double dt, int lin)
 {
     int i, j;
@@ -809,9 +924,10 @@ __global__ __launch_bounds__(TI *TJ) void k_pott_fused(Geo g, Ptrs p, const doub
     const double m_dy0 = FROM_WINDS ? p.dyis[c] : 0.0, m_dy1 = FROM_WINDS ? p.dyis[c + 1] : 0.0;
     const double m_dx0 = FROM_WINDS ? p.dxjs[c] : 0.0, m_dx1 = FROM_WINDS ? p.dxjs[c + P] : 0.0;
     const double *fu = FROM_WINDS ? p.UWIND : p.UFLX, *fv = FROM_WINDS ? p.VWIND : p.VFLX;
-    struct In { double pt, im1, ip1, jm1, jp1, uf, uf1, vf, vf1, w, pvb, po; };
+    struct In { double pt, im1, ip1, jm1, jp1, uf, uf1, vf, vf1, w, pvb, po, tb; };
     auto load = [&](int k, In &r) {
         const unsigned q = bc + (unsigned)k * bpl;
+        r.tb = TURB ? ldb(p.TURB_T, q) : 0.0;
         r.pt = ldb(p.POTT, q); r.im1 = ldb(p.POTT, q - 8); r.ip1 = ldb(p.POTT, q + 8);
         r.jm1 = ldb(p.POTT, q - bP); r.jp1 = ldb(p.POTT, q + bP);
         r.uf = ldb(fu, q); r.uf1 = ldb(fu, q + 8); r.vf = ldb(fv, q); r.vf1 = ldb(fv, q + bP);
@@ -840,6 +956,7 @@ __global__ __launch_bounds__(TI *TJ) void k_pott_fused(Geo g, Ptrs p, const doub
             pvbo_k = cur.pvb;
             t = t + cnew * (+w_k * pvbo_k - w_kp1 * pvbo_kp1) * rds;
         }
+        if (TURB) t = t + cur.tb;                       // k_turb_tendencies (dyn_functions.py:26-67)
         const double dif = p.POTT_dif_coef[k];
         if (dif > 0.0)
             t = t + dif * (c_im1 * p_im1 + c_ip1 * p_ip1 + c_jm1 * p_jm1 + c_jp1 * p_jp1 - 4.0 * colp * pt);

@@ -512,7 +512,9 @@ __device__ __forceinline__ double turb_flux(double phi, double phi_kp1, double p
 // reference, multiplied by WWIND[nz] = 0: taken as 0 here.
 // FROM_WINDS: UFLX, VFLX are re-formed from the winds (fused step without stored fluxes, see
 // k_continuity_reg).
-template <bool TURB, bool EULER, bool FROM_WINDS = false>
+// TURB_PRE: the turbulent tendencies come from k_turb_tendencies (fused turbulence-coupled step: by the
+// time this kernel runs, PHI already belongs to the new state).
+template <bool TURB, bool EULER, bool FROM_WINDS = false, bool TURB_PRE = false>
 __global__ __launch_bounds__(TI *TJ) void k_moist(Geo g, Ptrs p, const double *qv_old, const double *qc_old,
                                                   double *qv_out, double *qc_out, double dt, int lin)
 {
@@ -597,6 +599,7 @@ __global__ __launch_bounds__(TI *TJ) void k_moist(Geo g, Ptrs p, const double *q
                 d = d + tb;
                 if (s == 0 && !EULER) p.dQVdt_TURB[q] = tb;
             }
+            if (TURB_PRE) d = d + (s == 0 ? p.TURB_QV[q] : p.TURB_QC[q]);
             if (dif > 0.0)
                 d = d + dif * (c_im1 * x_im1 + c_ip1 * x_ip1 + c_jm1 * x_jm1 + c_jp1 * x_jp1 - 4.0 * colp * x);
             tq[s] = d;

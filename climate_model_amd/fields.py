@@ -56,6 +56,12 @@ FIELD_TABLE = OrderedDict([
     ('UWIND_EST',     (1, 0, 'nz')),
     ('VWIND_EST',     (0, 1, 'nz')),
     ('POTT_EST',      (0, 0, 'nz')),
+    # raw turbulent tendencies of the fused turbulence-coupled step (library scratch; device only with i_turb)
+    ('TURB_U',        (1, 0, 'nz')),
+    ('TURB_V',        (0, 1, 'nz')),
+    ('TURB_T',        (0, 0, 'nz')),
+    ('TURB_QV',       (0, 0, 'nz')),
+    ('TURB_QC',       (0, 0, 'nz')),
     # column pressure at the u- / v-points (2-D factors of UFLX, VFLX; library scratch)
     ('UCOL',          (1, 0, 1)),
     ('VCOL',          (0, 1, 1)),

@@ -420,3 +420,50 @@ def test_abi_error_reporting():
         HipDycore(2, 2, 2)
     with pytest.raises(DycoreError, match='outside the global grid'):
         HipDycore(36, 10, 4, ny_global=18, j_offset=12)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('i_moist', [0, 1])
+def test_fused_turbulent_step_equals_stage_kernels(monkeypatch, i_moist):
+    """A turbulence-coupled handle (i_turb) steps on the fused kernels too: k_turb_tendencies supplies the
+    turbulent terms (same expressions as k_prepare / k_*_tendency<true>).  Against the stage kernels
+    (DYCORE_FUSED_TURB=0) on random K fields and surface fluxes, halos included: 1e-11, and against the
+    oracle 1e-9."""
+    from climate_model_amd import Namelist, Grid, ModelFields, HipDycore
+    from climate_model_amd.synthetic import initialize_fields, initialize_moisture
+    from oracle_binding import Oracle
+    GR = Grid(Namelist(nz=8, dlat_deg=4, dlon_deg=4, i_UVFLX_vert_turb=1, i_POTT_vert_turb=1, i_moist_main_switch=i_moist))
+    F0 = ModelFields(GR)
+    initialize_fields(GR, F0)
+    if i_moist:
+        initialize_moisture(GR, F0)
+    rng = np.random.default_rng(9)
+    for n, lo_, hi_ in [('KMOM', 0.5, 20.), ('KHEAT', 0.5, 20.), ('SSHFLX', -50., 150.), ('SLHFLX', -20., 200.),
+                        ('SMOMXFLX', -0.2, 0.2), ('SMOMYFLX', -0.2, 0.2)]:
+        F0.host[n][...] = rng.uniform(lo_, hi_, F0.host[n].shape)
+    F0.host['dPOTTdt_RAD'][...] = 0.
+    names = ['HSURF', 'COLP', 'UWIND', 'VWIND', 'POTT', 'WWIND', 'POTTVB', 'KMOM', 'KHEAT', 'SSHFLX', 'SLHFLX',
+             'SMOMXFLX', 'SMOMYFLX', 'dPOTTdt_RAD'] + (['QV', 'QC'] if i_moist else [])
+    state = {n: F0.host[n].copy() for n in names}
+    check = ['UWIND', 'VWIND', 'POTT', 'COLP', 'PHI', 'PHIVB', 'PVTF', 'POTTVB'] + (['QV', 'QC'] if i_moist else [])
+    out = {}
+    for fused in ('1', '0'):
+        monkeypatch.setenv('DYCORE_FUSED_TURB', fused)
+        core = HipDycore(GR.nx, GR.ny, GR.nz, i_turb=1, i_moist=i_moist)
+        core.set_grid(GR.GRF['HIP'])
+        for n, a in state.items():
+            core.upload(n, a)
+        core.primary_diag()
+        assert core.flux_from_winds == (fused == '1') and not core.overlap_parts
+        core.step_matsuno(GR.dt, 3)
+        out[fused] = {n: core.download(n) for n in check}
+        core.close()
+    for n in check:
+        err, ncmp, bad = rel_max_err(out['1'][n], out['0'][n], n, GR.nx, GR.ny)
+        assert bad == 0 and ncmp > 0 and err <= (1e-8 if n == 'QC' else 1e-11), '%s: %.3e' % (n, err)
+    o = Oracle(GR.nx, GR.ny, GR.nz, GR.GRF['CPU'], state, pair_top=GR.nl.pair_top, i_turb=1, i_moist=i_moist)
+    o.primary_diag()
+    o.step_matsuno(GR.dt, 3, with_rho=True)
+    for n in ('UWIND', 'VWIND', 'POTT', 'COLP') + (('QV',) if i_moist else ()):
+        err, ncmp, bad = rel_max_err(out['1'][n], o.F[n], n, GR.nx, GR.ny)
+        assert bad == 0 and ncmp > 0 and err <= 1e-9, '%s vs oracle: %.3e' % (n, err)

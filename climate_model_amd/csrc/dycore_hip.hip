@@ -536,12 +536,7 @@ int do_turb_tendencies(dycore *h, const Ptrs &p)
 {
     int rc;
     const int nz = h->g.nz;
-    // dyn_org_discretizations.py:195-196, 212-216: lateral BC of the K field and the surface momentum fluxes
-    // (whole-field exchange as in the staged step: these inputs are never exchanged between bands, so the
-    // periodic columns of a band's halo rows are refreshed here too)
-    if ((rc = do_exchange(h, p.KMOM, 0, 0, nz + 1))) return rc;
-    if ((rc = do_exchange(h, p.SMOMXFLX, 0, 0, 1))) return rc;
-    if ((rc = do_exchange(h, p.SMOMYFLX, 0, 0, 1))) return rc;
+    (void)rc; (void)nz;
     Scope s(h, K_TURB_TEND);
     hipLaunchKernelGGL(k_turb_tendencies, grid_cells(h), dim3(TI, TJ), 0, h->stream, h->g, p, h->g.pole_s ? 2 : 1, cells_linear(h));
     return launch_check("k_turb_tendencies");
@@ -632,7 +627,18 @@ int step_begin(dycore *h, int with_rho)
     int rc;
     Ptrs &p = h->p;
     if (with_rho && ((rc = join_side(h)) || (rc = do_rho(h, p)))) return rc;
-    if (fused_path(h)) return do_copy(h, p.COLP_OLD, p.COLP, (size_t)h->g.plane);
+    if (fused_path(h)) {
+        if (h->g.i_turb) {
+            // dyn_org_discretizations.py:195-196, 212-216: lateral BC of the K field and the surface momentum
+            // fluxes, once per step (they do not change within one).  Whole-field exchange as in the staged
+            // step: these inputs never travel between bands, so the periodic columns of a band's halo rows
+            // are refreshed here too.
+            if ((rc = do_exchange(h, p.KMOM, 0, 0, h->g.nz + 1))) return rc;
+            if ((rc = do_exchange(h, p.SMOMXFLX, 0, 0, 1))) return rc;
+            if ((rc = do_exchange(h, p.SMOMYFLX, 0, 0, 1))) return rc;
+        }
+        return do_copy(h, p.COLP_OLD, p.COLP, (size_t)h->g.plane);
+    }
     std::swap(p.UWIND, p.UWIND_OLD);
     std::swap(p.VWIND, p.VWIND_OLD);
     std::swap(p.POTT, p.POTT_OLD);

@@ -67,9 +67,10 @@ def step_matsuno(GR, F):
     GR.ts += 1
 
 
-def step_matsuno_fused(GR, F, nsteps=1):
-    """The whole hot loop body inside the library: dycore_step_matsuno."""
+def step_matsuno_fused(GR, F, nsteps=1, with_rho=None):
+    """The whole hot loop body inside the library: dycore_step_matsuno.  with_rho=False: RHO / RHOVB are
+    current (the caller has just run secondary_diag, as solver.py:99-101 does before every step)."""
     GR.timer.start('step')
-    F.core.step_matsuno(GR.dt, nsteps)
+    F.core.step_matsuno(GR.dt, nsteps, with_rho)
     GR.timer.stop('step')
     GR.ts += nsteps

@@ -122,7 +122,7 @@ def run(GR, F, nts, nth_ts_print_diag=50, fused=True, fused_steps=1, out=print,
                 GR.ts = step - 1
 
         if fused:
-            step_matsuno_fused(GR, F, n)
+            step_matsuno_fused(GR, F, n, with_rho=False if n == 1 else None)     # secondary_diag above left RHO, RHOVB current
         else:
             step_matsuno(GR, F)
 

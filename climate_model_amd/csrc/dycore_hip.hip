@@ -223,15 +223,16 @@ int check_ready(dycore *h)
 }
 
 int join_side(dycore *h);
-int refresh_lazy(dycore *h);
+enum { LAZY_FLX = 1, LAZY_FLXDIV = 2, LAZY_PHIVB = 4, LAZY_ALL = 7 };
+int refresh_lazy(dycore *h, int need = LAZY_ALL);
 // stage entry points read what the side stream may still be writing and what the fused step
-// left to be derived
-int ready_join(dycore *h)
+// left to be derived (`need`: which of the derived fields the stage reads)
+int ready_join(dycore *h, int need = LAZY_ALL)
 {
     int rc = check_ready(h);
     if (rc) return rc;
     if ((rc = join_side(h))) return rc;
-    return refresh_lazy(h);
+    return refresh_lazy(h, need);
 }
 
 int launch_check(const char *what)
@@ -416,24 +417,27 @@ int do_continuity_fused(dycore *h, const Ptrs &p, double dt)
     return do_halo(h, {{p.UFLX, 1, 0, nz}, {p.VFLX, 0, 1, nz}, {p.WWIND, 0, 0, nz + 1}, {p.COLP_NEW, 0, 0, 1}});
 }
 // bring the on-demand fields up to date (called wherever they can be observed)
-int refresh_lazy(dycore *h)
+int refresh_lazy(dycore *h, int need)
 {
-    if (!h->stale_flxdiv && !h->stale_phivb && !h->stale_uvflx) return 0;
+    if (need & LAZY_FLXDIV) need |= LAZY_FLX;          // FLXDIV is derived from UFLX, VFLX
+    const bool d_flx = h->stale_uvflx && (need & LAZY_FLX), d_div = h->stale_flxdiv && (need & LAZY_FLXDIV),
+               d_phivb = h->stale_phivb && (need & LAZY_PHIVB);
+    if (!d_flx && !d_div && !d_phivb) return 0;
     int rc = join_side(h);
     if (rc) return rc;
     Scope s(h, K_DERIVE);
-    if (h->stale_uvflx) {
+    if (d_flx) {
         hipLaunchKernelGGL(k_derive_uvflx, grid_for(h->g, h->g.nx, h->g.ny), dim3(TI, TJ), 0, h->stream, h->g, h->p, h->flx_u, h->flx_v);
         if ((rc = launch_check("k_derive_uvflx"))) return rc;
         h->stale_uvflx = false;
         if ((rc = do_halo_noscope(h, {{h->p.UFLX, 1, 0, h->g.nz}, {h->p.VFLX, 0, 1, h->g.nz}}))) return rc;
     }
-    if (h->stale_flxdiv) {
+    if (d_div) {
         hipLaunchKernelGGL(k_derive_flxdiv, grid_for(h->g, h->g.nx, h->g.ny), dim3(TI, TJ), 0, h->stream, h->g, h->p);
         if ((rc = launch_check("k_derive_flxdiv"))) return rc;
         h->stale_flxdiv = false;
     }
-    if (h->stale_phivb) {
+    if (d_phivb) {
         hipLaunchKernelGGL(k_derive_phivb, grid_for(h->g, h->g.nx + 2, h->g.ny + 2), dim3(TI, TJ), 0, h->stream, h->g, h->p);
         if ((rc = launch_check("k_derive_phivb"))) return rc;
         h->stale_phivb = false;
@@ -978,6 +982,15 @@ int dycore_upload(dycore_t *h, const char *name, const double *host)
     return 0;
 }
 
+// which derivation a read of this field needs (0: the field is always current)
+static int lazy_need(const FieldDesc *d)
+{
+    if (d->member == &Ptrs::UFLX || d->member == &Ptrs::VFLX) return LAZY_FLX;
+    if (d->member == &Ptrs::FLXDIV) return LAZY_FLXDIV;
+    if (d->member == &Ptrs::PHIVB) return LAZY_PHIVB;
+    return 0;
+}
+
 int dycore_download(dycore_t *h, const char *name, double *host)
 {
     const FieldDesc *d;
@@ -985,7 +998,7 @@ int dycore_download(dycore_t *h, const char *name, double *host)
     if (rc) return rc;
     if (!host) return fail(DYCORE_EINVAL, "null host pointer");
     if ((rc = join_side(h))) return rc;
-    if ((rc = refresh_lazy(h))) return rc;
+    if ((rc = refresh_lazy(h, lazy_need(d)))) return rc;
     const Geo &g = h->g;
     const int n0 = g.nx + 2 + d->stgx, n1 = g.ny + 2 + d->stgy, n2 = h->nk_of(d->nk);
     const size_t n = (size_t)n0 * n1 * n2;
@@ -1002,7 +1015,7 @@ int dycore_field_ptr(dycore_t *h, const char *name, void **dev, int64_t *pitch, 
     const FieldDesc *d;
     int rc = find_field(h, name, &d);
     if (rc) return rc;
-    if ((rc = refresh_lazy(h))) return rc;
+    if ((rc = refresh_lazy(h, lazy_need(d)))) return rc;
     if (dev) *dev = h->p.*(d->member);
     if (pitch) *pitch = h->g.P;
     if (rows) *rows = h->g.NJ;
@@ -1018,7 +1031,7 @@ int dycore_copy_field(dycore_t *h, const char *dst, const char *src)
     if (a->stgx != b->stgx || a->stgy != b->stgy || a->nk != b->nk)
         return fail(DYCORE_EINVAL, "copy_field: '%s' and '%s' differ in shape", dst, src);
     if ((rc = join_side(h))) return rc;
-    if ((rc = refresh_lazy(h))) return rc;
+    if ((rc = refresh_lazy(h, lazy_need(a) | lazy_need(b)))) return rc;
     return do_copy(h, h->p.*(a->member), h->p.*(b->member), h->field_elems(a->nk));
 }
 
@@ -1045,15 +1058,15 @@ int dycore_moist_tendency(dycore_t *h)
 }
 int dycore_euler_forward(dycore_t *h, double dt) { int rc = ready_join(h); return rc ? rc : do_euler(h, h->p, dt); }
 int dycore_primary_diag(dycore_t *h) { int rc = ready_join(h); return rc ? rc : do_diag(h, h->p); }
-int dycore_secondary_diag_rho(dycore_t *h) { int rc = ready_join(h); return rc ? rc : do_rho(h, h->p); }
-int dycore_secondary_diag(dycore_t *h) { int rc = ready_join(h); return rc ? rc : do_secondary(h, h->p); }
-int dycore_compute_turbulence(dycore_t *h) { int rc = ready_join(h); return rc ? rc : do_turbulence(h, h->p); }
+int dycore_secondary_diag_rho(dycore_t *h) { int rc = ready_join(h, 0); return rc ? rc : do_rho(h, h->p); }
+int dycore_secondary_diag(dycore_t *h) { int rc = ready_join(h, 0); return rc ? rc : do_secondary(h, h->p); }
+int dycore_compute_turbulence(dycore_t *h) { int rc = ready_join(h, LAZY_PHIVB); return rc ? rc : do_turbulence(h, h->p); }
 
 int dycore_radiation(dycore_t *h, double solar_constant, int32_t nbins, const double *lambdas_center, const double *dlambdas)
 {
     if (!h) return fail(DYCORE_EINVAL, "null handle");
     if (!h->g.i_rad) return fail(DYCORE_ESTATE, "handle created without i_radiation");
-    int rc = ready_join(h);
+    int rc = ready_join(h, LAZY_PHIVB);
     if (rc) return rc;
     if (!lambdas_center || !dlambdas || nbins < 1 || nbins > RAD_MAX_BINS)
         return fail(DYCORE_EINVAL, "need 1..%d spectral bins", RAD_MAX_BINS);

@@ -283,7 +283,10 @@ class DistributedBands:
         self.staged = dist.get_backend(group) != 'nccl' and on_gpu
         # the split parts exist for the fused (dry / moist) step; the turbulence-coupled staged step
         # keeps the plain sequence
-        self.overlap = (on_gpu if overlap is None else bool(overlap)) and getattr(core, 'overlap_parts', False)
+        if overlap is None:
+            import os
+            overlap = on_gpu and os.environ.get('DYCORE_BANDS_OVERLAP', '1') != '0'
+        self.overlap = bool(overlap) and getattr(core, 'overlap_parts', False)
         if self.overlap:
             core._band_halo, core._band_bufs = self.halo, self.bufs
             self.streams = _Streams([core], device)

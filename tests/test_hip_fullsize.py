@@ -175,3 +175,21 @@ def test_long_run_tracks_oracle():
     m0, m1 = np.sum(state['COLP'][1:-1, 1:-1, 0] * A), np.sum(got['COLP'][1:-1, 1:-1, 0] * A)
     assert abs(m1 - m0) / m0 < 1e-12
     assert np.max(np.abs(got['UWIND'][1:GR.nx + 1, 1:-1])) < 200.
+
+
+@pytest.mark.parametrize('lat0,lat1,d,nz', [(-80, 80, 5, 8), (-84, 84, 1.0, 32)])
+def test_reference_preset_domains_vs_oracle(lat0, lat1, d, nz):
+    """The two preset grids of the reference's namelist.py:243-278 stop short of the poles (walls at 80 / 84
+    degrees): 5 steps against the oracle."""
+    GR = Grid(Namelist(nz=nz, dlat_deg=d, dlon_deg=d, lat0_deg=lat0, lat1_deg=lat1))
+    assert GR.ny == int((lat1 - lat0) / d)
+    F = ModelFields(GR)
+    initialize_fields(GR, F)
+    state = {n: F.host[n] for n in STATE}
+    got = _run_hip(GR, state, 5, PROGNOSTIC + ['PHI'])
+    o = Oracle(GR.nx, GR.ny, GR.nz, GR.GRF['CPU'], state, pair_top=GR.nl.pair_top, i_turb=0, fill_nan=False)
+    o.primary_diag()
+    o.step_matsuno(GR.dt, 5, with_rho=False)
+    for n in got:
+        err, ncmp, bad = rel_max_err(got[n], o.F[n], n, GR.nx, GR.ny)
+        assert bad == 0 and ncmp > 0 and err <= 1e-9, '%s: rel err %.3e (%d bad)' % (n, err, bad)

@@ -579,15 +579,16 @@ int do_diag_band_halo(dycore *h, const Ptrs &p)
 {
     if (h->g.pole_s && h->g.pole_n) return 0;
     const int row_a = h->g.pole_s ? -1 : 0, row_b = h->g.pole_n ? -1 : h->g.ny + 1;
-    const dim3 gr((h->g.nx + 2 + TI - 1) / TI, 2);
+    const dim3 gr((h->g.nx + 2 + 63) / 64, 2);
+    const size_t lds = (size_t)(h->g.nz + 1) * 64 * sizeof(double);
     if (h->prof == 1 || !h->side) { // full profiling brackets every launch on the main stream
         Scope s(h, K_DIAG_ROWS);
-        hipLaunchKernelGGL(k_primary_diag_rows, gr, dim3(TI), 0, h->stream, h->g, p, row_a, row_b);
+        hipLaunchKernelGGL(k_primary_diag_rows, gr, dim3(256), lds, h->stream, h->g, p, row_a, row_b);
         return launch_check("k_primary_diag_rows");
     }
     HIP_TRY(hipEventRecord(h->ev_main, h->stream));
     HIP_TRY(hipStreamWaitEvent(h->side, h->ev_main, 0));
-    hipLaunchKernelGGL(k_primary_diag_rows, gr, dim3(TI), 0, h->side, h->g, p, row_a, row_b);
+    hipLaunchKernelGGL(k_primary_diag_rows, gr, dim3(256), lds, h->side, h->g, p, row_a, row_b);
     int rc = launch_check("k_primary_diag_rows");
     if (rc) return rc;
     HIP_TRY(hipEventRecord(h->ev_side, h->side));
@@ -808,6 +809,12 @@ int dycore_create(const DycoreConfig *cfg, dycore_t **out)
     }
     h->home = h->stream;
     if (!(g.pole_s && g.pole_n)) {      // a band of a decomposed grid
+        if ((size_t)(g.nz + 1) * 64 * sizeof(double) > 65536 &&
+            hipFuncSetAttribute((const void *)k_primary_diag_rows, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((g.nz + 1) * 64 * sizeof(double))) != hipSuccess) {
+            (void)hipGetLastError();
+            delete h;
+            return fail(DYCORE_EINVAL, "too many levels (%d) for the halo-row diagnostics of a latitude band", g.nz);
+        }
         if (hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking) != hipSuccess ||
             hipEventCreateWithFlags(&h->ev_main, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&h->ev_side, hipEventDisableTiming) != hipSuccess) {

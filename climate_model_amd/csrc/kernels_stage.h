@@ -706,17 +706,24 @@ __device__ __forceinline__ double interface_pressure(double pair_top, double svb
     return pair_top + svb * colp;
 }
 struct DiagLevel { double p_km12, pvb_k, pvtf, phi, phivb; };
-__device__ __forceinline__ DiagLevel diag_level(double pair_top, double svb_k, double colp, double pott,
-                                                double p_kp12, double pvb_kp1, double phivb_kp1)
+// ... with the interface pressure and its Exner value already at hand
+__device__ __forceinline__ DiagLevel diag_level_pre(double p_km12, double pvb_k, double pott,
+                                                    double p_kp12, double pvb_kp1, double phivb_kp1)
 {
 #pragma clang fp contract(off)
     DiagLevel d;
-    d.p_km12 = pair_top + svb_k * colp;
-    d.pvb_k = exner_vb(d.p_km12);
+    d.p_km12 = p_km12;
+    d.pvb_k = pvb_k;
     d.pvtf = 1.0 / (1.0 + CON_KAPPA) * (pvb_kp1 * p_kp12 - d.pvb_k * d.p_km12) / (p_kp12 - d.p_km12);
     d.phi = phivb_kp1 - CON_CP * (pott * (d.pvtf - pvb_kp1));
     d.phivb = d.phi - CON_CP * (pott * (d.pvb_k - d.pvtf));
     return d;
+}
+__device__ __forceinline__ DiagLevel diag_level(double pair_top, double svb_k, double colp, double pott,
+                                                double p_kp12, double pvb_kp1, double phivb_kp1)
+{
+    const double p_km12 = interface_pressure(pair_top, svb_k, colp);
+    return diag_level_pre(p_km12, exner_vb(p_km12), pott, p_kp12, pvb_kp1, phivb_kp1);
 }
 // interface value between levels k and k+1, dyn_diagnostics.py:183-186
 __device__ __forceinline__ double pottvb_between(double pvb_kp1, double pvtf, double pott, double pvtf_kp1, double pott_kp1)
@@ -728,13 +735,14 @@ __device__ __forceinline__ double pottvb_between(double pvb_kp1, double pvtf, do
 // primary diagnostics: dyn_diagnostics.py:139-195 (diag_PVTF, diag_PHI, diag_POTTVB) in one
 // bottom-up sweep over the whole array incl. halos (i in [0,nx+1], j in [0,ny+1]).
 // One pow() per interface instead of the reference's two per cell: PVTFVB[k+1] is carried.
-__device__ __forceinline__ void diag_column(const Geo &g, const Ptrs &p, int i, int j)
+// `pvb` (optional): the Exner values of the column's interfaces, pvb[k * stride], computed beforehand.
+__device__ __forceinline__ void diag_column(const Geo &g, const Ptrs &p, int i, int j, const double *pvb = nullptr, int stride = 0)
 {
     const size_t c = at2(g, i, j);
     const int nz = g.nz;
     const double colp = p.COLP[c];
     double p_kp12 = interface_pressure(g.pair_top, p.sigma_vb[nz], colp);
-    double pvb_kp1 = exner_vb(p_kp12);
+    double pvb_kp1 = pvb ? pvb[nz * stride] : exner_vb(p_kp12);
     double phivb_kp1 = p.HSURF[c] * CON_G;
     p.PVTFVB[c + (size_t)nz * g.plane] = pvb_kp1;
     p.PHIVB[c + (size_t)nz * g.plane] = phivb_kp1;
@@ -742,7 +750,8 @@ __device__ __forceinline__ void diag_column(const Geo &g, const Ptrs &p, int i, 
     for (int k = nz - 1; k >= 0; k--) {
         const size_t q = c + (size_t)k * g.plane;
         const double pott = p.POTT[q];
-        const DiagLevel dl = diag_level(g.pair_top, p.sigma_vb[k], colp, pott, p_kp12, pvb_kp1, phivb_kp1);
+        const DiagLevel dl = pvb ? diag_level_pre(interface_pressure(g.pair_top, p.sigma_vb[k], colp), pvb[k * stride], pott, p_kp12, pvb_kp1, phivb_kp1)
+                                 : diag_level(g.pair_top, p.sigma_vb[k], colp, pott, p_kp12, pvb_kp1, phivb_kp1);
         const double p_km12 = dl.p_km12, pvb_k = dl.pvb_k, pvtf = dl.pvtf, phi = dl.phi, phivb = dl.phivb;
         p.PVTF[q] = pvtf;
         p.PVTFVB[q] = pvb_k;
@@ -771,13 +780,27 @@ __global__ __launch_bounds__(TI *TJ) void k_primary_diag(Geo g, Ptrs p)
     diag_column(g, p, i, j);
 }
 
-// the same on two rows only: the halo rows a latitude band receives from its neighbours
-__global__ __launch_bounds__(TI) void k_primary_diag_rows(Geo g, Ptrs p, int row_a, int row_b)
+// the same on two rows only: the halo rows a latitude band receives from its neighbours.  The two rows
+// are ~3000 columns, each a serial bottom-up recurrence: to keep the launch short (it sits between the
+// arrival of the rows and the momentum tiles that need them), a workgroup of 64 columns first evaluates
+// the Exner function of all its (column, interface) pairs in parallel (4 waves) and only then walks up
+// the columns with those values taken from LDS.  Same helper functions, same bits as diag_column.
+__global__ __launch_bounds__(256) void k_primary_diag_rows(Geo g, Ptrs p, int row_a, int row_b)
 {
-    const int i = blockIdx.x * TI + threadIdx.x;
+    extern __shared__ double s_pvb[];                   // [nz + 1][64]
+    const int i0 = blockIdx.x * 64;
     const int j = blockIdx.y == 0 ? row_a : row_b;
-    if (i > g.nx + 1 || j < 0) return;
-    diag_column(g, p, i, j);
+    if (j < 0) return;
+    const int nz = g.nz;
+    for (int t = threadIdx.x; t < 64 * (nz + 1); t += 256) {
+        const int k = t / 64, li = t - k * 64, i = i0 + li;
+        if (i <= g.nx + 1)
+            s_pvb[t] = exner_vb(interface_pressure(g.pair_top, p.sigma_vb[k], p.COLP[at2(g, i, j)]));
+    }
+    __syncthreads();
+    const int i = i0 + threadIdx.x;
+    if (threadIdx.x >= 64 || i > g.nx + 1) return;
+    diag_column(g, p, i, j, s_pvb + threadIdx.x, 64);
 }
 
 // secondary diagnostics, RHO / RHOVB only: dyn_diagnostics.py:199-222

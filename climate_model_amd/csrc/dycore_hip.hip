@@ -146,6 +146,8 @@ struct dycore {
     int n_cu = 256;                 // compute units of the device
     int cell_lin = -1;              // DYCORE_CELL_LINEAR: column-kernel launch, bit 0 = cell runs, bit 1 = XCD-aware order (default 3 or 2)
     int mom_ks = 0;                 // DYCORE_MOM_KS: force the level chunks per momentum tile (1, 2, 4)
+    int mom_split = 1;              // DYCORE_MOM_SPLIT=0: no second segment (short chunks for the tiles beyond the last full round)
+    double mom_pro = 2.0;           // DYCORE_MOM_PRO: prologue of a level chunk in units of one level (plan cost model)
     int mom_dma = 1;                // momentum kernel: 1 = LDS-DMA (default); 0 = register-staged tiles (DYCORE_MOM_DMA)
     // profiler
     int prof = 0;                   // 0 off, 1 every launch, 2 dominant kernel only
@@ -493,21 +495,46 @@ int do_momentum_fused(dycore *h, const Ptrs &p, const double *u_old, const doubl
             for (int by = gby2 - 1; by >= 0 && by * tj + 1 + tj + 1 > h->g.ny; by--) dep_n++;
         RowSet trows;
         if (!row_subset(gby2, h->g.pole_s ? 0 : 1, dep_n, mode, trows)) return 0;
-        int ks = 1;
+        // Work list (MomPlan).  One workgroup per CU: T tiles of nz levels take ceil(T / CUs) rounds;
+        // ks level chunks per tile take ceil(T * ks / CUs) rounds of nz / ks levels + the chunk's
+        // prologue (2-D loads, factor tiles, first DMA: ~mom_pro levels).  Candidates: the whole row set
+        // in 1, 2 or 4 chunks per tile, or -- for a contiguous row set of more than one round -- the
+        // tile rows that fill whole rounds as full tiles (segment a) and the remaining rows cut into
+        // up to 8 chunks (segment b), so that the last round costs a fraction of a tile.
+        MomPlan plan = {trows, 1, 0, {0, 0, 0, 0}, 1};
         {
             const long tiles = (long)gbx * trows.n;
+            const double pro = h->mom_pro;
+            auto rounds = [&](long wg) { return (double)((wg + h->n_cu - 1) / h->n_cu); };
             double best = -1.0;
             for (int cand : {1, 2, 4}) {
                 if (h->g.nz / cand < 4) break;
-                const double cost = (double)((tiles * cand + h->n_cu - 1) / h->n_cu) * ((double)h->g.nz / cand + (cand > 1 ? 1.0 : 0.0));
-                if (best < 0 || cost < best - 1e-9) { best = cost; ks = cand; }
+                const double cost = rounds(tiles * cand) * ((double)h->g.nz / cand + (cand > 1 ? pro : 0.0));
+                if (best < 0 || cost < best - 1e-9) { best = cost; plan.ks_a = cand; }
             }
-            if (h->mom_ks) ks = h->mom_ks;
+            if (h->mom_ks) plan.ks_a = h->mom_ks;
+            const long full = tiles / h->n_cu;            // whole rounds of full tiles
+            if (h->mom_split && !h->mom_ks && trows.gap == 0 && full >= 1 && tiles % h->n_cu) {
+                const int r1 = (int)(full * h->n_cu / gbx);       // tile rows inside those rounds
+                const int r2 = trows.n - r1;
+                if (r1 >= 1 && r2 >= 1) {
+                    for (int cand : {1, 2, 4, 8}) {
+                        if (h->g.nz / cand < 4) break;
+                        const double cost = rounds((long)gbx * r1) * h->g.nz + rounds((long)gbx * r2 * cand) * ((double)h->g.nz / cand + (cand > 1 ? pro : 0.0));
+                        if (cost < best - 1e-9) {
+                            best = cost;
+                            plan.a = {trows.first, r1, r1, 0}; plan.ks_a = 1;
+                            plan.b = {trows.first + r1, r2, r2, 0}; plan.ks_b = cand;
+                        }
+                    }
+                }
+            }
         }
-        const dim3 gr2(8 * ((gbx * trows.n * ks + 7) / 8)), blk(FTI, tj);
+        plan.nblk_a = 8 * ((gbx * plan.a.n * plan.ks_a + 7) / 8);
+        const dim3 gr2(plan.nblk_a + 8 * ((gbx * plan.b.n * plan.ks_b + 7) / 8)), blk(FTI, tj);
         const bool cur = (u_old == p.UWIND);
         const bool fw = flux_from_winds(h) && (h->fw_mask & 2);
-#define MOM_LAUNCH(CUR_, FW_, TB_) hipLaunchKernelGGL((k_momentum_dma<CUR_, tj, FW_, TB_>), gr2, blk, dma_lds_bytes(tj, FW_), h->stream, h->g, p, gbx, trows, ks, jv_lo, u_old, v_old, u_out, v_out, dt)
+#define MOM_LAUNCH(CUR_, FW_, TB_) hipLaunchKernelGGL((k_momentum_dma<CUR_, tj, FW_, TB_>), gr2, blk, dma_lds_bytes(tj, FW_), h->stream, h->g, p, gbx, plan, jv_lo, u_old, v_old, u_out, v_out, dt)
         if (h->g.i_turb) { if (cur) MOM_LAUNCH(true, true, true); else MOM_LAUNCH(false, true, true); }
         else if (cur) { if (fw) MOM_LAUNCH(true, true, false); else MOM_LAUNCH(true, false, false); }
         else { if (fw) MOM_LAUNCH(false, true, false); else MOM_LAUNCH(false, false, false); }
@@ -786,6 +813,8 @@ int dycore_create(const DycoreConfig *cfg, dycore_t **out)
     if (const char *e = getenv("DYCORE_FUSED_TURB")) h->fused_turb = atoi(e) != 0;
     if (const char *e = getenv("DYCORE_FW_MASK")) h->fw_mask = atoi(e);
     if (const char *e = getenv("DYCORE_MOM_KS")) h->mom_ks = atoi(e);
+    if (const char *e = getenv("DYCORE_MOM_SPLIT")) h->mom_split = atoi(e);
+    if (const char *e = getenv("DYCORE_MOM_PRO")) h->mom_pro = atof(e);
     if (const char *e = getenv("DYCORE_CELL_LINEAR")) h->cell_lin = atoi(e);
     {
         hipDeviceProp_t prop;

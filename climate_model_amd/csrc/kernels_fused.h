@@ -52,6 +52,23 @@ __device__ __forceinline__ bool xcd_tile(int gbx, int gby, int &bx, int &by)
 struct RowSet { int first, n, split, gap; };
 __device__ __forceinline__ int rowset_row(const RowSet &rs, int r) { return rs.first + r + (r >= rs.split ? rs.gap : 0); }
 
+// Work list of one k_momentum_dma launch: up to two segments of (tile rows, level chunks per tile).
+// With one workgroup per CU, T equal tiles take ceil(T / CUs) rounds; the tiles beyond the last full
+// round form the second segment and are cut into short level chunks, so that the last round is a
+// fraction of a tile's time (do_momentum_fused picks the plan).  Workgroups [0, nblk_a) belong to
+// segment a (nblk_a a multiple of 8, so both segments keep the XCD-aware order), the rest to b.
+struct MomPlan { RowSet a; int ks_a, nblk_a; RowSet b; int ks_b; };
+__device__ __forceinline__ bool xcd_tile_at(int b, int gbx, int gby, int &bx, int &by)
+{
+    const int nblk = gbx * gby;
+    const int chunk = (nblk + 7) / 8;
+    const int lin = (b % 8) * chunk + b / 8;
+    if (lin >= nblk) return false;
+    bx = lin % gbx;
+    by = lin / gbx;
+    return true;
+}
+
 // EULER: the pressure-weighted Euler step (dyn_timestep.py:212-297, UWIND/VWIND part) is
 // applied in the same thread -- dUFLXdt/dVFLXdt never reach HBM; u_old/v_old hold the state at
 // step start (read at the own cell only), u_out/v_out receive the new winds (interior cells;
@@ -319,11 +336,15 @@ typedef const __attribute__((address_space(1))) void gbl_void_t;
 // TURB: the turbulent tendencies of k_turb_tendencies (own cell, fetched one level ahead into
 // registers) join the sums.
 template <bool OLD_IS_CUR, int TJ, bool FROM_WINDS, bool TURB = false>
-__global__ __launch_bounds__(FTI *TJ) void k_momentum_dma(Geo g, Ptrs p, int gbx, RowSet trows, int ksplit, int jv_lo,
+__global__ __launch_bounds__(FTI *TJ) void k_momentum_dma(Geo g, Ptrs p, int gbx, MomPlan plan, int jv_lo,
                                                       const double *u_old, const double *v_old,
                                                       double *u_out, double *v_out, double dt)
 {
-    const int gby = trows.n;            // tile rows of this launch (a subset of the band's, see RowSet)
+    // segment of the work list this workgroup belongs to (MomPlan)
+    const bool seg_b = (int)blockIdx.x >= plan.nblk_a;
+    const RowSet trows = seg_b ? plan.b : plan.a;
+    const int ksplit = seg_b ? plan.ks_b : plan.ks_a;
+    const int gby = trows.n;            // tile rows of this segment (a subset of the band's, see RowSet)
     // tile geometry for TJ rows per workgroup (TJ is chosen per launch so that the number of
     // workgroups fits the 256 CUs with the least idle tail: dma_pick_tj on the host)
     constexpr int TH = TJ + 3, TN = FTW * TH, NT = FTI * TJ;          // tile rows, doubles, threads
@@ -335,7 +356,7 @@ __global__ __launch_bounds__(FTI *TJ) void k_momentum_dma(Geo g, Ptrs p, int gbx
     // workgroup -> (tile, level chunk): `ksplit` chunks of the k range per tile give a small
     // latitude band enough workgroups to balance over the CUs (one tile per CU otherwise)
     int bx, by;
-    if (!xcd_tile(gbx, gby * ksplit, bx, by)) return;
+    if (!xcd_tile_at((int)blockIdx.x - (seg_b ? plan.nblk_a : 0), gbx, gby * ksplit, bx, by)) return;
     const int kc = by / gby;
     by = rowset_row(trows, by - kc * gby);
     const int k0 = (int)((long long)kc * g.nz / ksplit), k1 = (int)((long long)(kc + 1) * g.nz / ksplit);

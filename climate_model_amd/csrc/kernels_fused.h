@@ -443,8 +443,18 @@ __global__ __launch_bounds__(FTI *TJ) void k_momentum_dma(Geo g, Ptrs p, int gbx
     const double lat = p.lat_rad[c], lat_jm1 = p.lat_rad[c - P];
     const double kc_c = p.corf[c] * CON_RE * cos(lat), sin_c = sin(lat);
     const double kc_jm1 = p.corf[c - P] * CON_RE * cos(lat_jm1), sin_jm1 = sin(lat_jm1);
-    const double metric = CON_RE * p.dlon_rad[c] * p.dlat_rad[c] / 2.0;
-    const double dyis = p.dyis[c], dxjs = p.dxjs[c];
+    // per-column factors of the Coriolis / metric and pressure-gradient terms (formed once; the "/ 2" of the
+    // reference's means are folded in exactly, the products are associated differently: <= 1 ulp each)
+    const double hsin_is = 0.5 * sin_is, hsin_c = 0.5 * sin_c, hsin_jm1 = 0.5 * sin_jm1;
+    double cor_im1, cor_c, cov_jm1, cov_c, pgu_a, pgu_b, pgv_a, pgv_b;
+    {
+        const double metric = CON_RE * p.dlon_rad[c] * p.dlat_rad[c] / 2.0;
+        const double dyis = p.dyis[c], dxjs = p.dxjs[c];
+        cor_im1 = 0.5 * metric * colp_im1; cor_c = 0.5 * metric * colp;
+        cov_jm1 = -0.5 * metric * colp_jm1; cov_c = -0.5 * metric * colp;
+        pgu_a = -dyis * ((colp + colp_im1) / 2.0); pgu_b = -dyis * ((colp - colp_im1) * CON_CP / 2.0);
+        pgv_a = -dxjs * ((colp + colp_jm1) / 2.0); pgv_b = -dxjs * ((colp - colp_jm1) * CON_CP / 2.0);
+    }
     double ca_is, cao_is, ca_js, cao_js;
     {
         double co[3][3];
@@ -613,56 +623,73 @@ __global__ __launch_bounds__(FTI *TJ) void k_momentum_dma(Geo g, Ptrs p, int gbx
             const double dif = c_dif[k];
             const double pvb_kp1 = SM(S_PVB, 0, 0), pvb_im1_kp1 = SM(S_PVB, -1, 0), pvb_jm1_kp1 = SM(S_PVB, 0, -1);
             const double phi = SM(S_PHI, 0, 0), pott = SM(S_POTT, 0, 0), pvtf = SM(S_PVTF, 0, 0);
+            // ---- the sixteen Arakawa-C flux means B,C,D,E / R,Q,S,T (dyn_UVFLX_prepare.py:249-439) from shared pair
+            // sums of the UFLX (3 x 4) and VFLX (4 x 3) neighbourhoods.  They carry HALF their weight (1/24, 1/48):
+            // the "/ 2" of the wind mean in every advective term is applied here, where it is free -- a power of
+            // two passes through every rounding unchanged.  The sums are associated pairwise instead of left to
+            // right (<= 1 ulp per sum from the reference's order); 80 instead of ~125 fp64 instructions.
+            const double hx_m_m = UF(-1, -1) + UF(0, -1), hx_0_m = UF(0, -1) + UF(1, -1), hx_p_m = UF(1, -1) + UF(2, -1);
+            const double hx_m_0 = UF(-1, 0) + UF(0, 0), hx_0_0 = UF(0, 0) + UF(1, 0), hx_p_0 = UF(1, 0) + UF(2, 0);
+            const double hx_m_p = UF(-1, 1) + UF(0, 1), hx_0_p = UF(0, 1) + UF(1, 1);
+            const double gy_m_m = VF(-1, -1) + VF(-1, 0), gy_0_m = VF(0, -1) + VF(0, 0), gy_p_m = VF(1, -1) + VF(1, 0);
+            const double gy_m_0 = VF(-1, 0) + VF(-1, 1), gy_0_0 = VF(0, 0) + VF(0, 1), gy_p_0 = VF(1, 0) + VF(1, 1);
+            const double gy_m_p = VF(-1, 1) + VF(-1, 2), gy_0_p = VF(0, 1) + VF(0, 2);
+            constexpr double W24 = 1.0 / 24.0, W48 = 1.0 / 48.0;
+            const double prs = pott * c_rds[k];            // POTT / dsigma of the own cell (pressure-gradient terms)
+            const double own = svb1 * (pvb_kp1 - pvtf) + svb * (pvtf - pvb_k);
             // =============================== dUFLXdt (level k, without vertical advection) ====
             {
-                double bflx = 1.0 / 12.0 * (UF(0, -1) + UF(1, -1) + 2.0 * (UF(0, 0) + UF(1, 0)) + UF(0, 1) + UF(1, 1));
-                double bflx_im1 = 1.0 / 12.0 * (UF(-1, -1) + UF(0, -1) + 2.0 * (UF(-1, 0) + UF(0, 0)) + UF(-1, 1) + UF(0, 1));
-                double cflx = 1.0 / 12.0 * (VF(-1, -1) + VF(0, -1) + 2.0 * (VF(-1, 0) + VF(0, 0)) + VF(-1, 1) + VF(0, 1));
-                double cflx_jp1 = 1.0 / 12.0 * (VF(-1, 0) + VF(0, 0) + 2.0 * (VF(-1, 1) + VF(0, 1)) + VF(-1, 2) + VF(0, 2));
-                double dflx_im1 = 1.0 / 24.0 * (VF(-1, -1) + 2.0 * VF(-1, 0) + VF(-1, 1) + UF(-1, -1) + UF(-1, 0) + UF(0, -1) + UF(0, 0));
-                double dflx_jp1 = 1.0 / 24.0 * (VF(0, 0) + 2.0 * VF(0, 1) + VF(0, 2) + UF(0, 0) + UF(0, 1) + UF(1, 0) + UF(1, 1));
-                double eflx = 1.0 / 24.0 * (VF(0, -1) + 2.0 * VF(0, 0) + VF(0, 1) - UF(0, -1) - UF(0, 0) - UF(1, -1) - UF(1, 0));
-                double eflx_im1_jp1 = 1.0 / 24.0 * (VF(-1, 0) + 2.0 * VF(-1, 1) + VF(-1, 2) - UF(-1, 0) - UF(-1, 1) - UF(0, 0) - UF(0, 1));
+                const double gx_m = VF(-1, -1) + VF(0, -1), gx_0 = VF(-1, 0) + VF(0, 0), gx_p = VF(-1, 1) + VF(0, 1), gx_pp = VF(-1, 2) + VF(0, 2);
+                const double bflx = W24 * (hx_0_m + 2.0 * hx_0_0 + hx_0_p);
+                const double bflx_im1 = W24 * (hx_m_m + 2.0 * hx_m_0 + hx_m_p);
+                double cflx = W24 * (gx_m + 2.0 * gx_0 + gx_p);
+                double cflx_jp1 = W24 * (gx_0 + 2.0 * gx_p + gx_pp);
+                double dflx_im1 = W48 * ((gy_m_m + gy_m_0) + (hx_m_m + hx_m_0));
+                double dflx_jp1 = W48 * ((gy_0_0 + gy_0_p) + (hx_0_0 + hx_0_p));
+                double eflx = W48 * ((gy_0_m + gy_0_0) - (hx_0_m + hx_0_0));
+                double eflx_im1_jp1 = W48 * ((gy_m_0 + gy_m_p) - (hx_m_0 + hx_m_p));
                 if (lo) { dflx_im1 = 0.0; cflx = 0.0; eflx = 0.0; }
                 if (hi) { dflx_jp1 = 0.0; cflx_jp1 = 0.0; eflx_im1_jp1 = 0.0; }
                 const double u_im1 = U(-1, 0), u_ip1 = U(1, 0);
-                double t = 0.0;
-                t = t + (+bflx_im1 * (u_im1 + u) / 2.0 - bflx * (u + u_ip1) / 2.0
-                         + cflx * (U(0, -1) + u) / 2.0 - cflx_jp1 * (u + U(0, 1)) / 2.0
-                         + dflx_im1 * (U(-1, -1) + u) / 2.0 - dflx_jp1 * (u + U(1, 1)) / 2.0
-                         + 1.0 * (+eflx * (U(1, -1) + u) / 2.0 - eflx_im1_jp1 * (u + U(-1, 1)) / 2.0));
-                t = t + metric * (colp_im1 * (V(-1, 0) + V(-1, 1)) / 2.0 * (kc_is + (u_im1 + u) / 2.0 * sin_is) +
-                                  colp * (V(0, 0) + V(0, 1)) / 2.0 * (kc_is + (u + u_ip1) / 2.0 * sin_is));
-                t = t + pre_grad(phi, SM(S_PHI, -1, 0), colp, colp_im1, pott, SM(S_POTT, -1, 0),
-                                 pvtf, SM(S_PVTF, -1, 0), pvb_k, pvb_im1_k, pvb_im1_kp1, pvb_kp1,
-                                 ds, svb, svb1, dyis);
-                if (dif > 0.0)
-                    t = t + dif * (UF(-1, 0) + UF(1, 0) + UF(0, -1) + UF(0, 1) - 4.0 * UF(0, 0));
+                const double um = u_im1 + u, up = u + u_ip1;
+                double t = (+bflx_im1 * um - bflx * up
+                            + cflx * (U(0, -1) + u) - cflx_jp1 * (u + U(0, 1))
+                            + dflx_im1 * (U(-1, -1) + u) - dflx_jp1 * (u + U(1, 1))
+                            + (+eflx * (U(1, -1) + u) - eflx_im1_jp1 * (u + U(-1, 1))));
+                // Coriolis and metric term (dyn_UFLX.py:39-66); cor_im1 = metric / 2 * COLP[i-1], hsin_is = sin / 2
+                t = t + (cor_im1 * (V(-1, 0) + V(-1, 1)) * (kc_is + um * hsin_is) +
+                         cor_c * (V(0, 0) + V(0, 1)) * (kc_is + up * hsin_is));
+                // pressure gradient (dyn_functions.py:177-207) with the per-column factors pg_a = -dy (COLP + COLP[i-1]) / 2,
+                // pg_b = -dy (COLP - COLP[i-1]) cp / 2 formed once and POTT / dsigma as POTT * (1 / dsigma)
+                t = t + ((phi - SM(S_PHI, -1, 0)) * pgu_a +
+                         pgu_b * ((SM(S_POTT, -1, 0) * c_rds[k]) * (svb1 * (pvb_im1_kp1 - SM(S_PVTF, -1, 0)) + svb * (SM(S_PVTF, -1, 0) - pvb_im1_k)) +
+                                  prs * own));
+                t = t + dif * (UF(-1, 0) + UF(1, 0) + UF(0, -1) + UF(0, 1) - 4.0 * UF(0, 0));      // dif >= 0; 0 adds nothing
                 if (TURB) t = t + tbu;
                 tu_km1 = t;
             }
             // =============================== dVFLXdt ===============================
             if (v_on) {
-                const double rflx = 1.0 / 12.0 * (VF(-1, 0) + VF(-1, 1) + 2.0 * (VF(0, 0) + VF(0, 1)) + VF(1, 0) + VF(1, 1));
-                const double rflx_jm1 = 1.0 / 12.0 * (VF(-1, -1) + VF(-1, 0) + 2.0 * (VF(0, -1) + VF(0, 0)) + VF(1, -1) + VF(1, 0));
-                const double qflx = 1.0 / 12.0 * (UF(-1, -1) + UF(-1, 0) + 2.0 * (UF(0, -1) + UF(0, 0)) + UF(1, -1) + UF(1, 0));
-                const double qflx_ip1 = 1.0 / 12.0 * (UF(0, -1) + UF(0, 0) + 2.0 * (UF(1, -1) + UF(1, 0)) + UF(2, -1) + UF(2, 0));
-                const double sflx_jm1 = 1.0 / 24.0 * (VF(-1, -1) + VF(-1, 0) + VF(0, -1) + VF(0, 0) + UF(-1, -1) + 2.0 * UF(0, -1) + UF(1, -1));
-                const double sflx_ip1 = 1.0 / 24.0 * (VF(0, 0) + VF(0, 1) + VF(1, 0) + VF(1, 1) + UF(0, 0) + 2.0 * UF(1, 0) + UF(2, 0));
-                const double tflx = 1.0 / 24.0 * (VF(-1, 0) + VF(-1, 1) + VF(0, 0) + VF(0, 1) - UF(-1, 0) - 2.0 * UF(0, 0) - UF(1, 0));
-                const double tflx_ip1_jm1 = 1.0 / 24.0 * (VF(0, -1) + VF(0, 0) + VF(1, -1) + VF(1, 0) - UF(0, -1) - 2.0 * UF(1, -1) - UF(2, -1));
-                double t = 0.0;
-                t = t + (+rflx_jm1 * (V(0, -1) + v) / 2.0 - rflx * (v + V(0, 1)) / 2.0
-                         + qflx * (V(-1, 0) + v) / 2.0 - qflx_ip1 * (v + V(1, 0)) / 2.0
-                         + sflx_jm1 * (V(-1, -1) + v) / 2.0 - sflx_ip1 * (v + V(1, 1)) / 2.0
-                         + -1.0 * (+tflx * (V(-1, 1) + v) / 2.0 - tflx_ip1_jm1 * (v + V(1, -1)) / 2.0));
-                const double ub_jm1 = (U(0, -1) + U(1, -1)) / 2.0, ub = (U(0, 0) + U(1, 0)) / 2.0;
-                t = t + -metric * (colp_jm1 * ub_jm1 * (kc_jm1 + ub_jm1 * sin_jm1) + colp * ub * (kc_c + ub * sin_c));
-                t = t + pre_grad(phi, SM(S_PHI, 0, -1), colp, colp_jm1, pott, SM(S_POTT, 0, -1),
-                                 pvtf, SM(S_PVTF, 0, -1), pvb_k, pvb_jm1_k, pvb_jm1_kp1, pvb_kp1,
-                                 ds, svb, svb1, dxjs);
-                if (dif > 0.0)
-                    t = t + dif * (VF(-1, 0) + VF(1, 0) + VF(0, -1) + VF(0, 1) - 4.0 * VF(0, 0));
+                const double hy_m = UF(-1, -1) + UF(-1, 0), hy_0 = UF(0, -1) + UF(0, 0), hy_p = UF(1, -1) + UF(1, 0), hy_pp = UF(2, -1) + UF(2, 0);
+                const double rflx = W24 * (gy_m_0 + 2.0 * gy_0_0 + gy_p_0);
+                const double rflx_jm1 = W24 * (gy_m_m + 2.0 * gy_0_m + gy_p_m);
+                const double qflx = W24 * (hy_m + 2.0 * hy_0 + hy_p);
+                const double qflx_ip1 = W24 * (hy_0 + 2.0 * hy_p + hy_pp);
+                const double sflx_jm1 = W48 * ((gy_m_m + gy_0_m) + (hx_m_m + hx_0_m));
+                const double sflx_ip1 = W48 * ((gy_0_0 + gy_p_0) + (hx_0_0 + hx_p_0));
+                const double tflx = W48 * ((gy_m_0 + gy_0_0) - (hx_m_0 + hx_0_0));
+                const double tflx_ip1_jm1 = W48 * ((gy_0_m + gy_p_m) - (hx_0_m + hx_p_m));
+                double t = (+rflx_jm1 * (V(0, -1) + v) - rflx * (v + V(0, 1))
+                            + qflx * (V(-1, 0) + v) - qflx_ip1 * (v + V(1, 0))
+                            + sflx_jm1 * (V(-1, -1) + v) - sflx_ip1 * (v + V(1, 1))
+                            - (+tflx * (V(-1, 1) + v) - tflx_ip1_jm1 * (v + V(1, -1))));
+                // dyn_VFLX.py:39-64; us = 2 x the mean u at the v-point, cov_* = -metric / 2 * COLP, hsin = sin / 2
+                const double us_jm1 = U(0, -1) + U(1, -1), us = U(0, 0) + U(1, 0);
+                t = t + (cov_jm1 * us_jm1 * (kc_jm1 + us_jm1 * hsin_jm1) + cov_c * us * (kc_c + us * hsin_c));
+                t = t + ((phi - SM(S_PHI, 0, -1)) * pgv_a +
+                         pgv_b * ((SM(S_POTT, 0, -1) * c_rds[k]) * (svb1 * (pvb_jm1_kp1 - SM(S_PVTF, 0, -1)) + svb * (SM(S_PVTF, 0, -1) - pvb_jm1_k)) +
+                                  prs * own));
+                t = t + dif * (VF(-1, 0) + VF(1, 0) + VF(0, -1) + VF(0, 1) - 4.0 * VF(0, 0));
                 if (TURB) t = t + tbv;
                 tv_km1 = t;
             }

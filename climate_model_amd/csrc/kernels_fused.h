@@ -456,6 +456,7 @@ __global__ __launch_bounds__(FTI *TJ) void k_momentum_dma(Geo g, Ptrs p, int gbx
         pgv_a = -dxjs * ((colp + colp_jm1) / 2.0); pgv_b = -dxjs * ((colp - colp_jm1) * CON_CP / 2.0);
     }
     double ca_is, cao_is, ca_js, cao_js;
+    double wu[6], wv[6];
     {
         double co[3][3];
 #pragma unroll
@@ -479,13 +480,23 @@ __global__ __launch_bounds__(FTI *TJ) void k_momentum_dma(Geo g, Ptrs p, int gbx
         }
         ca_js = 1.0 / 8.0 * (CA(1, -1) + CA(1, 0) + 2.0 * CA(0, -1) + 2.0 * CA(0, 0) + CA(-1, -1) + CA(-1, 0));
         cao_js = 1.0 / 8.0 * (CO(1, -1) + CO(1, 0) + 2.0 * CO(0, -1) + 2.0 * CO(0, 0) + CO(-1, -1) + CO(-1, 0));
+        // weights of the six-point COLP_NEW * A * WWIND means at the u- and v-point (dyn_functions.py:211-270)
+        // with 1/8 (1/4 at a polar row, "rigid wall") and the doubled centre pair folded in: powers of two,
+        // exact.  A polar row gives its two outside points weight 0 (their WWIND halo values are finite).
+        const double ws = lo ? 0.0 : (hi ? 0.25 : 0.125), wn = hi ? 0.0 : (lo ? 0.25 : 0.125);
+        wu[0] = wn * CA(-1, 1); wu[1] = wn * CA(0, 1); wu[2] = 0.25 * CA(-1, 0); wu[3] = 0.25 * CA(0, 0);
+        wu[4] = ws * CA(-1, -1); wu[5] = ws * CA(0, -1);
+        wv[0] = 0.125 * CA(1, -1); wv[1] = 0.125 * CA(1, 0); wv[2] = 0.25 * CA(0, -1); wv[3] = 0.25 * CA(0, 0);
+        wv[4] = 0.125 * CA(-1, -1); wv[5] = 0.125 * CA(-1, 0);
 #undef CA
 #undef CO
     }
     // Divisions by per-column (ca_is, ca_js) and per-level (dsigma) quantities are multiplications by
     // reciprocals formed once: <= 1 ulp from the reference's x / y per operation, 8 fp64 divisions
     // (~80 instructions) less per level -- -9 % kernel time.  The stage kernels keep the divisions.
-    const double r_ca_is = 1.0 / ca_is, r_ca_js = 1.0 / ca_js;
+    // ... and the pressure-weighted Euler step X_new = X_old * P_old / P + dt * dX / P (dyn_timestep.py:34-79) as
+    // X_old * eu1 + dX * eu2 with eu1 = P_old * (1 / P), eu2 = dt * (1 / P) per column
+    const double eu1 = cao_is * (1.0 / ca_is), eu2 = dt * (1.0 / ca_is), ev1 = cao_js * (1.0 / ca_js), ev2 = dt * (1.0 / ca_js);
     const size_t c0 = c + (size_t)k0 * g.plane;
     double pvb_k = p.PVTFVB[c0], pvb_im1_k = p.PVTFVB[c0 - 1], pvb_jm1_k = p.PVTFVB[c0 - P];
 
@@ -498,14 +509,10 @@ __global__ __launch_bounds__(FTI *TJ) void k_momentum_dma(Geo g, Ptrs p, int gbx
     double u_km1 = 0.0, v_km1 = 0.0, uo_km1 = 0.0, vo_km1 = 0.0;
     double tu_km1 = 0.0, tv_km1 = 0.0;      // tendencies of level k-1 without the vertical advection
     if (k0 > 0) {       // a chunk that starts inside the column: interface k0 and the winds above it
-#define WG(a, b) (ca[(b) + 1][(a) + 1] * p.WWIND[c0 + (b) * P + (a)])
-#define WG2(a, b) (2.0 * ca[(b) + 1][(a) + 1] * p.WWIND[c0 + (b) * P + (a)])
-        if (lo) su_k = 0.25 * (WG(-1, 1) + WG(0, 1) + WG(-1, 0) + WG(0, 0));
-        else if (hi) su_k = 0.25 * (WG(-1, 0) + WG(0, 0) + WG(-1, -1) + WG(0, -1));
-        else su_k = 0.125 * (WG(-1, 1) + WG(0, 1) + WG2(-1, 0) + WG2(0, 0) + WG(-1, -1) + WG(0, -1));
-        sv_k = 0.125 * (WG(1, -1) + WG(1, 0) + WG2(0, -1) + WG2(0, 0) + WG(-1, -1) + WG(-1, 0));
+#define WG(a, b) p.WWIND[c0 + (b) * P + (a)]
+        su_k = wu[0] * WG(-1, 1) + wu[1] * WG(0, 1) + wu[2] * WG(-1, 0) + wu[3] * WG(0, 0) + wu[4] * WG(-1, -1) + wu[5] * WG(0, -1);
+        sv_k = wv[0] * WG(1, -1) + wv[1] * WG(1, 0) + wv[2] * WG(0, -1) + wv[3] * WG(0, 0) + wv[4] * WG(-1, -1) + wv[5] * WG(-1, 0);
 #undef WG
-#undef WG2
         u_km1 = p.UWIND[c0 - g.plane];
         v_km1 = p.VWIND[c0 - g.plane];
     }
@@ -513,14 +520,18 @@ __global__ __launch_bounds__(FTI *TJ) void k_momentum_dma(Geo g, Ptrs p, int gbx
     // vertical 1-D constants -> LDS: a vector-memory load inside the loop would make the compiler
     // wait vmcnt(0) at its first use and drain the DMA prefetch (cdna_hip_programming.md, section 5)
     double *cst = dsm + 2 * BUF;
-    double *c_ds = cst, *c_svb = cst + DMAXZ, *c_dif = cst + 2 * DMAXZ + 1;
-    double *c_rds = cst + 3 * DMAXZ + 2, *c_rsum = cst + 4 * DMAXZ + 2;     // 1/dsigma[k], 1/(dsigma[k]+dsigma[k-1])
+    // c_wa[k], c_wb[k]: weights of the winds of levels k-1 and k in the dsigma-weighted mean at interface k
+    // (dyn_functions.py:236-241), dsigma[k] / (dsigma[k] + dsigma[k-1]) and dsigma[k-1] / (...); c_rds = 1 / dsigma
+    double *c_wa = cst, *c_svb = cst + DMAXZ, *c_dif = cst + 2 * DMAXZ + 1;
+    double *c_rds = cst + 3 * DMAXZ + 2, *c_wb = cst + 4 * DMAXZ + 2;
     for (int t = tid; t <= nz; t += NT) {
         c_svb[t] = p.sigma_vb[t];
         if (t < nz) {
-            c_ds[t] = p.dsigma[t]; c_dif[t] = p.UVFLX_dif_coef[t];
+            c_dif[t] = p.UVFLX_dif_coef[t];
             c_rds[t] = 1.0 / p.dsigma[t];
-            c_rsum[t] = t > 0 ? 1.0 / (p.dsigma[t] + p.dsigma[t - 1]) : 0.0;
+            const double rsum = t > 0 ? 1.0 / (p.dsigma[t] + p.dsigma[t - 1]) : 0.0;
+            c_wa[t] = p.dsigma[t] * rsum;
+            c_wb[t] = t > 0 ? p.dsigma[t - 1] * rsum : 0.0;
         }
     }
     // 2-D factor tiles, same element -> grid cell map as the DMA chunks
@@ -566,7 +577,6 @@ __global__ __launch_bounds__(FTI *TJ) void k_momentum_dma(Geo g, Ptrs p, int gbx
         if (TURB && k + 1 < k1) { tbu_nx = p.TURB_U[c + (size_t)(k + 1) * g.plane]; tbv_nx = v_on ? p.TURB_V[c + (size_t)(k + 1) * g.plane] : 0.0; }
         const double *buf = dsm + (k & 1) * BUF;
         if (active) {
-            const double ds = c_ds[k];
             double uf[3][4], vf[4][3], uw[3][3], vw[3][3];
 #pragma unroll
             for (int b = 0; b < 3; b++)
@@ -592,32 +602,26 @@ __global__ __launch_bounds__(FTI *TJ) void k_momentum_dma(Geo g, Ptrs p, int gbx
             }
             // ---- interface k closes level k-1 ----
             if (k >= 1) {
-                const double ds_km1 = c_ds[k - 1];
-                const double rsum = c_rsum[k];
-                const double wu_k = su_k * ((ds * u_km1 + ds_km1 * u) * rsum);
-                const double wv_k = sv_k * ((ds * v_km1 + ds_km1 * v) * rsum);
+                const double wa = c_wa[k], wb = c_wb[k];
+                const double wu_k = su_k * (wa * u_km1 + wb * u);
+                const double wv_k = sv_k * (wa * v_km1 + wb * v);
                 if (k > k0) {
                     const size_t qm = c + (size_t)(k - 1) * g.plane;
                     const double rds1 = c_rds[k - 1];
                     const double tu = tu_km1 + (wu_km1 - wu_k) * rds1;
-                    u_out[qm] = uo_km1 * cao_is * r_ca_is + dt * tu * r_ca_is;
+                    u_out[qm] = uo_km1 * eu1 + tu * eu2;
                     if (v_on) {
                         const double tv = tv_km1 + (wv_km1 - wv_k) * rds1;
-                        v_out[qm] = vo_km1 * cao_js * r_ca_js + dt * tv * r_ca_js;
+                        v_out[qm] = vo_km1 * ev1 + tv * ev2;
                     }
                 }
                 wu_km1 = wu_k; wv_km1 = wv_k;
             }
             // ---- six-point sums at interface k+1 (dyn_functions.py:211-270) ----
             if (k + 1 < nz) {
-#define WT(a, b) (ca[(b) + 1][(a) + 1] * SM(S_W, a, b))
-#define WT2(a, b) (2.0 * ca[(b) + 1][(a) + 1] * SM(S_W, a, b))
-                if (lo) su_k = 0.25 * (WT(-1, 1) + WT(0, 1) + WT(-1, 0) + WT(0, 0));
-                else if (hi) su_k = 0.25 * (WT(-1, 0) + WT(0, 0) + WT(-1, -1) + WT(0, -1));
-                else su_k = 0.125 * (WT(-1, 1) + WT(0, 1) + WT2(-1, 0) + WT2(0, 0) + WT(-1, -1) + WT(0, -1));
-                sv_k = 0.125 * (WT(1, -1) + WT(1, 0) + WT2(0, -1) + WT2(0, 0) + WT(-1, -1) + WT(-1, 0));
-#undef WT
-#undef WT2
+                const double w_c = SM(S_W, 0, 0), w_w = SM(S_W, -1, 0), w_s = SM(S_W, 0, -1), w_sw = SM(S_W, -1, -1);
+                su_k = wu[0] * SM(S_W, -1, 1) + wu[1] * SM(S_W, 0, 1) + wu[2] * w_w + wu[3] * w_c + wu[4] * w_sw + wu[5] * w_s;
+                sv_k = wv[0] * SM(S_W, 1, -1) + wv[1] * SM(S_W, 1, 0) + wv[2] * w_s + wv[3] * w_c + wv[4] * w_sw + wv[5] * w_w;
             }
             const double svb = c_svb[k], svb1 = c_svb[k + 1];
             const double dif = c_dif[k];
@@ -705,16 +709,14 @@ __global__ __launch_bounds__(FTI *TJ) void k_momentum_dma(Geo g, Ptrs p, int gbx
     }
     // ---- the last level of the chunk: its lower interface is k1 (WWIND*U = 0 at the surface) ----
     if (active) {
-        const double ds = c_ds[k1 - 1];
         const size_t qm = c + (size_t)(k1 - 1) * g.plane;
         double wu_k = 0.0, wv_k = 0.0;
         if (k1 < nz) {
-            const double ds1 = c_ds[k1];
-            wu_k = su_k * ((ds1 * u_km1 + ds * p.UWIND[qm + g.plane]) * c_rsum[k1]);
-            wv_k = sv_k * ((ds1 * v_km1 + ds * p.VWIND[qm + g.plane]) * c_rsum[k1]);
+            wu_k = su_k * (c_wa[k1] * u_km1 + c_wb[k1] * p.UWIND[qm + g.plane]);
+            wv_k = sv_k * (c_wa[k1] * v_km1 + c_wb[k1] * p.VWIND[qm + g.plane]);
         }
-        u_out[qm] = uo_km1 * cao_is * r_ca_is + dt * (tu_km1 + (wu_km1 - wu_k) * c_rds[k1 - 1]) * r_ca_is;
-        if (v_on) v_out[qm] = vo_km1 * cao_js * r_ca_js + dt * (tv_km1 + (wv_km1 - wv_k) * c_rds[k1 - 1]) * r_ca_js;
+        u_out[qm] = uo_km1 * eu1 + (tu_km1 + (wu_km1 - wu_k) * c_rds[k1 - 1]) * eu2;
+        if (v_on) v_out[qm] = vo_km1 * ev1 + (tv_km1 + (wv_km1 - wv_k) * c_rds[k1 - 1]) * ev2;
     }
 #undef SM
 }

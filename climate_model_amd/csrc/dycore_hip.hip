@@ -145,7 +145,7 @@ struct dycore {
     bool winds_bc_dirty = true;     // UWIND / VWIND came from the host: their lateral BC images (column nx+2!) may be unset
     int n_cu = 256;                 // compute units of the device
     int cell_lin = -1;              // DYCORE_CELL_LINEAR: column-kernel launch, bit 0 = cell runs, bit 1 = XCD-aware order (default 3 or 2)
-    int mom_ks = 0;                 // DYCORE_MOM_KS: force the level chunks per momentum tile (1, 2, 4)
+    int mom_ks = 0;                 // DYCORE_MOM_KS: force the level chunks per momentum tile (1 .. 16)
     int mom_split = 1;              // DYCORE_MOM_SPLIT=0: no second segment (short chunks for the tiles beyond the last full round)
     double mom_pro = 2.0;           // DYCORE_MOM_PRO: prologue of a level chunk in units of one level (plan cost model)
     int mom_dma = 1;                // momentum kernel: 1 = LDS-DMA (default); 0 = register-staged tiles (DYCORE_MOM_DMA)
@@ -500,16 +500,18 @@ int do_momentum_fused(dycore *h, const Ptrs &p, const double *u_old, const doubl
         // prologue (2-D loads, factor tiles, first DMA: ~mom_pro levels).  Candidates: the whole row set
         // in 1, 2 or 4 chunks per tile, or -- for a contiguous row set of more than one round -- the
         // tile rows that fill whole rounds as full tiles (segment a) and the remaining rows cut into
-        // up to 8 chunks (segment b), so that the last round costs a fraction of a tile.
+        // up to 16 chunks (segment b), so that the last round costs a fraction of a tile.
         MomPlan plan = {trows, 1, 0, {0, 0, 0, 0}, 1};
         {
             const long tiles = (long)gbx * trows.n;
             const double pro = h->mom_pro;
             auto rounds = [&](long wg) { return (double)((wg + h->n_cu - 1) / h->n_cu); };
             double best = -1.0;
-            for (int cand : {1, 2, 4}) {
+            // any number of chunks up to 16 (chunk kc covers levels [kc nz / ks, (kc + 1) nz / ks)); a chunk of fewer
+            // than 4 levels is all prologue
+            for (int cand = 1; cand <= 16; cand++) {
                 if (h->g.nz / cand < 4) break;
-                const double cost = rounds(tiles * cand) * ((double)h->g.nz / cand + (cand > 1 ? pro : 0.0));
+                const double cost = rounds(tiles * cand) * (ceil((double)h->g.nz / cand) + (cand > 1 ? pro : 0.0));
                 if (best < 0 || cost < best - 1e-9) { best = cost; plan.ks_a = cand; }
             }
             if (h->mom_ks) plan.ks_a = h->mom_ks;
@@ -518,9 +520,9 @@ int do_momentum_fused(dycore *h, const Ptrs &p, const double *u_old, const doubl
                 const int r1 = (int)(full * h->n_cu / gbx);       // tile rows inside those rounds
                 const int r2 = trows.n - r1;
                 if (r1 >= 1 && r2 >= 1) {
-                    for (int cand : {1, 2, 4, 8}) {
+                    for (int cand = 1; cand <= 16; cand++) {
                         if (h->g.nz / cand < 4) break;
-                        const double cost = rounds((long)gbx * r1) * h->g.nz + rounds((long)gbx * r2 * cand) * ((double)h->g.nz / cand + (cand > 1 ? pro : 0.0));
+                        const double cost = rounds((long)gbx * r1) * h->g.nz + rounds((long)gbx * r2 * cand) * (ceil((double)h->g.nz / cand) + (cand > 1 ? pro : 0.0));
                         if (cost < best - 1e-9) {
                             best = cost;
                             plan.a = {trows.first, r1, r1, 0}; plan.ks_a = 1;

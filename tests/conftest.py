@@ -24,3 +24,29 @@ def pytest_sessionstart(session):
             torch.zeros(1, device='cuda')
     except Exception:
         pass
+
+
+def pytest_terminal_summary(terminalreporter):
+    """Largest max-norm relative error each test measured through golden_util.rel_max_err (the margin
+    under its tolerance); also written to gpurun_out/parity_margins.txt when that directory exists."""
+    try:
+        from golden_util import ERR_LOG
+    except Exception:
+        return
+    if not ERR_LOG:
+        return
+    worst = {}
+    for node, name, err in ERR_LOG:
+        if node not in worst or err > worst[node][1]:
+            worst[node] = (name, err)
+    lines = ['%-100s %-8s %.2e' % (node[-100:], name, err) for node, (name, err) in sorted(worst.items())]
+    terminalreporter.write_sep('-', 'largest relative error per test (golden_util.rel_max_err)')
+    for l in lines:
+        terminalreporter.write_line(l)
+    out = os.path.join(ROOT, 'gpurun_out')
+    if os.path.isdir(out):
+        try:
+            with open(os.path.join(out, 'parity_margins.txt'), 'w') as fh:
+                fh.write('\n'.join(lines) + '\n')
+        except OSError:
+            pass

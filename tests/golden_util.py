@@ -35,6 +35,11 @@ def compare_region(name, nx, ny):
     return slice(None), slice(None)
 
 
+# every comparison a test makes: (pytest node id, field, error) -- conftest.py prints the largest error per test
+# at the end of the session next to nothing else, so the margin under each stated tolerance is on record
+ERR_LOG = []
+
+
 def rel_max_err(test, ref, name, nx, ny):
     """max|test-ref| / max|ref| over cells where the reference is finite
     (the reference's own testsuite.py:46-60 norm).  Returns (err, n_compared,
@@ -48,4 +53,6 @@ def rel_max_err(test, ref, name, nx, ny):
     bad = int((~np.isfinite(t[m])).sum())
     scale = np.max(np.abs(r[m]))
     d = np.max(np.abs(np.where(np.isfinite(t[m]), t[m], 0.0) - r[m]))
-    return (d / scale if scale > 0 else d), int(m.sum()), bad
+    err = d / scale if scale > 0 else d
+    ERR_LOG.append((os.environ.get('PYTEST_CURRENT_TEST', '').split(' ')[0], name, float(err)))
+    return err, int(m.sum()), bad

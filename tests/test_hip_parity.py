@@ -19,8 +19,11 @@ pytestmark = pytest.mark.gpu
 # acceptance threshold is 1e-4).  The device differs from the fp64 golden vectors by
 # FMA contraction and by ocml pow/sin/cos vs libm: a few ulp per operation, amplified by
 # the cancellation in the pressure-gradient and flux-difference terms.
-STAGE_TOL = 1e-11
-STEP_TOL = 1e-9
+# max-norm relative (the reference's testsuite.py:46-60 norm).  Observed on MI355X (gpurun_out/parity_margins.txt,
+# printed at the end of every pytest session): <= 6e-15 per stage, <= 5e-12 per multi-step run on every grid up to
+# 0.25 deg x 64 (QC 6e-11): the tolerances sit 20x above that, not at the 1e-4 the reference itself accepts.
+STAGE_TOL = 1e-13
+STEP_TOL = 1e-10
 PROGNOSTIC = ['COLP', 'UWIND', 'VWIND', 'POTT']
 
 
@@ -100,7 +103,7 @@ def test_whole_steps_vs_golden(case, steps, driver, i_moist):
                 continue
             # QC lives at the 1e-10 level through the 1e-7 clamp of the log interpolation and
             # amplifies last-bit differences of log(): looser bound
-            lim = 1e-7 if name == 'QC' else STEP_TOL
+            lim = 1e-9 if name == 'QC' else STEP_TOL
             assert err <= lim, '%s %s step %d %s: rel err %.3e' % (case, driver, s, name, err)
 
 
@@ -296,7 +299,7 @@ def test_solver_loop_matches_oracle_and_reports():
     F.copy_device_to_host(GR, ['COLP', 'UWIND', 'VWIND', 'POTT', 'QV', 'QC'])
     for n in ('COLP', 'UWIND', 'VWIND', 'POTT', 'QV'):
         err, ncmp, bad = rel_max_err(F.host[n], z['step005/' + n], n, GR.nx, GR.ny)
-        assert ncmp > 0 and bad == 0 and err < 1e-9, (n, err)
+        assert ncmp > 0 and bad == 0 and err < STEP_TOL, (n, err)
     # the line printed at step 2 describes the state after step 1
     vmax, vmean, tmean, colp = log[0]
     A = z['grid/A']
@@ -428,7 +431,7 @@ def test_fused_turbulent_step_equals_stage_kernels(monkeypatch, i_moist):
     """A turbulence-coupled handle (i_turb) steps on the fused kernels too: k_turb_tendencies supplies the
     turbulent terms (same expressions as k_prepare / k_*_tendency<true>).  Against the stage kernels
     (DYCORE_FUSED_TURB=0) on random K fields and surface fluxes, halos included: 1e-11, and against the
-    oracle 1e-9."""
+    oracle 1e-10."""
     from climate_model_amd import Namelist, Grid, ModelFields, HipDycore
     from climate_model_amd.synthetic import initialize_fields, initialize_moisture
     from oracle_binding import Oracle
@@ -466,4 +469,4 @@ def test_fused_turbulent_step_equals_stage_kernels(monkeypatch, i_moist):
     o.step_matsuno(GR.dt, 3, with_rho=True)
     for n in ('UWIND', 'VWIND', 'POTT', 'COLP') + (('QV',) if i_moist else ()):
         err, ncmp, bad = rel_max_err(out['1'][n], o.F[n], n, GR.nx, GR.ny)
-        assert bad == 0 and ncmp > 0 and err <= 1e-9, '%s vs oracle: %.3e' % (n, err)
+        assert bad == 0 and ncmp > 0 and err <= STEP_TOL, '%s vs oracle: %.3e' % (n, err)

@@ -489,6 +489,31 @@ __device__ __forceinline__ double varvb_log(double var, double var_km1)
     return (log(var_km1) - log(var)) / (1.0 / var - 1.0 / var_km1);
 }
 
+// The same value with the logarithm and reciprocal of each clamped level value formed at most once: a level is the
+// lower argument of one interface and the upper argument of the next (k_moist carries the cache down the column),
+// and neither is formed where the two clamped values are equal (cloud water is 1e-7 = the clamp in most of the
+// atmosphere).  Same operations on the same operands as varvb_log: bit-identical.
+struct LogCache { double c, l, r; bool have; };
+__device__ __forceinline__ LogCache log_cache(double var)
+{
+    const double min_val = 0.0000001;
+    LogCache x;
+    x.c = (min_val > var) ? min_val : var;
+    x.l = 0.0; x.r = 0.0; x.have = false;
+    return x;
+}
+__device__ __forceinline__ void log_need(LogCache &x)
+{
+    if (!x.have) { x.l = log(x.c); x.r = 1.0 / x.c; x.have = true; }
+}
+__device__ __forceinline__ double varvb_log_cached(LogCache &var, LogCache &var_km1)
+{
+    if (var_km1.c == var.c) return var.c;
+    log_need(var);
+    log_need(var_km1);
+    return (var_km1.l - var.l) / (var.r - var_km1.r);
+}
+
 // dyn_functions.py:26-67
 __device__ __forceinline__ double turb_flux(double phi, double phi_kp1, double phi_km1, double phivb,
                                             double phivb_kp1, double var, double var_kp1, double var_km1,
@@ -531,6 +556,7 @@ __global__ __launch_bounds__(TI *TJ) void k_moist(Geo g, Ptrs p, const double *q
     double qv_km1 = 0.0, qc_km1 = 0.0, phi_km1 = 0.0;
     double fv_k = 0.0, fc_k = 0.0;                 // W * interface value at interface k (0 at the top)
     double qv_k = p.QV[c], qc_k = p.QC[c];
+    LogCache lv_k = log_cache(qv_k), lc_k = log_cache(qc_k);
     // software pipeline as in k_pott_fused: the inputs of level k+1 are requested before level k is
     // computed, so the HBM latency overlaps the two logarithms per interface
     __shared__ double s_met[FROM_WINDS ? 4 : 1][TI * TJ];
@@ -574,8 +600,10 @@ __global__ __launch_bounds__(TI *TJ) void k_moist(Geo g, Ptrs p, const double *q
         double fv_kp1 = 0.0, fc_kp1 = 0.0;
         if (!last) {
             const double w_kp1 = cur.w1;
-            fv_kp1 = w_kp1 * varvb_log(qv_kp1, qv_k);
-            fc_kp1 = w_kp1 * varvb_log(qc_kp1, qc_k);
+            LogCache lv_kp1 = log_cache(qv_kp1), lc_kp1 = log_cache(qc_kp1);
+            fv_kp1 = w_kp1 * varvb_log_cached(lv_kp1, lv_k);
+            fc_kp1 = w_kp1 * varvb_log_cached(lc_kp1, lc_k);
+            lv_k = lv_kp1; lc_k = lc_kp1;
         }
         double tq[2];
 #pragma unroll

@@ -429,6 +429,10 @@ __global__ __launch_bounds__(FTI *TJ) void k_momentum_dma(Geo g, Ptrs p, int gbx
     const int jg = j + g.joff;
     const bool lo = (jg == 1), hi = (jg == g.ny_global);
     const bool v_on = active && (j >= jv_lo);
+    // a wavefront is one latitude row: the polar-row switches of the C, D, E fluxes are wave-uniform weights
+    const bool lo_u = __builtin_amdgcn_readfirstlane((int)lo) != 0, hi_u = __builtin_amdgcn_readfirstlane((int)hi) != 0;
+    const double w24_lo = lo_u ? 0.0 : 1.0 / 24.0, w48_lo = lo_u ? 0.0 : 1.0 / 48.0;
+    const double w24_hi = hi_u ? 0.0 : 1.0 / 24.0, w48_hi = hi_u ? 0.0 : 1.0 / 48.0;
     double ca[3][3];
 #pragma unroll
     for (int b = 0; b < 3; b++)
@@ -646,14 +650,12 @@ __global__ __launch_bounds__(FTI *TJ) void k_momentum_dma(Geo g, Ptrs p, int gbx
                 const double gx_m = VF(-1, -1) + VF(0, -1), gx_0 = VF(-1, 0) + VF(0, 0), gx_p = VF(-1, 1) + VF(0, 1), gx_pp = VF(-1, 2) + VF(0, 2);
                 const double bflx = W24 * (hx_0_m + 2.0 * hx_0_0 + hx_0_p);
                 const double bflx_im1 = W24 * (hx_m_m + 2.0 * hx_m_0 + hx_m_p);
-                double cflx = W24 * (gx_m + 2.0 * gx_0 + gx_p);
-                double cflx_jp1 = W24 * (gx_0 + 2.0 * gx_p + gx_pp);
-                double dflx_im1 = W48 * ((gy_m_m + gy_m_0) + (hx_m_m + hx_m_0));
-                double dflx_jp1 = W48 * ((gy_0_0 + gy_0_p) + (hx_0_0 + hx_0_p));
-                double eflx = W48 * ((gy_0_m + gy_0_0) - (hx_0_m + hx_0_0));
-                double eflx_im1_jp1 = W48 * ((gy_m_0 + gy_m_p) - (hx_m_0 + hx_m_p));
-                if (lo) { dflx_im1 = 0.0; cflx = 0.0; eflx = 0.0; }
-                if (hi) { dflx_jp1 = 0.0; cflx_jp1 = 0.0; eflx_im1_jp1 = 0.0; }
+                const double cflx = w24_lo * (gx_m + 2.0 * gx_0 + gx_p);          // 0 at the southern polar row (dyn_UFLX.py:377-384)
+                const double cflx_jp1 = w24_hi * (gx_0 + 2.0 * gx_p + gx_pp);     // 0 at the northern polar row
+                const double dflx_im1 = w48_lo * ((gy_m_m + gy_m_0) + (hx_m_m + hx_m_0));
+                const double dflx_jp1 = w48_hi * ((gy_0_0 + gy_0_p) + (hx_0_0 + hx_0_p));
+                const double eflx = w48_lo * ((gy_0_m + gy_0_0) - (hx_0_m + hx_0_0));
+                const double eflx_im1_jp1 = w48_hi * ((gy_m_0 + gy_m_p) - (hx_m_0 + hx_m_p));
                 const double u_im1 = U(-1, 0), u_ip1 = U(1, 0);
                 const double um = u_im1 + u, up = u + u_ip1;
                 double t = (+bflx_im1 * um - bflx * up

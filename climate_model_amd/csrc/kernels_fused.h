@@ -968,6 +968,7 @@ __global__ __launch_bounds__(TI *TJ) void k_pott_fused(Geo g, Ptrs p, const doub
     double w_kp1 = ldb(p.WWIND, bc + (unsigned)nz * bpl);
     double pvbo_kp1 = ldb(p.POTTVB, bc + (unsigned)nz * bpl);        // old interface values
     double pottn_kp1 = 0.0, pvtf_kp1 = 0.0, pottvb_first = 0.0;
+    double p_up = interface_pressure(g.pair_top, p.sigma_vb[nz - 1], cnew), pvb_up = exner_vb(p_up);   // upper interface of the bottom level
     // software pipeline: the inputs of level k-1 are requested before level k is computed, so the
     // HBM latency overlaps the pow/division chain instead of preceding it.  One level ahead is
     // enough (rings of 2-4 levels cost the third wave per SIMD and ran 5-15 % slower,
@@ -1017,7 +1018,14 @@ __global__ __launch_bounds__(TI *TJ) void k_pott_fused(Geo g, Ptrs p, const doub
         const double pott = cur.po * cold * r_cnew + dt * t * r_cnew;
         stb(pott_out, q, pott);
         // diagnostics of the new column, level k
-        const DiagLevel dl = diag_level(g.pair_top, p.sigma_vb[k], cnew, pott, p_kp12, pvb_kp1, phivb_kp1);
+        // the interface pressure of this level's upper interface and its Exner value (one pow) were formed during the
+        // level below: the pow depends on the column pressure only, so it need not sit in front of this level's
+        // dependent chain (PVTF -> PHI -> PHIVB, POTTVB); the one for the next level up is issued here
+        const DiagLevel dl = diag_level_pre(p_up, pvb_up, pott, p_kp12, pvb_kp1, phivb_kp1);
+        if (k > 0) {
+            p_up = interface_pressure(g.pair_top, p.sigma_vb[k - 1], cnew);
+            pvb_up = exner_vb(p_up);
+        }
         const double p_km12 = dl.p_km12, pvb_k = dl.pvb_k, pvtf = dl.pvtf, phi = dl.phi, phivb = dl.phivb;
         stb(p.PVTF, q, pvtf);
         stb(p.PVTFVB, q, pvb_k);

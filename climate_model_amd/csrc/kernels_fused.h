@@ -743,45 +743,54 @@ __global__ __launch_bounds__(TI *TJ) void k_turb_tendencies(Geo g, Ptrs p, int j
     const bool lo = (jg == 1), hi = (jg == g.ny_global);
     const bool v_on = j >= jv_lo;
     const double colp = p.COLP[c];
-    // COLP * A at the points of the two six-point stencils
-#define CAo(a, b) (p.COLP[c + (b) * P + (a)] * p.A[c + (b) * P + (a)])
-    // ---- u-point (i-1/2, j): columns i-1, i; rows j-1 .. j+1 ----
-#define KT(a, b, q) (p.RHOVB[(q) + (b) * P + (a)] * p.COLP[c + (b) * P + (a)] * p.A[c + (b) * P + (a)] * p.KMOM[(q) + (b) * P + (a)])
-#define KT2(a, b, q) (2.0 * p.RHOVB[(q) + (b) * P + (a)] * p.COLP[c + (b) * P + (a)] * p.A[c + (b) * P + (a)] * p.KMOM[(q) + (b) * P + (a)])
-#define PH(a, b, q) p.PHI[(q) + (b) * P + (a)]
+    constexpr double RG = 1.0 / CON_G;
+    // Everything that depends on the column only is formed once: COLP * A of the 3 x 3 neighbourhood folded into the
+    // weights of the six-point means at the u-point (columns i-1, i; rows j-1 .. j+1; four points with weight 1/4
+    // at a polar row: zero weights) and at the v-point (rows j-1, j; columns i-1 .. i+1), and the plain six-point
+    // weights of interp_VAR_ds (dyn_functions.py:383-424) with its division by g as a factor.  Divisions by g are
+    // multiplications by 1/g; the products are associated differently from the stage kernels (a few ulp).
+    // point order u: (-1,1) (0,1) (-1,0) (0,0) (-1,-1) (0,-1);  v: (1,-1) (1,0) (0,-1) (0,0) (-1,-1) (-1,0)
+    const int ou[6] = {P - 1, P, -1, 0, -P - 1, -P}, ov[6] = {-P + 1, 1, -P, 0, -P - 1, -1};
+    double wu[6], wv[6], ku[6], kv[6];
+    {
+        const double wn = hi ? 0.0 : (lo ? 0.25 : 0.125), ws = lo ? 0.0 : (hi ? 0.25 : 0.125);
+        const double w6u[6] = {wn, wn, 0.25, 0.25, ws, ws}, w6v[6] = {0.125, 0.125, 0.25, 0.25, 0.125, 0.125};
+#pragma unroll
+        for (int n = 0; n < 6; n++) {
+            wu[n] = w6u[n] * RG; wv[n] = w6v[n] * RG;
+            ku[n] = w6u[n] * (p.COLP[c + ou[n]] * p.A[c + ou[n]]);
+            kv[n] = w6v[n] * (p.COLP[c + ov[n]] * p.A[c + ov[n]]);
+        }
+    }
+    // six-point means of a field at the u- / v-point with the given weights (a polar row gives its outside points
+    // weight 0; their halo values are finite)
+    auto m6u = [&](const double *F, size_t q, const double *w) {
+        return w[0] * F[q + ou[0]] + w[1] * F[q + ou[1]] + w[2] * F[q + ou[2]] + w[3] * F[q + ou[3]] + w[4] * F[q + ou[4]] + w[5] * F[q + ou[5]];
+    };
+    auto m6v = [&](const double *F, size_t q, const double *w) {
+        return w[0] * F[q + ov[0]] + w[1] * F[q + ov[1]] + w[2] * F[q + ov[2]] + w[3] * F[q + ov[3]] + w[4] * F[q + ov[4]] + w[5] * F[q + ov[5]];
+    };
+    // RHOVB * COLP * A * KMOM means (dyn_functions.py:276-377)
     auto k6u = [&](size_t q) {
-        if (lo) return 0.25 * (KT(-1, 1, q) + KT(0, 1, q) + KT(-1, 0, q) + KT(0, 0, q));
-        if (hi) return 0.25 * (KT(-1, 0, q) + KT(0, 0, q) + KT(-1, -1, q) + KT(0, -1, q));
-        return 0.125 * (KT(-1, 1, q) + KT(0, 1, q) + KT2(-1, 0, q) + KT2(0, 0, q) + KT(-1, -1, q) + KT(0, -1, q));
+        double s = 0.0;
+#pragma unroll
+        for (int n = 0; n < 6; n++) s += ku[n] * (p.RHOVB[q + ou[n]] * p.KMOM[q + ou[n]]);
+        return s;
     };
-    auto altu = [&](size_t q) {
-        if (lo) return 0.25 * (PH(-1, 1, q) + PH(0, 1, q) + PH(-1, 0, q) + PH(0, 0, q)) / CON_G;
-        if (hi) return 0.25 * (PH(-1, 0, q) + PH(0, 0, q) + PH(-1, -1, q) + PH(0, -1, q)) / CON_G;
-        return 0.125 * (PH(-1, 1, q) + PH(0, 1, q) + 2.0 * PH(-1, 0, q) + 2.0 * PH(0, 0, q) + PH(-1, -1, q) + PH(0, -1, q)) / CON_G;
-    };
-    // ---- v-point (i, j-1/2): rows j-1, j; columns i-1 .. i+1 ----
     auto k6v = [&](size_t q) {
-        return 0.125 * (KT(1, -1, q) + KT(1, 0, q) + KT2(0, -1, q) + KT2(0, 0, q) + KT(-1, -1, q) + KT(-1, 0, q));
+        double s = 0.0;
+#pragma unroll
+        for (int n = 0; n < 6; n++) s += kv[n] * (p.RHOVB[q + ov[n]] * p.KMOM[q + ov[n]]);
+        return s;
     };
-    auto altv = [&](size_t q) {
-        return 0.125 * (PH(1, -1, q) + PH(1, 0, q) + 2.0 * PH(0, -1, q) + 2.0 * PH(0, 0, q) + PH(-1, -1, q) + PH(-1, 0, q)) / CON_G;
-    };
-#undef CAo
-    // interp_VAR_ds (dyn_functions.py:383-424) of an interface / level field to the u- and the v-point
-    auto ds_u = [&](const double *F, size_t q) {
-        return var_ds(F[q], F[q - 1], F[q - P], F[q + P], F[q - P - 1], F[q + P - 1], lo, hi);
-    };
-    auto ds_v = [&](const double *F, size_t q) {
-        return var_ds(F[q], F[q - P], F[q - 1], F[q + 1], F[q - P - 1], F[q - P + 1], false, false);
-    };
-    const double smom_is = ds_u(p.SMOMXFLX, c), smom_js = ds_v(p.SMOMYFLX, c);
+    const double smom_is = m6u(p.SMOMXFLX, c, wu), smom_js = m6v(p.SMOMYFLX, c, wv);
     const double surf_t = p.SSHFLX[c] / CON_CP, surf_q = g.i_moist ? p.SLHFLX[c] / CON_LH : 0.0;
 
     double kdu_k = 0.0, kdv_k = 0.0;                         // K dU/dz, K dV/dz at interface k (0 at the top)
     double u_k = p.UWIND[c], v_k = p.VWIND[c];
-    double altu_k = altu(c), altv_k = altv(c);
-    double avu_k = ds_u(p.PHIVB, c) / CON_G, avv_k = ds_v(p.PHIVB, c) / CON_G;   // ALTVB at the u- / v-point (g twice: dyn_UFLX.py:141)
-    double pott_km1 = 0.0, qv_km1 = 0.0, qc_km1 = 0.0, phi_km1 = 0.0;
+    double altu_k = m6u(p.PHI, c, wu), altv_k = m6v(p.PHI, c, wv);
+    double avu_k = m6u(p.PHIVB, c, wu) * RG, avv_k = m6v(p.PHIVB, c, wv) * RG;   // ALTVB at the u- / v-point (g twice: dyn_UFLX.py:141)
+    double pott_km1 = 0.0, qv_km1 = 0.0, qc_km1 = 0.0, alt_km1 = 0.0;
     for (int k = 0; k < nz; k++) {
         const size_t q = c + (size_t)k * pl, q1 = q + pl;
         const bool last = (k == nz - 1);
@@ -789,45 +798,35 @@ __global__ __launch_bounds__(TI *TJ) void k_turb_tendencies(Geo g, Ptrs p, int j
         double kdu_kp1 = 0.0, kdv_kp1 = 0.0, u_kp1 = 0.0, v_kp1 = 0.0, altu_kp1 = 0.0, altv_kp1 = 0.0;
         if (!last) {
             u_kp1 = p.UWIND[q1]; v_kp1 = p.VWIND[q1];
-            altu_kp1 = altu(q1); altv_kp1 = altv(q1);
+            altu_kp1 = m6u(p.PHI, q1, wu); altv_kp1 = m6v(p.PHI, q1, wv);
             kdu_kp1 = k6u(q1) * ((u_k - u_kp1) / (altu_k - altu_kp1));
             kdv_kp1 = k6v(q1) * ((v_k - v_kp1) / (altv_k - altv_kp1));
         }
-        const double avu_kp1 = ds_u(p.PHIVB, q1) / CON_G, avv_kp1 = ds_v(p.PHIVB, q1) / CON_G;
-        const double rho_is = ds_u(p.RHO, q), rho_js = ds_v(p.RHO, q);
-        double tu, tv;
-        if (k == 0) {
-            tu = (0.0 - kdu_kp1) / ((avu_k - avu_kp1) * rho_is);
-            tv = (0.0 - kdv_kp1) / ((avv_k - avv_kp1) * rho_js);
-        } else if (last) {
-            tu = (kdu_k + smom_is) / ((avu_k - avu_kp1) * rho_is);
-            tv = (kdv_k + smom_js) / ((avv_k - avv_kp1) * rho_js);
-        } else {
-            tu = (kdu_k - kdu_kp1) / ((avu_k - avu_kp1) * rho_is);
-            tv = (kdv_k - kdv_kp1) / ((avv_k - avv_kp1) * rho_js);
-        }
-        p.TURB_U[q] = tu;
-        if (v_on) p.TURB_V[q] = tv;
+        const double avu_kp1 = m6u(p.PHIVB, q1, wu) * RG, avv_kp1 = m6v(p.PHIVB, q1, wv) * RG;
+        const double rho_is = m6u(p.RHO, q, wu), rho_js = m6v(p.RHO, q, wv);
+        const double du = (k == 0 ? 0.0 : kdu_k) - (last ? -smom_is : kdu_kp1);
+        const double dv = (k == 0 ? 0.0 : kdv_k) - (last ? -smom_js : kdv_kp1);
+        p.TURB_U[q] = du / ((avu_k - avu_kp1) * rho_is);
+        if (v_on) p.TURB_V[q] = dv / ((avv_k - avv_kp1) * rho_js);
         kdu_k = kdu_kp1; kdv_k = kdv_kp1; u_k = u_kp1; v_k = v_kp1;
         altu_k = altu_kp1; altv_k = altv_kp1; avu_k = avu_kp1; avv_k = avv_kp1;
-        // ---- scalars ----
-        const double phi = p.PHI[q], phi_kp1 = last ? 0.0 : p.PHI[q1];
-        const double phivb = p.PHIVB[q], phivb_kp1 = p.PHIVB[q1];
-        const double kh = p.KHEAT[q], kh_kp1 = p.KHEAT[q1], rho = p.RHO[q], rvb = p.RHOVB[q], rvb_kp1 = p.RHOVB[q1];
+        // ---- scalars (dyn_functions.py:26-67): the three quotients that do not depend on the species once ----
+        const double alt = p.PHI[q] * RG, alt_kp1 = last ? 0.0 : p.PHI[q1] * RG;
+        const double thick = (p.PHIVB[q] * RG - p.PHIVB[q1] * RG) * p.RHO[q];
+        const double f_up = k == 0 ? 0.0 : p.RHOVB[q] * p.KHEAT[q] / (alt_km1 - alt);          // flux through interface k per unit difference
+        const double f_dn = last ? 0.0 : p.RHOVB[q1] * p.KHEAT[q1] / (alt - alt_kp1);          // ... through interface k+1
+        const double r_thick = colp / thick;
         const double pt = p.POTT[q], pt_kp1 = last ? 0.0 : p.POTT[q1];
-        p.TURB_T[q] = turb_flux(phi, phi_kp1, phi_km1, phivb, phivb_kp1, pt, pt_kp1, pott_km1, kh, kh_kp1, rho, rvb, rvb_kp1, colp, surf_t, k, nz);
+        p.TURB_T[q] = r_thick * ((pott_km1 - pt) * f_up - (pt - pt_kp1) * f_dn + (last ? surf_t : 0.0));
         pott_km1 = pt;
         if (g.i_moist) {
             const double qv = p.QV[q], qv_kp1 = last ? 0.0 : p.QV[q1], qc = p.QC[q], qc_kp1 = last ? 0.0 : p.QC[q1];
-            p.TURB_QV[q] = turb_flux(phi, phi_kp1, phi_km1, phivb, phivb_kp1, qv, qv_kp1, qv_km1, kh, kh_kp1, rho, rvb, rvb_kp1, colp, surf_q, k, nz);
-            p.TURB_QC[q] = turb_flux(phi, phi_kp1, phi_km1, phivb, phivb_kp1, qc, qc_kp1, qc_km1, kh, kh_kp1, rho, rvb, rvb_kp1, colp, 0.0, k, nz);
+            p.TURB_QV[q] = r_thick * ((qv_km1 - qv) * f_up - (qv - qv_kp1) * f_dn + (last ? surf_q : 0.0));
+            p.TURB_QC[q] = r_thick * ((qc_km1 - qc) * f_up - (qc - qc_kp1) * f_dn);
             qv_km1 = qv; qc_km1 = qc;
         }
-        phi_km1 = phi;
+        alt_km1 = alt;
     }
-#undef KT
-#undef KT2
-#undef PH
 }
 
 // ------------------------------------------------------------------------------------

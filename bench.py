@@ -176,6 +176,8 @@ def main():
         band_radiation(Radiation(GR), GR, L, rank, core)
     core.sync()
     bands = DistributedBands(core, L, rank, torch.device('cuda', local_rank)) if world > 1 else None
+    if bands is not None:
+        bands.connect()             # peer connections up before anything is timed, whatever --warmup says
 
     def run(nsteps):
         if bands is None:

@@ -312,6 +312,24 @@ class DistributedBands:
         if self.staged:
             b.recv[ph].copy_(recv)
 
+    def connect(self):
+        """One transport of the (still meaningless) send buffers into the receive buffers, nothing unpacked:
+        RCCL sets a peer connection up at the first send / recv between two ranks, which belongs in front of a
+        timed region, not inside it.  Every rank calls it."""
+        if self.south is None and self.north is None:
+            return
+        import torch
+        if self.overlap:
+            self.streams.comm.wait_stream(self.streams.main)
+            with torch.cuda.stream(self.streams.comm):
+                self._transport('A')
+            self.streams.main.wait_stream(self.streams.comm)
+        else:
+            self._transport('A')
+        if str(self.bufs.send['A'].device) != 'cpu':
+            self.core.sync()
+            torch.cuda.synchronize()
+
     def exchange(self, ph, sub=1):
         """pack, transport, unpack on the current stream."""
         if self.south is None and self.north is None:

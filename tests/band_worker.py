@@ -32,6 +32,7 @@ def main():
         core.upload(n, L.slice_rows(a, rank, FIELD_TABLE[n][1]))
     core.primary_diag()
     bands = DistributedBands(core, L, rank, torch.device('cuda', dev))
+    bands.connect()             # as bench.py does: must leave every field untouched
     bands.step_matsuno(GR.dt, 3)
     core.sync()
     out = {}

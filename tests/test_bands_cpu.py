@@ -61,6 +61,7 @@ def _exchange_worker(rank, world, port, nx, ny, nz, q):
                 a[:, nyl + 1:] = -1
         core = NumpyBandCore(nx, nyl, nz, local)
         bands = DistributedBands(core, L, rank, 'cpu')
+        bands.connect()             # peer connections first (bench.py): touches no field
         bands.exchange('A')
         bands.exchange('B')
         bad = []

@@ -9,10 +9,15 @@ over the whole synthetic grid; the metric is BASELINE.json's: cell-updates/s
 N > 1 (launched by torch.distributed.run, one rank per GPU) cuts the SAME grid into N
 latitude bands with RCCL neighbour send/recv between them: strong scaling.
 
+`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment starts the N ranks itself:
+before anything touches the GPU it runs `python -m torch.distributed.run --nproc-per-node N bench.py ...`
+as a child process, relays the child's JSON line and exits with its return code.
+
 Rank 0 prints one JSON line (contract in the task statement) with two extra objects:
-  roofline     : dominant kernel's algorithmic bytes per launch / its mean HIP-event duration
-                 in the timed region, against the 8 TB/s HBM3E peak; `step_*` keys give the
-                 same for the whole step (130 field passes x 8 B per cell-update)
+  roofline     : dominant kernel's compulsory bytes per launch / its mean HIP-event duration
+                 in the timed region, against the 8 TB/s HBM3E peak; `kernels` gives the same for
+                 every priced kernel of the step, `step_*` for the whole step: the compulsory bytes
+                 of the kernels the step actually launches (KERNEL_PASSES x launches) / step time
   cpu_baseline : the CPU restatement (oracle/, "port") timed on this box's host cores on a
                  bounded sample of the same workload (N = 1, rank 0 only)
 """
@@ -30,7 +35,7 @@ os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
 import numpy as np
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-PASSES_PER_STEP = 130          # compulsory 3-D field passes per Matsuno step
+PASSES_PER_STEP = 130          # 3-D field passes of the reference's stage graph per Matsuno step
 # Compulsory 3-D field passes per launch of each kernel = distinct 3-D inputs read once +
 # outputs written once (2-D/1-D fields and halos neglected, <2 %).
 # Stage kernels: the stage table of SURVEY.md 8(d).  Fused kernels move fewer bytes than the
@@ -44,7 +49,26 @@ KERNEL_PASSES = {
     'k_momentum_fused': 10.0,    # its register-staged fallback (nz > 160): same fields
     'k_pott_fused': 10.5,        # R POTT,UWIND,VWIND,WWIND,POTTVB (+1 old) W POTT,PVTF,PVTFVB,PHI,POTTVB
     'k_moist': 8.0,              # R QV,QC,UWIND,VWIND,WWIND (+2 old) W QV,QC
+    'k_turb_tendencies': 16.0,   # R UWIND,VWIND,PHI,PHIVB,RHO,RHOVB,KMOM,KHEAT,POTT(,QV,QC) W TURB_U,V,T(,QV,QC)
 }
+
+
+def self_launch(args):
+    """--gpus N > 1 without a launcher: start the ranks as a CHILD process (this process has not
+    touched the GPU and never will), pass the JSON line through, return the child's exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(('127.0.0.1', 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus),
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault('OMP_NUM_THREADS', '1')
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    sys.stdout.write(proc.stdout)
+    sys.stdout.flush()
+    return proc.returncode
 
 
 def parse():
@@ -122,6 +146,8 @@ def main():
     rank = int(os.environ.get('RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        raise SystemExit(self_launch(args))
     if world != args.gpus:
         raise SystemExit('--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d'
                          % (args.gpus, world, args.gpus))
@@ -207,7 +233,9 @@ def main():
     nbreak = max(1, min(args.steps, 5))
     run(nbreak)
     fence()
-    breakdown = {k: tot / nbreak for k, (n, tot) in core.kernel_stats().items() if n}
+    bstats = core.kernel_stats()
+    breakdown = {k: tot / nbreak for k, (n, tot) in bstats.items() if n}
+    launches_per_step = {k: n / nbreak for k, (n, tot) in bstats.items() if n}
     core.profile(0)
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device='cuda' if backend == 'nccl' else 'cpu')
@@ -255,22 +283,38 @@ def main():
             dom_n = 2 * args.steps
         avg_s = dom_ms / dom_n / 1e3
         ach = per_launch_bytes / avg_s / 1e9
-        step_ach = PASSES_PER_STEP * 8 * value / 1e9 / world      # per GPU
-        traffic = None
+        # whole step: the compulsory bytes of the kernels it actually launched (this rank's band), from the
+        # per-launch breakdown pass above
+        kern, step_bytes = {}, 0.0
+        for k, ms in breakdown.items():
+            if k not in KERNEL_PASSES:
+                continue
+            nl_ = launches_per_step[k]
+            gb = KERNEL_PASSES[k] * band_cells * 8 / 1e9
+            if world > 1 and k in ('k_momentum_dma',):
+                nl_ = nl_ / 2.0         # inner + edge launch = one pass over the band
+            step_bytes += gb * nl_
+            kern[k] = {'ms_per_step': ms, 'launches_per_step': launches_per_step[k], 'compulsory_GB_per_pass': gb,
+                       'achieved_GBs': gb * nl_ / (ms * 1e-3), 'frac': gb * nl_ / (ms * 1e-3) / HBM_PEAK_GBS}
+        step_ach = step_bytes / (ms_per_step * 1e-3)
+        traffic, traffic_src = None, None
         tfile = os.path.join(ROOT, 'profiles', 'traffic_latest.json')
         if os.path.exists(tfile) and world == 1:
             try:
                 tj = json.load(open(tfile))
                 if tj.get('kernel') == dom and tj.get('grid') == [GR.nx, GR.ny, GR.nz]:
                     traffic = tj.get('bytes_per_launch')
+                    traffic_src = 'stored PMC profile, not measured in this run: %s' % tj.get('source', 'profiles/traffic_latest.json')
             except Exception:
                 traffic = None
         roof = {'bound': 'hbm', 'kernel': dom, 'achieved': ach, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                'frac': ach / HBM_PEAK_GBS, 'traffic': traffic,
+                'frac': ach / HBM_PEAK_GBS, 'traffic': traffic, 'traffic_source': traffic_src,
                 'algorithmic_bytes_per_launch': per_launch_bytes, 'avg_launch_ms': dom_ms / dom_n,
                 'launches': dom_n,
-                'step_achieved': step_ach, 'step_frac': step_ach / HBM_PEAK_GBS,
+                'step_compulsory_GB': step_bytes, 'step_achieved': step_ach, 'step_frac': step_ach / HBM_PEAK_GBS,
+                'step_survey_130pass_GBs': PASSES_PER_STEP * 8 * value / 1e9 / world,
                 'measured_copy_GBs': copy_gbs,
+                'kernels': kern,
                 'kernels_ms_per_step': breakdown}
 
     line = {

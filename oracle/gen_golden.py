@@ -62,6 +62,11 @@ CASES = {
     # radiation columns (rad_main.Radiation.simple_radiation) on the model state after two steps
     'g10x4_rad':  dict(d=10, nz=4, steps=2,  snaps=(),         stages=False, turb=False, radiation=(2001, 3, 21, 9, 30, 0)),
     'g4x8_rad':   dict(d=4,  nz=8, steps=2,  snaps=(),         stages=False, turb=False, radiation=(1999, 12, 30, 22, 15, 40)),
+    # the reference's "testsuite equality" preset (namelist.py:246-261): 5 deg, +-80 deg, 8 levels, 0.72 days,
+    # history every 8 h; turbulence + radiation + moisture on, surface scheme / microphysics off (their
+    # products SOILTEMP, albedos, surface fluxes, QC sources are fixed inputs).  Runs the loop of solver.py:82-226
+    # up to the second history file (out0002 = the file testsuite.py compares).
+    'g5x8_preset': dict(preset=True, d=5, nz=8, lat0=-80, lat1=80, sim_n_days=0.72, out_nth_hour=8),
 }
 
 NUMBA_SHIM = r'''
@@ -137,18 +142,18 @@ i_comp_mode = 1
 i_load_from_restart = 0
 i_save_to_restart = 0
 i_load_from_IC = 0
-i_radiation = 0
+i_radiation = %(radiation)d
 i_microphysics = 0
 i_turbulence = %(turbulence)d
-i_surface_scheme = 0
+i_surface_scheme = %(radiation)d      # io_read_namelist.py:91-92 insists on it with radiation; the preset case detaches it again
 working_precision = %(wp)r
 nz = %(nz)d
-lat0_deg = -90
-lat1_deg = 90
+lat0_deg = %(lat0)r
+lat1_deg = %(lat1)r
 dlat_deg = %(d)r
 dlon_deg = %(d)r
-i_sim_n_days = 1
-i_out_nth_hour = 1
+i_sim_n_days = %(sim_n_days)r
+i_out_nth_hour = %(out_nth_hour)r
 # ---- namelist.py:286-316 table rule, re-applied for the overridden dlat ----
 UVFLX_dif_coef = 0
 POTT_dif_coef = 1E-5
@@ -163,7 +168,7 @@ UVFLX_dif_coef *= 2.0
 '''
 
 
-def _install_shims(tmp, d, nz, wp, turbulence=0):
+def _install_shims(tmp, d, nz, wp, turbulence=0, radiation=0, lat0=-90, lat1=90, sim_n_days=1, out_nth_hour=1):
     os.makedirs(os.path.join(tmp, 'numba'))
     with open(os.path.join(tmp, 'numba', '__init__.py'), 'w') as f:
         f.write(NUMBA_SHIM)
@@ -176,7 +181,8 @@ def _install_shims(tmp, d, nz, wp, turbulence=0):
                    'rad_calc_LW_RTE_matrix_c'):
             f.write('def %s(*a, **k):\n    raise NotImplementedError\n' % fn)
     with open(os.path.join(tmp, 'namelist.py'), 'w') as f:
-        f.write(NAMELIST_SHIM % dict(ref=REF, d=d, nz=nz, wp=wp, turbulence=int(turbulence)))
+        f.write(NAMELIST_SHIM % dict(ref=REF, d=d, nz=nz, wp=wp, turbulence=int(turbulence), radiation=int(radiation),
+                                     lat0=lat0, lat1=lat1, sim_n_days=sim_n_days, out_nth_hour=out_nth_hour))
 
     # scipy.interpolate.interp2d (removed in SciPy >= 1.14): bilinear, nearest outside.
     import scipy.interpolate as si
@@ -208,8 +214,102 @@ GRID_CONSTS = ['corf', 'corf_is', 'A', 'sigma_vb', 'dsigma', 'dxjs', 'dyis',
 PROGNOSTIC = ['COLP', 'UWIND', 'VWIND', 'POTT', 'QV', 'QC']
 
 
+def run_preset_case(name):
+    """solver.py:82-226 on the reference's preset-1 grid with its own Grid / ModelFields / Turbulence /
+    Radiation objects; snapshots at the history steps."""
+    cfg = CASES[name]
+    sys.dont_write_bytecode = True
+    tmp = tempfile.mkdtemp(prefix='golden_shims_')
+    _install_shims(tmp, cfg['d'], cfg['nz'], 'float64', turbulence=1, radiation=1, lat0=cfg['lat0'], lat1=cfg['lat1'],
+                   sim_n_days=cfg['sim_n_days'], out_nth_hour=cfg['out_nth_hour'])
+    sys.path.insert(0, REF)
+    sys.path.insert(0, tmp)
+    os.chdir(REF)
+    from datetime import timedelta
+    from io_read_namelist import CPU
+    from main_grid import Grid
+    import main_fields
+    import dyn_matsuno
+    import rad_longwave
+    import rad_main
+    from dyn_org_discretizations import DiagnosticsFactory
+    from namelist import pair_top
+    rad_longwave.run_cython = 0
+    # ModelFields.__init__ runs a first radiation call (main_fields.py:94-101) on the surface scheme's
+    # SOILTEMP; with the surface scheme off that field is NaN, so the radiation object is attached below
+    # (same order: after Turbulence / Microphysics, before the loop) once its inputs are set
+    main_fields.i_radiation = 0
+    main_fields.i_surface_scheme = 0            # no Surface object: SOILTEMP, albedos and the surface fluxes are fixed inputs
+    GR = Grid()
+    F = main_fields.ModelFields(GR, False)
+    Diagnostics = DiagnosticsFactory(target=CPU)
+    h = F.host
+    for n in ['SSHFLX', 'SLHFLX', 'SMOMXFLX', 'SMOMYFLX', 'dPOTTdt_RAD']:
+        h[n][:] = 0.
+    # surface inputs: the surface scheme's initial state (srfc_main.py:44-72), held fixed
+    lat = GR.lat_rad[:, :, 0]
+    h['SOILTEMP'][:, :, 0] = 295 - np.sin(lat) ** 2 * 30 - h['HSURF'][:, :, 0] * 0.01
+    h['SURFALBEDLW'][:] = 0.
+    h['SURFALBEDSW'][:, :, 0] = np.where(h['HSURF'][:, :, 0] <= 100, 0.05, 0.2)
+    h['SURFALBEDSW'][:, :, 0][h['SOILTEMP'][:, :, 0] <= 273.15] = 0.6
+    out = {}
+    out['meta/nx'], out['meta/ny'], out['meta/nz'] = np.int64(GR.nx), np.int64(GR.ny), np.int64(GR.nz)
+    out['meta/dt'] = np.int64(GR.dt)
+    out['meta/pair_top'] = np.float64(pair_top)
+    out['meta/dlat_deg'] = np.float64(cfg['d'])
+    out['meta/lat0_deg'], out['meta/lat1_deg'] = np.float64(cfg['lat0']), np.float64(cfg['lat1'])
+    out['meta/i_out_nth_ts'] = np.int64(GR.i_out_nth_ts)
+    out['meta/nts'] = np.float64(GR.nts)
+    for n in GRID_CONSTS:
+        out['grid/' + n] = np.array(GR.GRF[CPU][n])
+    for n in PROGNOSTIC + ['HSURF', 'WWIND', 'POTTVB', 'SSHFLX', 'SLHFLX', 'SMOMXFLX', 'SMOMYFLX',
+                           'SOILTEMP', 'SURFALBEDLW', 'SURFALBEDSW']:
+        out['ic/' + n] = h[n].copy()
+    RAD = rad_main.Radiation(GR)
+    F.RAD = RAD
+    RAD.calc_radiation(GR, F)                   # main_fields.py:101
+    out['meta/rad_nth_ts'] = np.int64(RAD.rad_nth_ts)
+    out['ic_rad/dPOTTdt_RAD'] = h['dPOTTdt_RAD'].copy()
+    Diagnostics.primary_diag(GR.GRF[CPU], **F.get(Diagnostics.fields_primary_diag, target=CPU))    # solver.py:70-73
+    SNAP = ['UWIND', 'VWIND', 'WWIND', 'COLP', 'PHI', 'POTT', 'QV', 'QC', 'SWFLXNET', 'LWFLXNET', 'dPOTTdt_RAD',
+            'KMOM', 'KHEAT', 'dVFLXdt_TURB', 'TAIR', 'RHO', 'WIND']
+    n_out = 2
+    last = n_out * GR.i_out_nth_ts
+    track = np.zeros((last, 3))
+    import time as _time
+    t0 = _time.time()
+    while GR.ts < last:
+        GR.ts += 1                              # solver.py:86-90
+        GR.sim_time_sec = GR.ts * GR.dt
+        GR.GMT += timedelta(seconds=GR.dt)
+        Diagnostics.secondary_diag(**F.get(Diagnostics.fields_secondary_diag, target=CPU))
+        F.TURB.compute_turbulence(GR, **F.get(F.TURB.fields_main, target=CPU))
+        RAD.launch_radiation_calc(GR, F)
+        dyn_matsuno.step_matsuno(GR, F)
+        umax = np.nanmax(np.abs(h['UWIND'][1:-1, 1:-1, :]))
+        track[GR.ts - 1] = (umax, np.nanmean(h['COLP'][1:-1, 1:-1, 0]), np.nanmean(h['POTT'][1:-1, 1:-1, :]))
+        if GR.ts % 10 == 0 or GR.ts == 1:
+            print('[%s] step %d / %d  max|U| = %.6f  mean COLP = %.3f  (%.0f s)' % (
+                name, GR.ts, last, umax, track[GR.ts - 1, 1], _time.time() - t0), flush=True)
+        if not np.isfinite(umax):
+            raise RuntimeError('reference run produced non-finite UWIND')
+        if GR.ts % GR.i_out_nth_ts == 0:        # solver.py:152-164
+            tag = 'out%04d' % (GR.ts // GR.i_out_nth_ts)
+            Diagnostics.secondary_diag(**F.get(Diagnostics.fields_secondary_diag, target=CPU)) if False else None
+            for n in SNAP:
+                out['%s/%s' % (tag, n)] = h[n].copy()
+            out['%s/ts' % tag] = np.int64(GR.ts)
+    out['track/umax_colp_pott'] = track
+    os.makedirs(GOLDEN, exist_ok=True)
+    path = os.path.join(GOLDEN, name + '.npz')
+    np.savez_compressed(path, **out)
+    print('wrote', path, os.path.getsize(path), 'bytes')
+
+
 def run_case(name):
     cfg = CASES[name]
+    if cfg.get('preset'):
+        return run_preset_case(name)
     sys.dont_write_bytecode = True
     tmp = tempfile.mkdtemp(prefix='golden_shims_')
     _install_shims(tmp, cfg['d'], cfg['nz'], 'float64', cfg.get('turbulence', False))

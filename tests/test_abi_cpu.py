@@ -120,3 +120,31 @@ def test_plain_c_client_atmosphere_at_rest(tmp_path):
     exe = _build_c_client(tmp_path)
     r = subprocess.run([exe, LIB], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and 'C_CLIENT_OK' in r.stdout, r.stdout + r.stderr
+
+
+def test_bench_self_launch_command_and_no_gpu_touch(monkeypatch):
+    """`python bench.py --gpus N` without a launcher: the parent builds the torch.distributed.run command
+    for N ranks on 127.0.0.1, runs it as a child, relays stdout and returns its exit code -- and importing
+    bench.py (all the parent does before that) loads neither torch nor the HIP library."""
+    import subprocess
+    import types
+    r = subprocess.run([sys.executable, '-c',
+                        'import sys; sys.argv=["bench.py"]; import bench; '
+                        'print("torch" in sys.modules, any("dycore_hip" in (getattr(m, "__file__", "") or "") for m in sys.modules.values()))'],
+                       cwd=ROOT, capture_output=True, text=True)
+    assert r.returncode == 0 and r.stdout.split() == ['False', 'False'], r.stdout + r.stderr
+    sys.path.insert(0, ROOT)
+    import bench
+    seen = {}
+
+    def fake_run(cmd, env=None, stdout=None, text=None):
+        seen['cmd'], seen['env'] = cmd, env
+        return types.SimpleNamespace(returncode=7, stdout='{"metric": "x"}\n')
+    monkeypatch.setattr(subprocess, 'run', fake_run)
+    monkeypatch.setattr(sys, 'argv', ['bench.py', '--gpus', '4', '--steps', '2'])
+    rc = bench.self_launch(types.SimpleNamespace(gpus=4))
+    assert rc == 7
+    cmd = seen['cmd']
+    assert cmd[1:3] == ['-m', 'torch.distributed.run'] and '--nproc-per-node' in cmd and cmd[cmd.index('--nproc-per-node') + 1] == '4'
+    assert cmd[cmd.index('--master-addr') + 1] == '127.0.0.1'
+    assert cmd[-4:] == ['--gpus', '4', '--steps', '2'] and cmd[-5].endswith('bench.py')

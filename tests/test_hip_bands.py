@@ -104,20 +104,34 @@ def test_multi_process_gloo_bands_equal_single(tmp_path, nproc):
 
 
 def test_bench_two_ranks_rehearsal():
-    """bench.py's N > 1 path (band set-up, exchange, barrier, max-over-ranks, JSON line) with two
-    ranks on the one GPU and gloo instead of RCCL, on a small grid."""
+    """The bare command the round driver runs, `python bench.py --gpus 2 ...` with no launcher and no
+    WORLD_SIZE: bench.py starts torch.distributed.run as a child before it touches the GPU, relays the
+    JSON line and returns the child's exit code.  Two ranks on the one GPU, gloo instead of RCCL, small grid."""
     import json
-    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0', DYCORE_BANDS_BACKEND='gloo', DYCORE_BANDS_ONE_GPU='1')
-    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
-           '--master-addr', '127.0.0.1', '--master-port', str(port),
-           os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1', '--dlat', '2', '--nz', '16']
+    for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1', '--dlat', '2', '--nz', '16']
     r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
-    line = [l for l in r.stdout.splitlines() if l.startswith('{')][-1]
-    j = json.loads(line)
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, r.stdout[-3000:]
+    j = json.loads(lines[0])
     assert j['n_gpus'] == 2 and j['steps'] == 3 and j['value'] > 0 and j['scaling'] == 'strong'
-    assert j['roofline'] and j['roofline']['frac'] > 0
+    assert j['config']['parallelism'] == 'latitude bands x2'
+    roof = j['roofline']
+    assert roof and 0 < roof['frac'] <= 1 and 0 < roof['step_frac'] <= 1
+    assert all(0 < k['frac'] <= 1 for k in roof['kernels'].values())
+
+
+def test_bench_self_launch_propagates_failure():
+    """A failing child (here: more bands than the grid has row pairs) must fail the bare command too."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0', DYCORE_BANDS_BACKEND='gloo', DYCORE_BANDS_ONE_GPU='1')
+    for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '0', '--dlat', '90', '--nz', '4']
+    r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0
 
 
 def test_rccl_transport_self_exchange():

@@ -4,6 +4,7 @@ import inspect
 import os
 import re
 import subprocess
+import sys
 
 import numpy as np
 import pytest

@@ -30,6 +30,7 @@ struct Geo {
     int ny_global, joff;   // global row = local row + joff
     int pole_s, pole_n;    // this band touches the south / north wall
     int i_turb, i_rad, i_moist;
+    int i_moist_clip;      // QV, QC < 0 -> 0 after the Euler step (dyn_timestep.py:145-154, the reference's accelerator path)
     double pair_top;
 };
 

@@ -806,6 +806,7 @@ int dycore_create(const DycoreConfig *cfg, dycore_t **out)
     g.pole_s = (cfg->j_offset == 0);
     g.pole_n = (cfg->j_offset + cfg->ny == cfg->ny_global);
     g.i_turb = cfg->i_turb != 0; g.i_rad = cfg->i_radiation != 0; g.i_moist = cfg->i_moist != 0;
+    g.i_moist_clip = cfg->i_moist_clip != 0;
     g.pair_top = cfg->pair_top;
     memset(&h->p, 0, sizeof h->p);
     if (const char *e = getenv("DYCORE_FUSED")) h->fused = atoi(e) != 0;
@@ -987,6 +988,13 @@ static int find_field(dycore_t *h, const char *name, const FieldDesc **d)
     if (!(h->p.*((*d)->member)))
         return fail(DYCORE_ESTATE, "field '%s' exists only on handles created with %s", name, (*d)->rad == 2 ? "i_turb" : "i_radiation");
     return 0;
+}
+
+int dycore_has_field(dycore_t *h, const char *name)
+{
+    if (!h || !name) return 0;
+    auto it = h->field_idx.find(name);
+    return it != h->field_idx.end() && (h->p.*(kFields[it->second].member)) != nullptr;
 }
 
 int dycore_field_shape(dycore_t *h, const char *name, int32_t shape[3])

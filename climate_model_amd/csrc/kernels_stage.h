@@ -633,8 +633,14 @@ __global__ __launch_bounds__(TI *TJ) void k_moist(Geo g, Ptrs p, const double *q
             tq[s] = d;
         }
         if (EULER) {
-            qv_out[q] = cur.vo * colp_old * r_cn + dt * tq[0] * r_cn;
-            qc_out[q] = cur.co * colp_old * r_cn + dt * tq[1] * r_cn;
+            double nv = cur.vo * colp_old * r_cn + dt * tq[0] * r_cn;
+            double nc = cur.co * colp_old * r_cn + dt * tq[1] * r_cn;
+            if (g.i_moist_clip) {       // dyn_timestep.py:145-154: `if QV < 0: QV = 0` (a NaN stays a NaN)
+                if (nv < 0.0) nv = 0.0;
+                if (nc < 0.0) nc = 0.0;
+            }
+            qv_out[q] = nv;
+            qc_out[q] = nc;
         } else {
             p.dQVdt[q] = tq[0];
             p.dQCdt[q] = tq[1];
@@ -695,9 +701,15 @@ __global__ __launch_bounds__(TI *TJ) void k_euler_forward(Geo g, Ptrs p, double 
         if (row_c) {
             p.UWIND[at(g, i, j, k)] = p.UWIND_OLD[q] * cao_is / ca_is + dt * p.dUFLXdt[q] / ca_is;
             p.POTT[at(g, i, j, k)] = p.POTT_OLD[q] * co / cn + dt * p.dPOTTdt[q] / cn;
-            if (g.i_moist) {   // no clipping of QV/QC on the reference's CPU path (dyn_timestep.py:291-296)
-                p.QV[q] = p.QV_OLD[q] * co / cn + dt * p.dQVdt[q] / cn;
-                p.QC[q] = p.QC_OLD[q] * co / cn + dt * p.dQCdt[q] / cn;
+            if (g.i_moist) {   // the reference's CPU kernel does not clip (dyn_timestep.py:291-296), its accelerator kernel does (:145-154)
+                double nv = p.QV_OLD[q] * co / cn + dt * p.dQVdt[q] / cn;
+                double nc = p.QC_OLD[q] * co / cn + dt * p.dQCdt[q] / cn;
+                if (g.i_moist_clip) {
+                    if (nv < 0.0) nv = 0.0;
+                    if (nc < 0.0) nc = 0.0;
+                }
+                p.QV[q] = nv;
+                p.QC[q] = nc;
             }
         }
         if (v_own) {

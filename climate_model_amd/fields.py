@@ -204,6 +204,11 @@ class ModelFields:
     def attach(self, core):
         self.core = core
         self.device = {name: DeviceField(name, core) for name in FIELD_TABLE}
+        # main_fields.py:150-182: ALL_FIELDS = every field -- of those this handle holds (the radiation fields
+        # exist only with i_radiation, the TURB_* scratch fields only with i_turb)
+        has = getattr(core, 'has_field', None)
+        if has is not None:
+            self.field_groups[self.ALL_FIELDS] = [n for n in FIELD_TABLE if has(n)]
         for name in PASS_THROUGH_FIELDS:
             self.device[name] = None
 

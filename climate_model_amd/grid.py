@@ -113,10 +113,19 @@ class Grid:
             self.dt = int(nl.CFL * mindx / 400)
             if self.dt < 1:
                 # the reference's rule gives 0 below ~1 deg with the poles included (its own
-                # `while 3600 % dt` loop would divide by zero); use half the CFL bound instead
+                # `while ... % dt` loop would divide by zero); use half the CFL bound instead
                 self.dt = 0.5 * nl.CFL * mindx / 400
+            else:
+                while nl.i_out_nth_hour * 3600 % self.dt > 0:        # main_grid.py:262-263
+                    self.dt -= 1
         else:
             self.dt = nl.dt
+        # main_grid.py:264-270
+        self.i_sim_n_days, self.i_out_nth_hour, self.i_restart_nth_day = nl.i_sim_n_days, nl.i_out_nth_hour, nl.i_restart_nth_day
+        self.nts = nl.i_sim_n_days * 3600 * 24 / self.dt
+        self.i_out_nth_ts = int(nl.i_out_nth_hour * 3600 / self.dt)
+        self.i_restart_nth_ts = int(nl.i_restart_nth_day * 24 / nl.i_out_nth_hour * self.i_out_nth_ts)
+        self.nc_output_count = 0
         self.ts = 0
         self.GMT = nl.GMT_initialization        # main_grid.py:273; advanced by the solver loop
         self.timer = Timer()

@@ -20,15 +20,15 @@ class DycoreError(RuntimeError):
 class DycoreConfig(C.Structure):
     _fields_ = [('abi_version', C.c_int32), ('nx', C.c_int32), ('ny', C.c_int32), ('nz', C.c_int32),
                 ('ny_global', C.c_int32), ('j_offset', C.c_int32), ('device', C.c_int32),
-                ('i_turb', C.c_int32), ('i_radiation', C.c_int32), ('i_moist', C.c_int32),
-                ('reserved', C.c_int32 * 6),
+                ('i_turb', C.c_int32), ('i_radiation', C.c_int32), ('i_moist', C.c_int32), ('i_moist_clip', C.c_int32),
+                ('reserved', C.c_int32 * 5),
                 ('pair_top', C.c_double), ('stream', C.c_void_p)]
 
 
 # every symbol include/dycore.h declares (tests check the library exports all of them)
 ABI_SYMBOLS = [
     'dycore_create', 'dycore_destroy', 'dycore_last_error', 'dycore_abi_version', 'dycore_sync',
-    'dycore_set_grid', 'dycore_field_shape', 'dycore_upload', 'dycore_download', 'dycore_field_ptr',
+    'dycore_set_grid', 'dycore_has_field', 'dycore_field_shape', 'dycore_upload', 'dycore_download', 'dycore_field_ptr',
     'dycore_copy_field', 'dycore_exchange_bc',
     'dycore_continuity', 'dycore_momentum', 'dycore_momentum_prepare', 'dycore_uflx_tendency',
     'dycore_vflx_tendency', 'dycore_pott_tendency', 'dycore_moist_tendency', 'dycore_euler_forward',
@@ -41,6 +41,36 @@ ABI_SYMBOLS = [
 ]
 
 _lib = None
+_runtime_preloaded = None
+
+
+def _one_hip_runtime():
+    """One HIP / HSA runtime per process, brought up in the order PyTorch-ROCm needs.
+    libdycore_hip.so asks for `libamdhip64.so.7` (/opt/rocm/lib); a PyTorch-ROCm wheel ships its own copy and
+    asks for it as `libamdhip64.so` (same for libhsa-runtime64).  The loader matches an already loaded library
+    by SONAME or by file, so: torch first -> this library binds to torch's copy, one runtime; this library first
+    -> a later `import torch` maps its own copy NEXT TO the system one, two HSA runtimes share the process and
+    torch.cuda comes up with "No HIP GPUs are available" -- the failure that used to depend on which test module
+    pytest happened to import first (tools/probe_runtime_order.py shows both cases).  Loading torch's copy by
+    hand before this library is no way out either: torch's libraries then register their code objects with an
+    already initialised runtime, which loads them eagerly (minutes).  So when torch is installed it is imported
+    before libdycore_hip.so is mapped; a host without torch (plain C: examples/c_client.c) runs on the system
+    runtime.  DYCORE_NO_TORCH_PRELOAD=1 switches this off (probe only)."""
+    global _runtime_preloaded
+    if _runtime_preloaded is not None or os.environ.get('DYCORE_NO_TORCH_PRELOAD'):
+        return
+    _runtime_preloaded = False
+    import sys
+    if 'torch' in sys.modules:
+        return
+    try:
+        import importlib.util
+        if importlib.util.find_spec('torch') is None:
+            return
+        import torch  # noqa: F401  (its bundled HIP runtime becomes the process's one)
+        _runtime_preloaded = True
+    except Exception:
+        pass
 
 
 def load_library(path=None):
@@ -52,6 +82,7 @@ def load_library(path=None):
     if not os.path.exists(path):
         raise DycoreError('HIP extension not built: %s is missing (run __graft_entry__.build() '
                           'or `make -C climate_model_amd/csrc`); there is no CPU fallback' % path)
+    _one_hip_runtime()
     lib = C.CDLL(path)
     hp = C.c_void_p
     dp = C.POINTER(C.c_double)
@@ -61,6 +92,7 @@ def load_library(path=None):
     lib.dycore_sync.argtypes = [hp]
     lib.dycore_set_grid.argtypes = [hp, C.c_char_p, dp, C.c_int32, C.c_int32, C.c_int32]
     lib.dycore_field_shape.argtypes = [hp, C.c_char_p, C.POINTER(C.c_int32 * 3)]
+    lib.dycore_has_field.argtypes = [hp, C.c_char_p]
     lib.dycore_upload.argtypes = [hp, C.c_char_p, dp]
     lib.dycore_download.argtypes = [hp, C.c_char_p, dp]
     lib.dycore_field_ptr.argtypes = [hp, C.c_char_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int64),
@@ -106,7 +138,7 @@ class HipDycore:
     """One dycore handle = one GPU (or one latitude band of a decomposed grid)."""
 
     def __init__(self, nx, ny, nz, pair_top=10000., i_turb=0, i_radiation=0, device=0,
-                 ny_global=None, j_offset=0, stream=None, i_moist=0):
+                 ny_global=None, j_offset=0, stream=None, i_moist=0, i_moist_clip=0):
         self.lib = load_library()
         self.nx, self.ny, self.nz = int(nx), int(ny), int(nz)
         cfg = DycoreConfig()
@@ -118,12 +150,14 @@ class HipDycore:
         cfg.i_turb = int(bool(i_turb))
         cfg.i_radiation = int(bool(i_radiation))
         cfg.i_moist = int(bool(i_moist))
+        cfg.i_moist_clip = int(bool(i_moist_clip))
         cfg.pair_top = float(pair_top)
         cfg.stream = C.c_void_p(stream) if stream else None
         self._h = C.c_void_p()
         self._check(self.lib.dycore_create(C.byref(cfg), C.byref(self._h)))
         self.i_turb = bool(i_turb)
         self.i_moist = bool(i_moist)
+        self.i_radiation = bool(i_radiation)
 
     # ---- plumbing ----
     def _check(self, rc):
@@ -152,6 +186,10 @@ class HipDycore:
             shp = a.shape if a.ndim == 3 else (a.size, 1, 1)
             self._check(self.lib.dycore_set_grid(self._h, name.encode(), a.ctypes.data_as(C.POINTER(C.c_double)),
                                                  shp[0], shp[1], shp[2]))
+
+    def has_field(self, name):
+        """False for the radiation / TURB_* fields of a handle created without that switch."""
+        return bool(self.lib.dycore_has_field(self._h, name.encode()))
 
     def field_shape(self, name):
         s = (C.c_int32 * 3)()

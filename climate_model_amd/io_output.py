@@ -177,6 +177,8 @@ def load_restart(GR, F, path):
     z = np.load(path, allow_pickle=False)
     if not np.array_equal(z['sigma_vb'], GR.sigma_vb.reshape(-1)):
         raise ValueError('restart file was written for other sigma levels')
+    if 'dt' in z.files and float(z['dt']) != float(GR.dt):
+        raise ValueError('restart file was written with dt = %r s, this grid steps with %r s' % (float(z['dt']), float(GR.dt)))
     GR.ts = int(z['ts'])
     GR.GMT = datetime.fromisoformat(str(z['gmt']))
     GR.nc_output_count = int(z['nc_output_count'])

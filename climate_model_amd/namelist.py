@@ -42,6 +42,9 @@ class Namelist:
     i_POTT_vert_turb: int = 0
     i_POTT_radiation: int = 0
     i_moist_main_switch: int = 0        # dyn_moist: QV/QC advection (namelist.py:80)
+    # QV, QC < 0 -> 0 after every Euler step: what the reference's accelerator kernel does (dyn_timestep.py:145-154,
+    # its default i_comp_mode = 2); 0 = its CPU kernel (:291-296), the path the parity fixtures come from
+    i_moist_clip: int = 0
     i_radiation: int = 0                # radiation scheme (namelist.py:104); implies i_POTT_radiation
     rad_nth_hour: float = 3.9           # namelist.py:117
     GMT_initialization: datetime = field(default_factory=lambda: datetime(2019, 1, 1, 0, 0, 0))   # namelist.py:21
@@ -51,7 +54,13 @@ class Namelist:
     moist_dif_coef: float = None        # None = POTT_dif_coef (namelist.py:284)
     # time stepping (namelist.py:219-221)
     CFL: float = 0.7
-    dt: float = None            # None = reference rule int(CFL*min(dx)/400)
+    dt: float = None            # None = reference rule int(CFL*min(dx)/400), lowered until it divides the output interval
+    # run length and output / restart intervals (namelist.py:147, 243-278; values of the shipped preset 2).
+    # i_out_nth_hour also enters the time-step rule (main_grid.py:262-263).
+    i_sim_n_days: float = 365.0
+    i_out_nth_hour: float = 12.0
+    i_restart_nth_day: float = 1.0
+    nth_ts_print_diag: int = 50         # namelist.py:145
     working_precision: str = 'float64'
 
     def __post_init__(self):

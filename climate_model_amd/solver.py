@@ -1,8 +1,8 @@
 """Time loop around the dycore step, the way the reference's `solver.py:82-226` runs it.
 
-Per time step: status line every `nth_ts_print_diag` steps (io_functions.py:93-134, with the
-"MODEL CRASH" test), secondary diagnostics, turbulence and radiation if switched on, then the
-Matsuno step.  Microphysics, the surface scheme and NetCDF output of the reference's loop are
+Per time step, in the reference's order: status line every `nth_ts_print_diag` steps
+(io_functions.py:93-134, with the "MODEL CRASH" test), secondary diagnostics, turbulence and
+radiation if switched on, then the Matsuno step.  Microphysics, the surface scheme and NetCDF output of the reference's loop are
 outside the hot path (out of scope) and have no slot here; the fields they would
 produce (QC, SOILTEMP, surface albedos) are inputs.
 
@@ -59,15 +59,25 @@ def print_ts_info(GR, F, nth_ts_print_diag=50, out=print):
     return vmax, mean_wind, mean_temp, mean_colp
 
 
-def run(GR, F, nts, nth_ts_print_diag=50, fused=True, fused_steps=1, out=print,
+def run(GR, F, nts, nth_ts_print_diag=None, fused=True, fused_steps=1, out=print,
         output_path=None, i_out_nth_hour=None, restart_dir=None, i_restart_nth_day=None):
     """solver.py:70-226.  F.host must already be uploaded.  Returns the list of printed
     diagnostics tuples.  With `output_path`, history files out%04d.nc are written every
     `i_out_nth_hour` simulated hours (and constants.nc at the start) as io_nc_output.py does; with
-    `restart_dir`, a restart archive every `i_restart_nth_day` days (solver.py:156-177)."""
+    `restart_dir`, a restart archive every `i_restart_nth_day` days (solver.py:156-177).  The
+    intervals default to the namelist's (GR.nl), the step counts to main_grid.py:264-270.
+
+    Order inside one iteration as in the reference: status line, secondary diagnostics, turbulence,
+    radiation, Matsuno step, output.  The status line therefore shows the WIND the secondary
+    diagnostics of the PREVIOUS iteration left (the state before that iteration's dynamics), next
+    to the current COLP / POTT -- solver.py:91 comes before :98-101.  Before the first iteration WIND
+    holds the diagnosis of the initial state (io_initial_conditions.py:101-104)."""
     core = F.core
-    turb = Turbulence(GR) if GR.nl.i_turb else None
-    rad = Radiation(GR, GR.nl.rad_nth_hour) if GR.nl.i_radiation else None
+    nl = GR.nl
+    if nth_ts_print_diag is None:
+        nth_ts_print_diag = getattr(nl, 'nth_ts_print_diag', 50)
+    turb = Turbulence(GR) if nl.i_turb else None
+    rad = Radiation(GR, nl.rad_nth_hour) if nl.i_radiation else None
     fused_steps = max(1, int(fused_steps))
     if turb is not None or rad is not None or not fused:
         fused_steps = 1
@@ -76,18 +86,25 @@ def run(GR, F, nts, nth_ts_print_diag=50, fused=True, fused_steps=1, out=print,
     GR.timer.start('diag')
     Diagnostics.primary_diag(GR.GRF[Diagnostics.target],
                              **F.get(Diagnostics.fields_primary_diag, target=Diagnostics.target))
+    if GR.ts == 0:      # WIND (PAIR, TAIR, RHO) of the initial state, as initialize_fields leaves them
+        Diagnostics.secondary_diag(**F.get(Diagnostics.fields_secondary_diag, target=Diagnostics.target))
     GR.timer.stop('diag')
+    if rad is not None and GR.ts == 0:
+        rad.calc_radiation(GR, F)       # main_fields.py:94-101: a first radiation call on the initial state
 
     out_nth_ts = rst_nth_ts = 0
     if output_path is not None:
         from . import io_output
-        out_nth_ts = max(1, int((i_out_nth_hour or 12.) * 3600 / GR.dt))          # main_grid.py:268
+        hours = i_out_nth_hour if i_out_nth_hour is not None else getattr(nl, 'i_out_nth_hour', 12.)
+        out_nth_ts = max(1, int(hours * 3600 / GR.dt))                           # main_grid.py:268
         io_output.constant_fields_to_NC(GR, F, output_path)                      # solver.py:66
         if not hasattr(GR, 'nc_output_count'):
             GR.nc_output_count = 0
     if restart_dir is not None:
         from . import io_output
-        rst_nth_ts = max(1, int((i_restart_nth_day or 1.) * 24 * 3600 / GR.dt))
+        hours = i_out_nth_hour if i_out_nth_hour is not None else getattr(nl, 'i_out_nth_hour', 12.)
+        days = i_restart_nth_day if i_restart_nth_day is not None else getattr(nl, 'i_restart_nth_day', 1.)
+        rst_nth_ts = max(1, int(days * 24 / hours * max(1, int(hours * 3600 / GR.dt))))      # main_grid.py:269-270
     if out_nth_ts or rst_nth_ts:
         fused_steps = 1
 
@@ -95,19 +112,24 @@ def run(GR, F, nts, nth_ts_print_diag=50, fused=True, fused_steps=1, out=print,
     while GR.ts < end:
         GR.timer.start('total')
         step = GR.ts + 1                      # the reference counts the step before running it
-        # a fused chunk may not run past the next status line
-        n = min(fused_steps, end - GR.ts, (step // nth_ts_print_diag + 1) * nth_ts_print_diag - step)
+        # a fused chunk runs one secondary-diagnostics call for all its steps, so it may contain neither a
+        # status-line step nor the step before one (whose diagnostics that line shows) except as its first
+        n = 1
+        while (n < fused_steps and step + n <= end and (step + n) % nth_ts_print_diag != 0
+               and (step + n + 1) % nth_ts_print_diag != 0):
+            n += 1
         GR.GMT += timedelta(seconds=GR.dt * n)           # solver.py:88-90: clock first, then physics and dynamics
 
-        GR.timer.start('diag')
-        Diagnostics.secondary_diag(**F.get(Diagnostics.fields_secondary_diag, target=Diagnostics.target))
-        GR.timer.stop('diag')
-        if step % nth_ts_print_diag == 0:
+        if step % nth_ts_print_diag == 0:     # solver.py:91
             GR.ts = step
             try:
                 log.append(print_ts_info(GR, F, nth_ts_print_diag, out))
             finally:
                 GR.ts = step - 1
+
+        GR.timer.start('diag')
+        Diagnostics.secondary_diag(**F.get(Diagnostics.fields_secondary_diag, target=Diagnostics.target))
+        GR.timer.stop('diag')
 
         if turb is not None:
             GR.timer.start('turb')

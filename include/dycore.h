@@ -59,7 +59,10 @@ typedef struct DycoreConfig {
     int32_t i_turb;        /* i_UVFLX_vert_turb & i_POTT_vert_turb (namelist.py:66,77)  */
     int32_t i_radiation;   /* i_POTT_radiation (io_read_namelist.py:66-67)              */
     int32_t i_moist;       /* i_moist_main_switch (namelist.py:80): QV/QC advection, dyn_moist */
-    int32_t reserved[6];
+    int32_t i_moist_clip;  /* != 0: QV, QC < 0 -> 0 after every Euler step, the rule of the reference's accelerator
+                            * kernel (dyn_timestep.py:145-154); 0 = its CPU kernel (:291-296), which does not clip
+                            * and which the parity fixtures follow */
+    int32_t reserved[5];
     double  pair_top;      /* model-top pressure [Pa] (namelist.py:37)                  */
     void   *stream;        /* hipStream_t to issue work on; NULL = handle creates one   */
 } DycoreConfig;
@@ -80,6 +83,10 @@ int dycore_set_grid(dycore_t *h, const char *name, const double *host,
                     int32_t n0, int32_t n1, int32_t n2);
 
 /* ---- fields: main_fields.py:184-215 (copy_host_to_device / copy_device_to_host) ---- */
+/* 1 if the handle holds a buffer for `name` (the radiation fields exist only with i_radiation, the
+ * TURB_* scratch fields only with i_turb), else 0: lets main_fields.ModelFields build its ALL_FIELDS
+ * group (main_fields.py:150-182) from what can actually be transferred */
+int dycore_has_field(dycore_t *h, const char *name);
 int dycore_field_shape(dycore_t *h, const char *name, int32_t shape[3]);
 int dycore_upload(dycore_t *h, const char *name, const double *host);
 int dycore_download(dycore_t *h, const char *name, double *host);   /* synchronises */

@@ -653,6 +653,10 @@ void oracle_make_timestep(const oracle_cfg *c, const oracle_grid *g, oracle_fiel
                     for (int k = 0; k < nz; k++) {
                         AT(f->QV, i, j, k, 0, nz) = AT(f->QV_OLD, i, j, k, 0, nz) * co / cn + dt * AT(f->dQVdt, i, j, k, 0, nz) / cn;
                         AT(f->QC, i, j, k, 0, nz) = AT(f->QC_OLD, i, j, k, 0, nz) * co / cn + dt * AT(f->dQCdt, i, j, k, 0, nz) / cn;
+                        if (c->i_moist_clip) {      /* dyn_timestep.py:145-154 (accelerator path) */
+                            if (AT(f->QV, i, j, k, 0, nz) < 0.0) AT(f->QV, i, j, k, 0, nz) = 0.0;
+                            if (AT(f->QC, i, j, k, 0, nz) < 0.0) AT(f->QC, i, j, k, 0, nz) = 0.0;
+                        }
                     }
             }
         }

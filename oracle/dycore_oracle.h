@@ -32,6 +32,8 @@ typedef struct {
     int nthreads;      /* OpenMP threads, 0 = runtime default                      */
     double pair_top;   /* namelist.py pair_top                                     */
     int i_moist;       /* i_moist_main_switch (namelist.py:80): QV/QC advection     */
+    int i_moist_clip;  /* QV, QC < 0 -> 0 after the Euler step: the rule of the reference's GPU kernel
+                          (dyn_timestep.py:145-154); its CPU kernel (:291-296) does not clip       */
 } oracle_cfg;
 
 /* grid constants: main_grid.py:299-314 (GRF dict) */

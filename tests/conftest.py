@@ -12,20 +12,6 @@ def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
 
 
-def pytest_sessionstart(session):
-    """On a GPU box bring torch's device context up before the first dycore handle: torch
-    (band buffers, torch.distributed) and libdycore_hip.so share one HIP runtime in the process,
-    and torch's lazy initialisation failed ("No HIP GPUs are available") when it came late in a
-    long session."""
-    try:
-        import torch
-        if torch.cuda.is_available():
-            torch.cuda.init()
-            torch.zeros(1, device='cuda')
-    except Exception:
-        pass
-
-
 def pytest_terminal_summary(terminalreporter):
     """Largest max-norm relative error each test measured through golden_util.rel_max_err (the margin
     under its tolerance); also written to gpurun_out/parity_margins.txt when that directory exists."""

@@ -21,7 +21,7 @@ _dp = C.POINTER(C.c_double)
 class OracleCfg(C.Structure):
     _fields_ = [('nx', C.c_int), ('ny', C.c_int), ('nz', C.c_int),
                 ('i_turb', C.c_int), ('i_radiation', C.c_int), ('nthreads', C.c_int),
-                ('pair_top', C.c_double), ('i_moist', C.c_int)]
+                ('pair_top', C.c_double), ('i_moist', C.c_int), ('i_moist_clip', C.c_int)]
 
 
 GRID_2D = ['A', 'dxjs', 'dyis', 'corf', 'corf_is', 'lat_rad', 'lat_is_rad', 'dlon_rad', 'dlat_rad']
@@ -90,13 +90,13 @@ class Oracle:
     """The CPU restatement bound to one set of numpy arrays (reference layout)."""
 
     def __init__(self, nx, ny, nz, grid, fields=None, pair_top=10000., i_turb=1,
-                 i_radiation=0, nthreads=0, fill_nan=True, i_moist=0):
+                 i_radiation=0, nthreads=0, fill_nan=True, i_moist=0, i_moist_clip=0):
         self.lib = load_oracle()
         self.nx, self.ny, self.nz = int(nx), int(ny), int(nz)
         if not nthreads:        # a GPU box shows every core of its host; its share is 16
             nthreads = min(16, len(os.sched_getaffinity(0)))
         self.cfg = OracleCfg(self.nx, self.ny, self.nz, int(i_turb), int(i_radiation),
-                             int(nthreads), float(pair_top), int(i_moist))
+                             int(nthreads), float(pair_top), int(i_moist), int(i_moist_clip))
         self.G = {}
         self.grid = OracleGrid()
         for n in GRID_2D + GRID_1D:

@@ -470,3 +470,66 @@ def test_fused_turbulent_step_equals_stage_kernels(monkeypatch, i_moist):
     for n in ('UWIND', 'VWIND', 'POTT', 'COLP') + (('QV',) if i_moist else ()):
         err, ncmp, bad = rel_max_err(out['1'][n], o.F[n], n, GR.nx, GR.ny)
         assert bad == 0 and ncmp > 0 and err <= STEP_TOL, '%s vs oracle: %.3e' % (n, err)
+
+
+@pytest.mark.gpu
+def test_copy_device_to_host_all_fields_on_a_dry_handle():
+    """The reference's pre-output call F.copy_device_to_host(GR, F.ALL_FIELDS) (solver.py:155,170) on a handle
+    created without i_turb / i_radiation: the group holds the fields that handle has, nothing raises; with the
+    switches on the group grows by the TURB_* scratch and the radiation fields."""
+    from climate_model_amd.fields import RADIATION_FIELDS, FIELD_TABLE
+    z = load_golden('g10x4_dry')
+    GR = grid_from_golden(z)
+    core = make_core(GR)
+    F = fields_from(GR, core, fields_of(z, 'ic'))
+    core.primary_diag()
+    core.step_matsuno(GR.dt, 1)
+    names = F.field_groups[F.ALL_FIELDS]
+    assert 'UWIND' in names and 'UFLX' in names and not set(names) & set(RADIATION_FIELDS) and 'TURB_U' not in names
+    assert not core.has_field('SOILTEMP') and not core.has_field('TURB_T') and not core.has_field('NO_SUCH_FIELD')
+    F.copy_device_to_host(GR, F.ALL_FIELDS)
+    F.copy_device_to_host()                          # default group
+    assert np.isfinite(F.host['UWIND'][1:GR.nx + 1, 1:-1]).all()
+    err, _, bad = rel_max_err(F.host['POTT'], z['step001/POTT'], 'POTT', GR.nx, GR.ny)
+    assert bad == 0 and err <= STEP_TOL
+    core.close()
+    from climate_model_amd import HipDycore, ModelFields
+    core = HipDycore(GR.nx, GR.ny, GR.nz, i_turb=1, i_radiation=1)
+    F2 = ModelFields(GR, core)
+    assert set(F2.field_groups[F2.ALL_FIELDS]) == set(FIELD_TABLE)
+    core.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('fused', ['1', '0'])
+def test_moisture_clip_matches_the_accelerator_rule(fused, monkeypatch):
+    """DycoreConfig.i_moist_clip: QV, QC < 0 -> 0 after every Euler step (dyn_timestep.py:145-154) in the fused
+    k_moist and in the stage k_euler_forward; against the oracle run with the same switch, and off by default."""
+    monkeypatch.setenv('DYCORE_FUSED', fused)
+    from climate_model_amd import HipDycore
+    z = load_golden('g10x4_dry')
+    GR = grid_from_golden(z, i_moist=1)
+    dt = float(z['meta/dt'])
+    for clip in (0, 1):
+        o = oracle_from_golden(z, None, i_turb=0, i_moist=1)
+        o.cfg.i_moist_clip = clip
+        qc = np.zeros_like(o.F['QC'])
+        qc[8:14, 5:9, :] = 2e-3                       # a sharp cloud edge: the advection undershoots
+        o.F['QC'][...] = qc
+        core = HipDycore(GR.nx, GR.ny, GR.nz, pair_top=GR.nl.pair_top, i_moist=1, i_moist_clip=clip)
+        core.set_grid(GR.GRF['HIP'])
+        F = fields_from(GR, core, {n: o.F[n] for n in ORACLE_FIELDS})
+        o.primary_diag()
+        core.primary_diag()
+        o.step_matsuno(dt, 2, with_rho=False)
+        core.step_matsuno(dt, 2)
+        got = core.download('QC')
+        inner = got[1:-1, 1:-1]
+        if clip:
+            assert inner.min() == 0.0 and (inner == 0.0).sum() > 0
+        else:
+            assert inner.min() < 0
+        for n in ('QV', 'QC', 'POTT'):
+            err, ncmp, bad = rel_max_err(core.download(n), o.F[n], n, GR.nx, GR.ny)
+            assert bad == 0 and ncmp > 0 and err <= (1e-9 if n == 'QC' else STEP_TOL), (clip, n, err)
+        core.close()

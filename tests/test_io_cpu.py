@@ -114,3 +114,36 @@ def test_restart_round_trip(tmp_path):
     GR3 = Grid(Namelist(nz=4, dlat_deg=10, dlon_deg=10), sigma_vb=np.linspace(0, 1, 5))
     with pytest.raises(ValueError, match='sigma'):
         io_output.load_restart(GR3, ModelFields(GR3), path)
+
+
+def test_time_step_rule_of_the_reference_presets():
+    """main_grid.py:258-270: dt = int(CFL min(dx) / 400), lowered until it divides the output interval; the step
+    counts derived from it.  The two presets of namelist.py:243-278 (values from running the reference's own Grid
+    in the build container: dt = 200 s for preset 1 -- meta/dt of tests/golden/g5x8_preset.npz -- and 20 s for preset 2)."""
+    from climate_model_amd import Namelist, Grid
+    g = Grid(Namelist(nz=8, dlat_deg=5, dlon_deg=5, lat0_deg=-80, lat1_deg=80, i_out_nth_hour=8, i_sim_n_days=0.72))
+    assert (g.dt, g.i_out_nth_ts, g.i_restart_nth_ts) == (200, 144, 432) and abs(g.nts - 311.04) < 1e-9
+    g = Grid(Namelist(nz=32, dlat_deg=1, dlon_deg=1, lat0_deg=-84, lat1_deg=84, i_out_nth_hour=12))
+    assert (g.dt, g.i_out_nth_ts, g.i_restart_nth_ts) == (20, 2160, 4320)
+    assert 12 * 3600 % g.dt == 0
+    # an explicit dt is taken as is
+    assert Grid(Namelist(nz=8, dlat_deg=5, dlon_deg=5, dt=37.5)).dt == 37.5
+
+
+def test_restart_refuses_another_time_step(tmp_path):
+    from climate_model_amd import Namelist, Grid, ModelFields, io_output
+    GR = Grid(Namelist(nz=4, dlat_deg=10, dlon_deg=10))
+
+    class _Core:
+        i_moist = False
+
+        def download(self, n, out):
+            return out
+    F = ModelFields(GR)
+    F.core = _Core()
+    path = io_output.write_restart(GR, F, str(tmp_path))
+    F.core = None
+    GR2 = Grid(Namelist(nz=4, dlat_deg=10, dlon_deg=10, dt=GR.dt / 2))
+    with pytest.raises(ValueError, match='dt'):
+        io_output.load_restart(GR2, ModelFields(GR2), path)
+    io_output.load_restart(GR, F, path)

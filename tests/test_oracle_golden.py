@@ -172,3 +172,22 @@ def test_radiation_oracle_vs_reference(case):
         assert np.isfinite(g).all(), n
         scale = np.max(np.abs(ref))
         assert np.max(np.abs(g - ref)) <= 1e-12 * scale, (n, np.max(np.abs(g - ref)) / scale)
+
+
+def test_moisture_clip_switch():
+    """i_moist_clip = the rule of the reference's accelerator kernel (dyn_timestep.py:145-154): QV, QC < 0 -> 0
+    after the Euler step; off (the CPU kernel, :291-296, which the fixtures follow) negative values survive.
+    A state with a sharp cloud edge makes the advection undershoot."""
+    z = load_golden('g10x4_dry')
+    res = {}
+    for clip in (0, 1):
+        o = oracle_from_golden(z, None, i_turb=0, i_moist=1)
+        o.cfg.i_moist_clip = clip
+        qc = np.zeros_like(o.F['QC'])
+        qc[8:14, 5:9, :] = 2e-3
+        o.F['QC'][...] = qc
+        o.primary_diag()
+        o.step_matsuno(float(z['meta/dt']), 2, with_rho=False)
+        res[clip] = o.F['QC'][1:-1, 1:-1].copy()
+    assert res[0].min() < 0 and res[1].min() == 0.0
+    assert np.isfinite(res[1]).all() and res[1].max() > 1e-3

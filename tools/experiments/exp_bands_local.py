@@ -2,7 +2,7 @@
 another (LocalBands) and report the mean per-band kernel time per step = what each of N GPUs
 would spend in kernels (exchange excluded)."""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import numpy as np
 import torch

@@ -1,7 +1,7 @@
 """Bitwise comparison of two library builds (same ABI): N fused steps on a small grid, every
-downloadable field of interest compared bit for bit.  usage: python tests/exp_bitcmp.py old.so new.so [dlat nz steps moist]"""
+downloadable field of interest compared bit for bit.  usage: python tools/experiments/exp_bitcmp.py old.so new.so [dlat nz steps moist]"""
 import os, subprocess, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 WORKER = r'''
 import sys, os
 sys.path.insert(0, %r)

@@ -1,7 +1,7 @@
 """Host-side cost of the overlapped band schedule: 2 bands of a tiny grid in one process, so that the
 GPU work is negligible and the wall time per step is Python + ctypes + torch stream/event calls."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from climate_model_amd import Namelist, Grid, ModelFields, HipDycore
 from climate_model_amd.bands import BandLayout, LocalBands, band_grid_arrays

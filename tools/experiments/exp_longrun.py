@@ -1,6 +1,6 @@
 """Stability probe: every scheme on (turbulence, moisture, radiation) through solver.run for a few simulated hours."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from climate_model_amd import Namelist, Grid, ModelFields, HipDycore, solver
 from climate_model_amd.synthetic import initialize_fields, initialize_moisture

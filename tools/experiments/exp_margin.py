@@ -1,7 +1,7 @@
 """Parity margin of the fused step: max-norm relative error against the oracle after 1, 2, 10 steps
 (4 deg x 8 levels golden initial state) and against the golden snapshots."""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import numpy as np
 from golden_util import load_golden, rel_max_err

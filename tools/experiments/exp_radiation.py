@@ -1,6 +1,6 @@
 """Timing probe: one radiation call at the bench grid (0.25 deg x 64), HIP events."""
 import datetime, os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from climate_model_amd import Namelist, Grid, ModelFields, HipDycore, Radiation
 from climate_model_amd.synthetic import initialize_fields, initialize_moisture

@@ -1,7 +1,7 @@
 """Timing probe: the reference's loop body (secondary diagnostics, turbulence scheme, Matsuno step with
 moisture and the turbulent terms) at the bench grid through solver.run."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from climate_model_amd import Namelist, Grid, ModelFields, HipDycore, solver
 from climate_model_amd.synthetic import initialize_fields, initialize_moisture

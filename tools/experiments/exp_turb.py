@@ -1,6 +1,6 @@
 """Timing probe: turbulence-coupled Matsuno step at the bench grid, fused (default) vs stage kernels."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from climate_model_amd import Namelist, Grid, ModelFields, HipDycore
 from climate_model_amd.synthetic import initialize_fields

@@ -1,8 +1,8 @@
 """A/B timing of library builds (same ABI) on the bench workload.  usage:
-   python tests/exp_variants.py [--d 0.25] [--nz 64] [--steps 6] lib1.so lib2.so ...
+   python tools/experiments/exp_variants.py [--d 0.25] [--nz 64] [--steps 6] lib1.so lib2.so ...
 Each library runs in its own subprocess (DYCORE_LIB); rounds are interleaved."""
 import os, subprocess, sys, json
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 WORKER = r'''
 import sys, os, json

@@ -1,6 +1,6 @@
 """Ad-hoc first GPU check: timing of the staged v1 kernels at a few grid sizes."""
 import sys, time, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from climate_model_amd import Namelist, Grid, ModelFields, HipDycore
 from climate_model_amd.synthetic import initialize_fields

@@ -271,12 +271,26 @@ class DistributedBands:
     do not depend on them (_overlapped_step); overlap=False is the plain sequence
     part 0, exchange A, part 1, exchange B, part 2."""
 
-    def __init__(self, core, layout, rank, device, group=None, overlap=None):
+    def __init__(self, core, layout, rank, device, group=None, overlap=None, native=None):
         import torch.distributed as dist
         self.dist = dist
         self.core, self.layout, self.rank = core, layout, rank
         self.group = group
         self.south, self.north = layout.south(rank), layout.north(rank)
+        # RCCL process group + a handle on the fused step: the whole band step runs inside the library
+        # (hip_backend.NativeBands: ncclSend / ncclRecv issued by the library itself on its comm stream, one call per
+        # step sequence); the torch.distributed transport below remains for gloo (tests, one-GPU rehearsals), for
+        # the turbulence-coupled step and behind DYCORE_BANDS_NATIVE=0
+        self.native = None
+        if native is None:
+            import os
+            native = os.environ.get('DYCORE_BANDS_NATIVE', '1') != '0'
+        if (native and str(device) != 'cpu' and dist.get_backend(group) == 'nccl' and getattr(core, 'overlap_parts', False)
+                and getattr(core, 'flux_from_winds', False) and layout.nbands > 1):
+            from .hip_backend import NativeBands, bands_unique_id
+            ids = [bands_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(ids, src=0, group=group)
+            self.native = NativeBands.rccl(core, ids[0], rank, layout.nbands, self.south, self.north)
         self.halo = BandHalo(core, layout.ny(rank), self.south is not None, self.north is not None)
         self.bufs = _TorchBuffers(self.halo, device)
         on_gpu = str(device) != 'cpu'
@@ -318,6 +332,10 @@ class DistributedBands:
         timed region, not inside it.  Every rank calls it."""
         if self.south is None and self.north is None:
             return
+        if self.native is not None:
+            self.native.connect()
+            self.core.sync()
+            return
         import torch
         if self.overlap:
             self.streams.comm.wait_stream(self.streams.main)
@@ -346,6 +364,8 @@ class DistributedBands:
         core = self.core
         if self.south is None and self.north is None:
             return core.step_matsuno(dt, nsteps, with_rho)
+        if self.native is not None:
+            return self.native.step_matsuno(dt, nsteps, with_rho)
         if self.overlap:
             return _overlapped_step([core], self.streams, self._deliver, dt, nsteps, with_rho)
         for _ in range(nsteps):
@@ -363,8 +383,15 @@ class LocalBands:
     through device-to-device copies.  Test vehicle for the band-aware kernels and for the
     overlapped schedule (overlap=True: same stream choreography as DistributedBands)."""
 
-    def __init__(self, cores, layout, device, overlap=True):
+    def __init__(self, cores, layout, device, overlap=True, native=False):
         self.cores, self.layout = cores, layout
+        # native: the schedule runs inside the library (dycore_bands_create_local), device copies between the bands
+        self.native = None
+        if native and len(cores) > 1:
+            from .hip_backend import NativeBands
+            self.native = NativeBands.local(cores)
+            self.overlap = True
+            return
         self.halos = [BandHalo(c, layout.ny(r), layout.south(r) is not None, layout.north(r) is not None)
                       for r, c in enumerate(cores)]
         self.bufs = [_TorchBuffers(h, device) for h in self.halos]
@@ -403,6 +430,8 @@ class LocalBands:
         self._deliver(ph, sub, host_sync=True)
 
     def step_matsuno(self, dt, nsteps=1, with_rho=None):
+        if self.native is not None:
+            return self.native.step_matsuno(dt, nsteps, with_rho)
         if self.overlap:
             return _overlapped_step(self.cores, self.streams, self._deliver, dt, nsteps, with_rho)
         for _ in range(nsteps):

@@ -67,6 +67,10 @@ struct Ptrs {
     // grid constants, vertical 1-D
     const double *sigma_vb, *dsigma, *UVFLX_dif_coef, *POTT_dif_coef, *moist_dif_coef;
     const double *rdsigma;      // 1 / dsigma, formed by the library when dsigma is set
+    // per-level constants of the momentum kernel, five arrays of stride nz + 2 (formed by the library from dsigma,
+    // sigma_vb, UVFLX_dif_coef): wa[k] = dsigma[k] / (dsigma[k] + dsigma[k-1]), wb[k] = dsigma[k-1] / (...) (0 at k = 0),
+    // 1 / dsigma[k], sigma_vb[k] (nz + 1 entries), UVFLX_dif_coef[k]
+    const double *mom_c;
 };
 
 __device__ __forceinline__ size_t at(const Geo &g, int i, int j, int k)

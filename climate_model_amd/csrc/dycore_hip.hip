@@ -133,6 +133,7 @@ struct dycore {
     double *rad_ws = nullptr;       // workspace of the radiation columns, [element][column]
     long long rad_ws_cols = 0;
     double *stage = nullptr;        // staging buffer for the layout adaptor
+    std::vector<double> h_dsigma, h_sigma_vb, h_uvdif;      // host copies of the vertical grid (-> Ptrs::mom_c)
     size_t stage_elems = 0;
     int grid_set = 0;
     bool fused = true;              // production kernels in dycore_step_matsuno (DYCORE_FUSED=0: stage kernels)
@@ -149,6 +150,8 @@ struct dycore {
     int mom_split = 1;              // DYCORE_MOM_SPLIT=0: no second segment (short chunks for the tiles beyond the last full round)
     double mom_pro = 2.0;           // DYCORE_MOM_PRO: prologue of a level chunk in units of one level (plan cost model)
     int mom_dma = 1;                // momentum kernel: 1 = LDS-DMA (default); 0 = register-staged tiles (DYCORE_MOM_DMA)
+    int mom_patch = 4;              // tile order: bands of this many tile rows traversed column by column (DYCORE_MOM_PATCH; 1 = row by row)
+    int mom_depth = 2;              // levels the LDS-DMA kernel keeps in flight (DYCORE_MOM_DEPTH=1: one, the round-1 schedule)
     // profiler
     int prof = 0;                   // 0 off, 1 every launch, 2 dominant kernel only
     std::vector<ProfRec> recs;
@@ -501,7 +504,7 @@ int do_momentum_fused(dycore *h, const Ptrs &p, const double *u_old, const doubl
         // in 1, 2 or 4 chunks per tile, or -- for a contiguous row set of more than one round -- the
         // tile rows that fill whole rounds as full tiles (segment a) and the remaining rows cut into
         // up to 16 chunks (segment b), so that the last round costs a fraction of a tile.
-        MomPlan plan = {trows, 1, 0, {0, 0, 0, 0}, 1};
+        MomPlan plan = {trows, 1, 0, {0, 0, 0, 0}, 1, h->mom_patch};
         {
             const long tiles = (long)gbx * trows.n;
             const double pro = h->mom_pro;
@@ -536,10 +539,11 @@ int do_momentum_fused(dycore *h, const Ptrs &p, const double *u_old, const doubl
         const dim3 gr2(plan.nblk_a + 8 * ((gbx * plan.b.n * plan.ks_b + 7) / 8)), blk(FTI, tj);
         const bool cur = (u_old == p.UWIND);
         const bool fw = flux_from_winds(h) && (h->fw_mask & 2);
-#define MOM_LAUNCH(CUR_, FW_, TB_) hipLaunchKernelGGL((k_momentum_dma<CUR_, tj, FW_, TB_>), gr2, blk, dma_lds_bytes(tj, FW_), h->stream, h->g, p, gbx, plan, jv_lo, u_old, v_old, u_out, v_out, dt)
-        if (h->g.i_turb) { if (cur) MOM_LAUNCH(true, true, true); else MOM_LAUNCH(false, true, true); }
-        else if (cur) { if (fw) MOM_LAUNCH(true, true, false); else MOM_LAUNCH(true, false, false); }
-        else { if (fw) MOM_LAUNCH(false, true, false); else MOM_LAUNCH(false, false, false); }
+        // ring depth: two levels in flight for the production (dry / moist, fluxes from the winds) instances
+#define MOM_LAUNCH(CUR_, FW_, TB_, DP_) hipLaunchKernelGGL((k_momentum_dma<CUR_, tj, FW_, TB_, DP_>), gr2, blk, dma_lds_bytes(tj, FW_, CUR_, DP_), h->stream, h->g, p, gbx, plan, jv_lo, u_old, v_old, u_out, v_out, dt)
+        if (h->g.i_turb) { if (cur) MOM_LAUNCH(true, true, true, 1); else MOM_LAUNCH(false, true, true, 1); }
+        else if (cur) { if (!fw) MOM_LAUNCH(true, false, false, 1); else if (h->mom_depth == 2) MOM_LAUNCH(true, true, false, 2); else MOM_LAUNCH(true, true, false, 1); }
+        else { if (!fw) MOM_LAUNCH(false, false, false, 1); else if (h->mom_depth == 2) MOM_LAUNCH(false, true, false, 2); else MOM_LAUNCH(false, true, false, 1); }
 #undef MOM_LAUNCH
     } else if (u_out)
         hipLaunchKernelGGL(k_momentum_fused<true>, gr, bl, 0, h->stream, h->g, p, gbx, gby, jv_lo, u_old, v_old, u_out, v_out, dt);
@@ -816,6 +820,8 @@ int dycore_create(const DycoreConfig *cfg, dycore_t **out)
     if (const char *e = getenv("DYCORE_FUSED_TURB")) h->fused_turb = atoi(e) != 0;
     if (const char *e = getenv("DYCORE_FW_MASK")) h->fw_mask = atoi(e);
     if (const char *e = getenv("DYCORE_MOM_KS")) h->mom_ks = atoi(e);
+    if (const char *e = getenv("DYCORE_MOM_PATCH")) h->mom_patch = atoi(e) > 1 ? atoi(e) : 1;
+    if (const char *e = getenv("DYCORE_MOM_DEPTH")) h->mom_depth = atoi(e) == 1 ? 1 : 2;
     if (const char *e = getenv("DYCORE_MOM_SPLIT")) h->mom_split = atoi(e);
     if (const char *e = getenv("DYCORE_MOM_PRO")) h->mom_pro = atof(e);
     if (const char *e = getenv("DYCORE_CELL_LINEAR")) h->cell_lin = atoi(e);
@@ -823,15 +829,19 @@ int dycore_create(const DycoreConfig *cfg, dycore_t **out)
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, cfg->device) == hipSuccess && prop.multiProcessorCount > 0) h->n_cu = prop.multiProcessorCount;
     }
-    {   // the LDS-DMA kernel double-buffers 122 KB of tiles: raise the dynamic-LDS limit once
-        hipError_t e1 = hipFuncSetAttribute((const void *)k_momentum_dma<true, FTJ, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dma_lds_bytes(FTJ, false));
-        hipError_t e2 = hipFuncSetAttribute((const void *)k_momentum_dma<false, FTJ, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dma_lds_bytes(FTJ, false));
-        hipError_t e3 = hipFuncSetAttribute((const void *)k_momentum_dma<true, FTJ, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dma_lds_bytes(FTJ, true));
-        hipError_t e4 = hipFuncSetAttribute((const void *)k_momentum_dma<false, FTJ, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dma_lds_bytes(FTJ, true));
-        if (e3 == hipSuccess) e3 = hipFuncSetAttribute((const void *)k_momentum_dma<true, FTJ, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dma_lds_bytes(FTJ, true));
-        if (e4 == hipSuccess) e4 = hipFuncSetAttribute((const void *)k_momentum_dma<false, FTJ, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dma_lds_bytes(FTJ, true));
-        if (e1 != hipSuccess || e2 != hipSuccess) { (void)hipGetLastError(); h->mom_dma = 0; }
-        if (e3 != hipSuccess || e4 != hipSuccess) { (void)hipGetLastError(); h->lazy_flx = false; }
+    {   // the LDS-DMA kernel keeps up to 155 KB of tiles in LDS: raise the dynamic-LDS limit of every instantiation once
+        bool ok_plain = true, ok_fw = true, ok_deep = true;
+#define MOM_ATTR(CUR_, FW_, TB_, DP_, FLAG_)                                                                          \
+        if (hipFuncSetAttribute((const void *)k_momentum_dma<CUR_, FTJ, FW_, TB_, DP_>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                (int)dma_lds_bytes(FTJ, FW_, CUR_, DP_)) != hipSuccess) { (void)hipGetLastError(); FLAG_ = false; }
+        MOM_ATTR(true, false, false, 1, ok_plain) MOM_ATTR(false, false, false, 1, ok_plain)
+        MOM_ATTR(true, true, false, 1, ok_fw) MOM_ATTR(false, true, false, 1, ok_fw)
+        MOM_ATTR(true, true, true, 1, ok_fw) MOM_ATTR(false, true, true, 1, ok_fw)
+        MOM_ATTR(true, true, false, 2, ok_deep) MOM_ATTR(false, true, false, 2, ok_deep)
+#undef MOM_ATTR
+        if (!ok_plain) h->mom_dma = 0;
+        if (!ok_fw) h->lazy_flx = false;
+        if (!ok_deep) h->mom_depth = 1;
     }
     if (cfg->stream) h->stream = (hipStream_t)cfg->stream;
     else {
@@ -901,6 +911,11 @@ int dycore_create(const DycoreConfig *cfg, dycore_t **out)
         h->p.rdsigma = d;
     }
     if (!rc) {
+        double *d = nullptr;
+        rc = alloc((size_t)(5 * (g.nz + 2)), &d);
+        h->p.mom_c = d;
+    }
+    if (!rc) {
         h->stage_elems = (size_t)(g.nx + 3) * (g.ny + 3) * (g.nz + 1);
         double *d = nullptr;
         rc = alloc(h->stage_elems, &d);
@@ -962,6 +977,28 @@ int dycore_set_grid(dycore_t *h, const char *name, const double *host, int32_t n
             std::vector<double> r(n);
             for (int k = 0; k < n; k++) r[k] = 1.0 / host[k];
             HIP_TRY(hipMemcpyAsync(const_cast<double *>(h->p.rdsigma), r.data(), n * sizeof(double), hipMemcpyHostToDevice, h->stream));
+            HIP_TRY(hipStreamSynchronize(h->stream));
+            h->h_dsigma.assign(host, host + n);
+        }
+        if (d.member == &Ptrs::sigma_vb) h->h_sigma_vb.assign(host, host + n);
+        if (d.member == &Ptrs::UVFLX_dif_coef) h->h_uvdif.assign(host, host + n);
+        if ((d.member == &Ptrs::dsigma || d.member == &Ptrs::sigma_vb || d.member == &Ptrs::UVFLX_dif_coef) &&
+            !h->h_dsigma.empty() && !h->h_sigma_vb.empty() && !h->h_uvdif.empty()) {
+            // the momentum kernel's per-level constants (Ptrs::mom_c); plain IEEE operations, no contraction possible
+            const int nz = g.nz, cs = nz + 2;
+            std::vector<double> m(5 * (size_t)cs, 0.0);
+            for (int t = 0; t <= nz; t++) {
+                m[3 * cs + t] = h->h_sigma_vb[t];
+                if (t < nz) {
+                    const double ds = h->h_dsigma[t];
+                    const double rsum = t > 0 ? 1.0 / (ds + h->h_dsigma[t - 1]) : 0.0;
+                    m[t] = ds * rsum;
+                    m[cs + t] = t > 0 ? h->h_dsigma[t - 1] * rsum : 0.0;
+                    m[2 * cs + t] = 1.0 / ds;
+                    m[4 * cs + t] = h->h_uvdif[t];
+                }
+            }
+            HIP_TRY(hipMemcpyAsync(const_cast<double *>(h->p.mom_c), m.data(), m.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
             HIP_TRY(hipStreamSynchronize(h->stream));
         }
     } else {
@@ -1266,3 +1303,5 @@ int dycore_kernel_stats(dycore_t *h, int32_t idx, const char **name, int64_t *la
 }
 
 }  // extern "C"
+
+#include "dycore_bands.h"

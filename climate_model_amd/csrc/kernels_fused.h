@@ -57,15 +57,25 @@ __device__ __forceinline__ int rowset_row(const RowSet &rs, int r) { return rs.f
 // round form the second segment and are cut into short level chunks, so that the last round is a
 // fraction of a tile's time (do_momentum_fused picks the plan).  Workgroups [0, nblk_a) belong to
 // segment a (nblk_a a multiple of 8, so both segments keep the XCD-aware order), the rest to b.
-struct MomPlan { RowSet a; int ks_a, nblk_a; RowSet b; int ks_b; };
-__device__ __forceinline__ bool xcd_tile_at(int b, int gbx, int gby, int &bx, int &by)
+struct MomPlan { RowSet a; int ks_a, nblk_a; RowSet b; int ks_b; int patch; };
+// `patch` = H > 1: inside bands of H tile rows the order runs down the columns first, so that the ~32 tiles an XCD
+// works on at one time form an H x 32/H block: H-1 of H horizontal tile boundaries then have both neighbours in
+// flight together and their shared halo rows are served by that XCD's L2 instead of being fetched twice
+__device__ __forceinline__ bool xcd_tile_at(int b, int gbx, int gby, int &bx, int &by, int patch = 1)
 {
     const int nblk = gbx * gby;
     const int chunk = (nblk + 7) / 8;
     const int lin = (b % 8) * chunk + b / 8;
     if (lin >= nblk) return false;
-    bx = lin % gbx;
-    by = lin / gbx;
+    if (patch > 1) {
+        const int per = patch * gbx, q = lin / per, r = lin - q * per;
+        const int hq = min(patch, gby - q * patch);         // rows of this band (the last one may be short)
+        bx = r / hq;
+        by = q * patch + (r - bx * hq);
+    } else {
+        bx = lin % gbx;
+        by = lin / gbx;
+    }
     return true;
 }
 
@@ -305,9 +315,10 @@ __global__ __launch_bounds__(FNT) void k_momentum_fused(Geo g, Ptrs p, int gbx, 
 // ------------------------------------------------------------------------------------
 // k_momentum_dma: the same computation as k_momentum_fused<true>, restructured around
 // LDS-DMA (global_load_lds_dwordx4: HBM/L2 -> LDS without passing through VGPRs):
-//   * every input of level k+1 is in flight, 16 B per lane / 1 KB per wave-instruction,
-//     into the second LDS buffer while level k is computed from the first: one barrier per
-//     level, no vector-memory load inside the loop whose result the loop waits for;
+//   * the inputs of the next DEPTH levels are in flight, 16 B per lane / 1 KB per
+//     wave-instruction, into a ring of DEPTH+1 LDS slots while level k is computed: one
+//     barrier per level, no vector-memory load inside the loop whose result the loop waits
+//     for;
 //   * arrays are allocated with longitude i = 1 on a 512-B boundary; tiles start at i0-2, an
 //     even element, so every 16-B chunk is aligned in HBM and the tile is a linear LDS image
 //     (the DMA writes wave-base + lane*16);
@@ -316,67 +327,128 @@ __global__ __launch_bounds__(FNT) void k_momentum_fused(Geo g, Ptrs p, int gbx, 
 //     winds of levels k-1 and k, which closes the tendency of level k-1.
 // OLD_IS_CUR: predictor (u_old is the field the tendencies are evaluated on); otherwise the
 // step-start winds are staged as two more (interior-height) tiles.
-constexpr int DMAXZ = 160;                        // levels the LDS copy of the 1-D constants can hold
-// two buffers of 9 full tiles (tj+3 rows) + 2 step-start tiles (tj rows), then the 1-D constants
-// (+ four 2-D factor tiles when the fluxes are re-formed from the winds)
-constexpr size_t dma_lds_bytes(int tj, bool from_winds)
+//
+// DEPTH = 2 (production, dry / moist): __syncthreads() is `s_waitcnt vmcnt(0) lgkmcnt(0); s_barrier`, i.e.
+// it drains every DMA the wave has in flight -- with it a level's data movement is one exposed memory
+// latency per level whatever the number of buffers (the kernel without its arithmetic took 1.32 ms of the
+// full kernel's 1.36 ms, the arithmetic alone 0.91 ms: profiles/r02_notes.md).  The level loop therefore
+// synchronises with a bare s_barrier and counts its own DMA instructions: vmcnt is in order, so
+// `s_waitcnt vmcnt(n)` with n = the instructions this wave issued for level k+2 means "my part of level k+1
+// has landed" while level k+2 stays in flight.  The two stores of an iteration are issued BEFORE that
+// iteration's DMA, so they are older than it and the count is exact.
+constexpr int DMAXZ = 160;                        // levels up to which the LDS-DMA kernel is used (beyond: k_momentum_fused)
+
+// Tile rows a staged field needs from row j0-1 on: UFLX, UWIND, WWIND j-1..j+1 (TJ+2 rows), VFLX (and VWIND
+// when VFLX is re-formed from it) j-1..j+2 (TJ+3), PHI / POTT / PVTF / PVTFVB only j-1 and j (TJ+1).
+enum { S_UF = 0, S_VF, S_UW, S_VW, S_W, S_PHI, S_POTT, S_PVTF, S_PVB };
+constexpr int mom_rows(int f, int tj, bool fw)
 {
-    return (2 * (size_t)(FNF * FTW * (tj + 3) + 2 * FTW * tj) + 5 * DMAXZ + 2 + (from_winds ? 4 * FTW * (tj + 3) : 0)) * sizeof(double);
+#ifdef DYC_MOM_NOHALO       // experiment builds only (wrong results): no halo rows staged
+    return tj;
+#endif
+    return f == S_UF ? tj + 2 : f == S_VF ? tj + 3 : f == S_UW ? tj + 2 : f == S_VW ? (fw ? tj + 3 : tj + 2) : f == S_W ? tj + 2 : tj + 1;
+}
+// LDS layout (doubles).  A DMA slot holds the staged fields of one level back to back (each rows x FTW), then the
+// two step-start tiles of the corrector (tj rows each); with `fw` (fluxes re-formed from the winds) UFLX / VFLX
+// are not staged: they live in their own two-slot ring, written by the DMA wavefronts (flux_own).
+constexpr int mom_off(int f, int tj, bool fw)     // offset of field f inside its slot; f = FNF: the step-start tiles
+{
+    if (fw && f < 2) return f == S_UF ? 0 : (tj + 2) * FTW;
+    int o = 0;
+    for (int g = (fw ? 2 : 0); g < f; g++) o += mom_rows(g, tj, fw) * FTW;
+    return o;
+}
+constexpr int mom_dma_slot(int tj, bool fw, bool cur) { return mom_off(FNF, tj, fw) + (cur ? 0 : 2 * FTW * tj); }
+constexpr int mom_flux_slot(int tj, bool fw) { return fw ? (2 * tj + 5) * FTW : 0; }
+constexpr size_t dma_lds_bytes(int tj, bool fw, bool cur, int depth)
+{
+    return ((size_t)(depth + 1) * mom_dma_slot(tj, fw, cur) + 2 * (size_t)mom_flux_slot(tj, fw)) * sizeof(double);
 }
 
+#ifndef DYC_DMA_AUX
+#define DYC_DMA_AUX 0       // cache policy of the LDS-DMA loads (2 = nt)
+#endif
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef const __attribute__((address_space(1))) void gbl_void_t;
 
+// `s_waitcnt vmcnt(n)` for a wave-uniform run-time n (the instruction takes an immediate)
+__device__ __forceinline__ void wait_vmcnt(int n)
+{
+    switch (n) {
+    case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+    case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+    case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+    case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+    case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+    case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+    case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+    case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+    case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
+    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    }
+}
+// workgroup barrier that publishes this wave's LDS writes but leaves its vector-memory operations in flight
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 // FROM_WINDS: UFLX and VFLX are not staged (k_continuity_reg<., false> does not store them); their
-// tiles are re-formed in LDS every level from the UWIND / VWIND tiles and four per-tile 2-D factor
-// tiles, UFLX = UCOL * UWIND * dyis and VFLX = VCOL * VWIND * dxjs (operand order of the continuity
+// tiles are re-formed in LDS every level from the UWIND / VWIND tiles and the 2-D factors,
+// UFLX = UCOL * UWIND * dyis and VFLX = VCOL * VWIND * dxjs (operand order of the continuity
 // kernel, so the values are the ones it would have stored): 7 instead of 9 fields through the DMA.
-// Each DMA wavefront converts the chunks it moved itself once its own loads have landed (flux_own),
-// so the one barrier per level publishes the DMA data and the flux tiles together.
+// Each DMA lane converts the chunks it moved itself once its own loads have landed (flux_own; its factors
+// never change, so they sit in registers), and the one barrier per level publishes the DMA data and the
+// flux tiles together.
 // TURB: the turbulent tendencies of k_turb_tendencies (own cell, fetched one level ahead into
-// registers) join the sums.
-template <bool OLD_IS_CUR, int TJ, bool FROM_WINDS, bool TURB = false>
+// registers) join the sums; DEPTH = 1 (the compiler's own waits for those loads drain the DMA anyway).
+// The per-level constants (weights of the interface means, 1 / dsigma, sigma_vb, diffusion coefficient: p.mom_c,
+// formed by the library when the vertical grid is set) are wave-uniform scalar loads: they use neither LDS nor vmcnt.
+template <bool OLD_IS_CUR, int TJ, bool FROM_WINDS, bool TURB = false, int DEPTH = 1>
 __global__ __launch_bounds__(FTI *TJ) void k_momentum_dma(Geo g, Ptrs p, int gbx, MomPlan plan, int jv_lo,
                                                       const double *u_old, const double *v_old,
                                                       double *u_out, double *v_out, double dt)
 {
+    static_assert(DEPTH == 1 || DEPTH == 2, "ring of 2 or 3 slots");
+    static_assert(!(TURB && DEPTH != 1), "the turbulence-coupled variant keeps vector loads in the loop");
     // segment of the work list this workgroup belongs to (MomPlan)
     const bool seg_b = (int)blockIdx.x >= plan.nblk_a;
     const RowSet trows = seg_b ? plan.b : plan.a;
     const int ksplit = seg_b ? plan.ks_b : plan.ks_a;
     const int gby = trows.n;            // tile rows of this segment (a subset of the band's, see RowSet)
-    // tile geometry for TJ rows per workgroup (TJ is chosen per launch so that the number of
-    // workgroups fits the 256 CUs with the least idle tail: dma_pick_tj on the host)
-    constexpr int TH = TJ + 3, TN = FTW * TH, NT = FTI * TJ;          // tile rows, doubles, threads
-    constexpr int NCH = TN / 2, NSL = (NCH + 63) / 64;               // 16-B chunks, 64-chunk slices
+    constexpr int NCH = (TJ + 3) * FTW / 2, NSL = (NCH + 63) / 64;     // 16-B chunks of the tallest tile, 64-chunk slices
     constexpr int ON = FTW * TJ, ONCH = ON / 2, ONSL = (ONCH + 63) / 64;   // step-start ("old") tiles
-    constexpr int BUF = FNF * TN + 2 * ON;
+    constexpr int NS = DEPTH + 1;                                       // slots of the DMA ring
+    constexpr int DSLOT = mom_dma_slot(TJ, FROM_WINDS, OLD_IS_CUR), FSLOT = mom_flux_slot(TJ, FROM_WINDS);
+    constexpr int OFF_OLD = mom_off(FNF, TJ, FROM_WINDS);
     static_assert(NSL + 2 <= TJ, "not enough wavefronts for the DMA slices");
     extern __shared__ __attribute__((aligned(16))) double dsm[];
     // workgroup -> (tile, level chunk): `ksplit` chunks of the k range per tile give a small
     // latitude band enough workgroups to balance over the CUs (one tile per CU otherwise)
     int bx, by;
-    if (!xcd_tile_at((int)blockIdx.x - (seg_b ? plan.nblk_a : 0), gbx, gby * ksplit, bx, by)) return;
+    if (!xcd_tile_at((int)blockIdx.x - (seg_b ? plan.nblk_a : 0), gbx, gby * ksplit, bx, by, ksplit == 1 ? plan.patch : 1)) return;
     const int kc = by / gby;
     by = rowset_row(trows, by - kc * gby);
     const int k0 = (int)((long long)kc * g.nz / ksplit), k1 = (int)((long long)(kc + 1) * g.nz / ksplit);
     const int tx = threadIdx.x, ty = threadIdx.y;
     const int tid = ty * FTI + tx;
-    const int wave = tid >> 6, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int i0 = bx * FTI + 1, j0 = by * TJ + 1;
     const int i = i0 + tx, j = j0 + ty;
     const int P = g.P, nz = g.nz;
     const bool active = (i <= g.nx) && (j <= g.ny);
 
-    // ---- DMA assignment: waves 0..NSL-1 move slice `wave` (64 chunks) of each of the 9 full
-    // tiles; the last two waves move the UWIND / VWIND step-start tiles (ONSL slices each) ----
-    int goff = 0;                       // plane offset of this lane's chunk (full tiles)
+    // ---- DMA assignment: waves 0..NSL-1 move slice `wave` (64 chunks) of each staged field;
+    // the last two waves move the UWIND / VWIND step-start tiles (ONSL slices each) ----
+    const int ch = wave * 64 + lane;                // this lane's chunk (full tiles)
+    int goff = 0;                                   // its plane offset
     bool dma_on = false;
+    int n_issue = 0;                                // DMA instructions this wave issues per level (wave-uniform)
     if (wave < NSL) {
-        const int ch = wave * 64 + lane;
         dma_on = ch < NCH;
         const int e = 2 * (dma_on ? ch : 0), r = e / FTW, c2 = e - r * FTW;
         goff = min(j0 - 1 + r, g.NJ - 1) * P + min(i0 - 2 + c2, P - 2);
+#pragma unroll
+        for (int f = (FROM_WINDS ? 2 : 0); f < FNF; f++)
+            if (wave * 64 < mom_rows(f, TJ, FROM_WINDS) * (FTW / 2)) n_issue++;
     }
     int ooff[ONSL];
     bool oon[ONSL];
@@ -385,41 +457,36 @@ __global__ __launch_bounds__(FTI *TJ) void k_momentum_dma(Geo g, Ptrs p, int gbx
     if (!OLD_IS_CUR && wave >= TJ - 2) {
 #pragma unroll
         for (int s5 = 0; s5 < ONSL; s5++) {
-            const int ch = s5 * 64 + lane;
-            oon[s5] = ch < ONCH;
-            const int e = 2 * (oon[s5] ? ch : 0), r = e / FTW, c2 = e - r * FTW;
+            const int oc = s5 * 64 + lane;
+            oon[s5] = oc < ONCH;
+            const int e = 2 * (oon[s5] ? oc : 0), r = e / FTW, c2 = e - r * FTW;
             ooff[s5] = min(j0 + r, g.NJ - 1) * P + min(i0 - 2 + c2, P - 2);
         }
+        n_issue = ONSL;
     }
     const double *src[FNF] = {p.UFLX, p.VFLX, p.UWIND, p.VWIND, p.WWIND, p.PHI, p.POTT, p.PVTF, p.PVTFVB};
     const int kofs[FNF] = {0, 0, 0, 0, 1, 0, 0, 0, 1};
-    enum { S_UF = 0, S_VF, S_UW, S_VW, S_W, S_PHI, S_POTT, S_PVTF, S_PVB };
     const double *osrc = (wave == TJ - 2) ? u_old : v_old;
 
-    auto issue = [&](int k, int b) {
-        double *buf = dsm + b * BUF;
+    auto issue = [&](int k, int slot) {
+        double *buf = dsm + slot * DSLOT;
         if (wave < NSL) {
             if (dma_on) {
-                // rows a field really needs below j-1: UFLX, winds, WWIND j+1 (TJ+2 rows), VFLX j+2
-                // (all TJ+3), PHI/POTT/PVTF/PVTFVB only j-1 and j (TJ+1): skip the chunks beyond
-                constexpr int rows_f[FNF] = {FROM_WINDS ? 0 : TJ + 2, FROM_WINDS ? 0 : TJ + 3, TJ + 2, FROM_WINDS ? TJ + 3 : TJ + 2,
-                                             TJ + 2, TJ + 1, TJ + 1, TJ + 1, TJ + 1};
-                const int ch = wave * 64 + lane;
 #pragma unroll
-                for (int f = 0; f < FNF; f++) {
-                    if (ch < rows_f[f] * (FTW / 2)) {
+                for (int f = (FROM_WINDS ? 2 : 0); f < FNF; f++) {
+                    if (ch < mom_rows(f, TJ, FROM_WINDS) * (FTW / 2)) {
                         const double *gp = src[f] + (size_t)(k + kofs[f]) * g.plane + goff;
-                        __builtin_amdgcn_global_load_lds((gbl_void_t *)gp, (lds_void_t *)(buf + f * TN + wave * 128), 16, 0, 0);
+                        __builtin_amdgcn_global_load_lds((gbl_void_t *)gp, (lds_void_t *)(buf + mom_off(f, TJ, FROM_WINDS) + wave * 128), 16, 0, DYC_DMA_AUX);
                     }
                 }
             }
         } else if (!OLD_IS_CUR && wave >= TJ - 2) {
-            double *ob = buf + FNF * TN + (wave - (TJ - 2)) * ON;
+            double *ob = buf + OFF_OLD + (wave - (TJ - 2)) * ON;
 #pragma unroll
             for (int s5 = 0; s5 < ONSL; s5++)
                 if (oon[s5]) {
                     const double *gp = osrc + (size_t)k * g.plane + ooff[s5];
-                    __builtin_amdgcn_global_load_lds((gbl_void_t *)gp, (lds_void_t *)(ob + s5 * 128), 16, 0, 0);
+                    __builtin_amdgcn_global_load_lds((gbl_void_t *)gp, (lds_void_t *)(ob + s5 * 128), 16, 0, DYC_DMA_AUX);
                 }
         }
     };
@@ -505,7 +572,8 @@ __global__ __launch_bounds__(FTI *TJ) void k_momentum_dma(Geo g, Ptrs p, int gbx
     double pvb_k = p.PVTFVB[c0], pvb_im1_k = p.PVTFVB[c0 - 1], pvb_jm1_k = p.PVTFVB[c0 - P];
 
     const int lx = tx + 2, ly = ty + 1;   // tile column 0 is longitude i0-2 (16-B aligned in HBM)
-#define SM(f, a, b) buf[(f) * TN + (ly + (b)) * FTW + (lx + (a))]
+    // field f of the level being computed: `db` = its DMA slot, `fb` = its flux slot
+#define SM(f, a, b) ((FROM_WINDS && (f) < 2) ? fb : db)[mom_off(f, TJ, FROM_WINDS) + (ly + (b)) * FTW + (lx + (a))]
 
     // carried across levels
     double su_k = 0.0, sv_k = 0.0;          // six-point COLP_NEW*A*WWIND sums at interface k
@@ -521,88 +589,85 @@ __global__ __launch_bounds__(FTI *TJ) void k_momentum_dma(Geo g, Ptrs p, int gbx
         v_km1 = p.VWIND[c0 - g.plane];
     }
 
-    // vertical 1-D constants -> LDS: a vector-memory load inside the loop would make the compiler
-    // wait vmcnt(0) at its first use and drain the DMA prefetch (cdna_hip_programming.md, section 5)
-    double *cst = dsm + 2 * BUF;
-    // c_wa[k], c_wb[k]: weights of the winds of levels k-1 and k in the dsigma-weighted mean at interface k
-    // (dyn_functions.py:236-241), dsigma[k] / (dsigma[k] + dsigma[k-1]) and dsigma[k-1] / (...); c_rds = 1 / dsigma
-    double *c_wa = cst, *c_svb = cst + DMAXZ, *c_dif = cst + 2 * DMAXZ + 1;
-    double *c_rds = cst + 3 * DMAXZ + 2, *c_wb = cst + 4 * DMAXZ + 2;
-    for (int t = tid; t <= nz; t += NT) {
-        c_svb[t] = p.sigma_vb[t];
-        if (t < nz) {
-            c_dif[t] = p.UVFLX_dif_coef[t];
-            c_rds[t] = 1.0 / p.dsigma[t];
-            const double rsum = t > 0 ? 1.0 / (p.dsigma[t] + p.dsigma[t - 1]) : 0.0;
-            c_wa[t] = p.dsigma[t] * rsum;
-            c_wb[t] = t > 0 ? p.dsigma[t - 1] * rsum : 0.0;
-        }
-    }
-    // 2-D factor tiles, same element -> grid cell map as the DMA chunks
-    double *fac = cst + 5 * DMAXZ + 2;
-    if (FROM_WINDS) {
-        for (int e = tid; e < TN; e += NT) {
+    // per-level constants (p.mom_c, stride nz + 2): weights c_wa[k], c_wb[k] of the winds of levels k-1 and k in the
+    // dsigma-weighted mean at interface k (dyn_functions.py:236-241), dsigma[k] / (dsigma[k] + dsigma[k-1]) and
+    // dsigma[k-1] / (...); c_rds = 1 / dsigma; sigma_vb; UVFLX_dif_coef
+    // Read through the constant address space: the kernel stores through u_out / v_out, so the compiler cannot prove
+    // a plain global load unclobbered and would issue it as a VECTOR load -- whose wait (vmcnt is in order) drains the
+    // DMA prefetch.  Constant-address-space loads at a wave-uniform index are scalar loads (s_load, lgkmcnt).
+    const int cs = nz + 2;
+    typedef const __attribute__((address_space(4))) double cdouble_t;
+    cdouble_t *c_wa = (cdouble_t *)p.mom_c, *c_wb = c_wa + cs, *c_rds = c_wa + 2 * cs, *c_svb = c_wa + 3 * cs, *c_dif = c_wa + 4 * cs;
+    // factors of the flux-tile entries this lane forms (FROM_WINDS), same element -> grid cell map as its DMA chunks
+    double f_uc[2] = {0.0, 0.0}, f_dy[2] = {0.0, 0.0}, f_vc[2] = {0.0, 0.0}, f_dx[2] = {0.0, 0.0};
+    if (FROM_WINDS && wave < NSL && dma_on) {
+#pragma unroll
+        for (int d = 0; d < 2; d++) {
+            const int e = 2 * ch + d;
             const int r = e / FTW, cc = e - r * FTW, c2 = cc & ~1;
             const int gi = min(i0 - 2 + c2, P - 2) + (cc - c2);
             const int o = min(j0 - 1 + r, g.NJ - 1) * P + gi;
-            fac[e] = p.UCOL[o];
+            f_uc[d] = p.UCOL[o];
             // the reference never fills column nx+2 of its x-staggered grid arrays (main_grid.py:317-357):
             // take the periodic image the UFLX halo copy would have delivered
-            fac[TN + e] = p.dyis[gi == g.nx + 2 ? o - g.nx : o];
-            fac[2 * TN + e] = p.VCOL[o];
-            fac[3 * TN + e] = p.dxjs[o];
+            f_dy[d] = p.dyis[gi == g.nx + 2 ? o - g.nx : o];
+            f_vc[d] = p.VCOL[o];
+            f_dx[d] = p.dxjs[o];
         }
     }
-    // flux tiles of a level (FROM_WINDS): every DMA wavefront turns the chunks IT moved into UFLX / VFLX
-    // entries (the unused slots of that buffer) as soon as its own loads have landed -- no barrier
-    // between the DMA and this step, the one at the end of the level publishes both
-    auto flux_own = [&](int b) {
+    // flux tiles of a level (FROM_WINDS): every DMA lane turns the chunks IT moved into UFLX / VFLX
+    // entries as soon as its own loads have landed -- no barrier between the DMA and this step, the one at
+    // the end of the level publishes both
+    auto flux_own = [&](int slot, int fslot) {
         if (FROM_WINDS && wave < NSL && dma_on) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            double *nb = dsm + b * BUF;
-            const int e = 2 * (wave * 64 + lane);
+            const double *nb = dsm + slot * DSLOT;
+            double *nf = dsm + NS * DSLOT + fslot * FSLOT;
+            const int e = 2 * ch;
 #pragma unroll
             for (int d = 0; d < 2; d++) {
-                if (e + d < (TJ + 2) * FTW) nb[S_UF * TN + e + d] = fac[e + d] * nb[S_UW * TN + e + d] * fac[TN + e + d];
-                nb[S_VF * TN + e + d] = fac[2 * TN + e + d] * nb[S_VW * TN + e + d] * fac[3 * TN + e + d];
+                if (e + d < (TJ + 2) * FTW) nf[mom_off(S_UF, TJ, true) + e + d] = f_uc[d] * nb[mom_off(S_UW, TJ, true) + e + d] * f_dy[d];
+                nf[mom_off(S_VF, TJ, true) + e + d] = f_vc[d] * nb[mom_off(S_VW, TJ, true) + e + d] * f_dx[d];
             }
         }
     };
-    issue(k0, k0 & 1);
+    // ---- prologue: the first DEPTH levels go out; level k0 lands and its flux tiles are formed ----
+    issue(k0, 0);
+    if (DEPTH == 2 && k0 + 1 < k1) issue(k0 + 1, 1);
     double tbu_nx = 0.0, tbv_nx = 0.0;  // turbulent tendencies of the next level
     if (TURB) { tbu_nx = p.TURB_U[c + (size_t)k0 * g.plane]; tbv_nx = v_on ? p.TURB_V[c + (size_t)k0 * g.plane] : 0.0; }
-    __syncthreads();                    // factor tiles, constants (and level k0) visible
-    flux_own(k0 & 1);
-    __syncthreads();
+    wait_vmcnt((DEPTH == 2 && k0 + 1 < k1) ? n_issue : 0);
+    flux_own(0, k0 & 1);
+    lds_barrier();
+#ifndef DYC_MOM_MODE
+#define DYC_MOM_MODE 0      // experiment builds only: 1 = data movement without the arithmetic, 2 = arithmetic without the data movement
+#endif
+    int slot = 0;                       // ring slot of level k
 #pragma unroll 1
     for (int k = k0; k < k1; k++) {
-        if (k + 1 < k1) issue(k + 1, (k + 1) & 1);
+        int slot1 = slot + 1;           // ... of level k+1
+        if (slot1 == NS) slot1 = 0;
+        // DEPTH 1: level k+1 goes out first thing.  DEPTH 2: level k+2 goes out after this iteration's two stores
+        // (below), so that every older vector-memory operation of the wave precedes it and `vmcnt(n_issue)` at the
+        // end of the iteration means exactly "level k+1 has landed"
+        if (DEPTH == 1 && k + 1 < k1 && DYC_MOM_MODE != 2) issue(k + 1, slot1);
         const double tbu = tbu_nx, tbv = tbv_nx;
         if (TURB && k + 1 < k1) { tbu_nx = p.TURB_U[c + (size_t)(k + 1) * g.plane]; tbv_nx = v_on ? p.TURB_V[c + (size_t)(k + 1) * g.plane] : 0.0; }
-        const double *buf = dsm + (k & 1) * BUF;
-        if (active) {
-            double uf[3][4], vf[4][3], uw[3][3], vw[3][3];
-#pragma unroll
-            for (int b = 0; b < 3; b++)
-#pragma unroll
-                for (int a = 0; a < 4; a++) uf[b][a] = SM(S_UF, a - 1, b - 1);
-#pragma unroll
-            for (int b = 0; b < 4; b++)
-#pragma unroll
-                for (int a = 0; a < 3; a++) vf[b][a] = SM(S_VF, a - 1, b - 1);
-#pragma unroll
-            for (int b = 0; b < 3; b++)
-#pragma unroll
-                for (int a = 0; a < 3; a++) { uw[b][a] = SM(S_UW, a - 1, b - 1); vw[b][a] = SM(S_VW, a - 1, b - 1); }
-#define UF(a, b) uf[(b) + 1][(a) + 1]
-#define VF(a, b) vf[(b) + 1][(a) + 1]
-#define U(a, b) uw[(b) + 1][(a) + 1]
-#define V(a, b) vw[(b) + 1][(a) + 1]
-            const double u = U(0, 0), v = V(0, 0);
-            double uo = u, vo = v;
+        const double *db = dsm + slot * DSLOT;
+        const double *fb = dsm + NS * DSLOT + (k & 1) * FSLOT;
+        (void)fb;
+        double u = 0.0, v = 0.0, uo = 0.0, vo = 0.0;
+        if (DYC_MOM_MODE == 1) {
+            if (active) {
+                const size_t qm = c + (size_t)k * g.plane;
+                u_out[qm] = SM(S_UW, 0, 0) + SM(S_PHI, 0, 0) + SM(S_UF, 1, 0);
+                if (v_on) v_out[qm] = SM(S_VW, 0, 0) + SM(S_PVB, 0, 0) + SM(S_VF, 0, 1) + (OLD_IS_CUR ? 0.0 : db[OFF_OLD + ty * FTW + lx] + db[OFF_OLD + ON + ty * FTW + lx]);
+            }
+        } else if (active) {
+            u = SM(S_UW, 0, 0); v = SM(S_VW, 0, 0);
+            uo = u; vo = v;
             if (!OLD_IS_CUR) {
-                uo = buf[FNF * TN + ty * FTW + lx];
-                vo = buf[FNF * TN + ON + ty * FTW + lx];
+                uo = db[OFF_OLD + ty * FTW + lx];
+                vo = db[OFF_OLD + ON + ty * FTW + lx];
             }
             // ---- interface k closes level k-1 ----
             if (k >= 1) {
@@ -621,6 +686,33 @@ __global__ __launch_bounds__(FTI *TJ) void k_momentum_dma(Geo g, Ptrs p, int gbx
                 }
                 wu_km1 = wu_k; wv_km1 = wv_k;
             }
+        }
+        if (DEPTH == 2) {
+            asm volatile("" ::: "memory");      // the stores above stay above the DMA below
+            if (k + 2 < k1 && DYC_MOM_MODE != 2) {
+                int slot2 = slot1 + 1;
+                if (slot2 == NS) slot2 = 0;
+                issue(k + 2, slot2);
+            }
+        }
+        if (DYC_MOM_MODE != 1 && active) {
+            double uf[3][4], vf[4][3], uw[3][3], vw[3][3];
+#pragma unroll
+            for (int b = 0; b < 3; b++)
+#pragma unroll
+                for (int a = 0; a < 4; a++) uf[b][a] = SM(S_UF, a - 1, b - 1);
+#pragma unroll
+            for (int b = 0; b < 4; b++)
+#pragma unroll
+                for (int a = 0; a < 3; a++) vf[b][a] = SM(S_VF, a - 1, b - 1);
+#pragma unroll
+            for (int b = 0; b < 3; b++)
+#pragma unroll
+                for (int a = 0; a < 3; a++) { uw[b][a] = SM(S_UW, a - 1, b - 1); vw[b][a] = SM(S_VW, a - 1, b - 1); }
+#define UF(a, b) uf[(b) + 1][(a) + 1]
+#define VF(a, b) vf[(b) + 1][(a) + 1]
+#define U(a, b) uw[(b) + 1][(a) + 1]
+#define V(a, b) vw[(b) + 1][(a) + 1]
             // ---- six-point sums at interface k+1 (dyn_functions.py:211-270) ----
             if (k + 1 < nz) {
                 const double w_c = SM(S_W, 0, 0), w_w = SM(S_W, -1, 0), w_s = SM(S_W, 0, -1), w_sw = SM(S_W, -1, -1);
@@ -629,6 +721,7 @@ __global__ __launch_bounds__(FTI *TJ) void k_momentum_dma(Geo g, Ptrs p, int gbx
             }
             const double svb = c_svb[k], svb1 = c_svb[k + 1];
             const double dif = c_dif[k];
+            const double rds = c_rds[k];
             const double pvb_kp1 = SM(S_PVB, 0, 0), pvb_im1_kp1 = SM(S_PVB, -1, 0), pvb_jm1_kp1 = SM(S_PVB, 0, -1);
             const double phi = SM(S_PHI, 0, 0), pott = SM(S_POTT, 0, 0), pvtf = SM(S_PVTF, 0, 0);
             // ---- the sixteen Arakawa-C flux means B,C,D,E / R,Q,S,T (dyn_UVFLX_prepare.py:249-439) from shared pair
@@ -643,7 +736,7 @@ __global__ __launch_bounds__(FTI *TJ) void k_momentum_dma(Geo g, Ptrs p, int gbx
             const double gy_m_0 = VF(-1, 0) + VF(-1, 1), gy_0_0 = VF(0, 0) + VF(0, 1), gy_p_0 = VF(1, 0) + VF(1, 1);
             const double gy_m_p = VF(-1, 1) + VF(-1, 2), gy_0_p = VF(0, 1) + VF(0, 2);
             constexpr double W24 = 1.0 / 24.0, W48 = 1.0 / 48.0;
-            const double prs = pott * c_rds[k];            // POTT / dsigma of the own cell (pressure-gradient terms)
+            const double prs = pott * rds;                 // POTT / dsigma of the own cell (pressure-gradient terms)
             const double own = svb1 * (pvb_kp1 - pvtf) + svb * (pvtf - pvb_k);
             // =============================== dUFLXdt (level k, without vertical advection) ====
             {
@@ -668,7 +761,7 @@ __global__ __launch_bounds__(FTI *TJ) void k_momentum_dma(Geo g, Ptrs p, int gbx
                 // pressure gradient (dyn_functions.py:177-207) with the per-column factors pg_a = -dy (COLP + COLP[i-1]) / 2,
                 // pg_b = -dy (COLP - COLP[i-1]) cp / 2 formed once and POTT / dsigma as POTT * (1 / dsigma)
                 t = t + ((phi - SM(S_PHI, -1, 0)) * pgu_a +
-                         pgu_b * ((SM(S_POTT, -1, 0) * c_rds[k]) * (svb1 * (pvb_im1_kp1 - SM(S_PVTF, -1, 0)) + svb * (SM(S_PVTF, -1, 0) - pvb_im1_k)) +
+                         pgu_b * ((SM(S_POTT, -1, 0) * rds) * (svb1 * (pvb_im1_kp1 - SM(S_PVTF, -1, 0)) + svb * (SM(S_PVTF, -1, 0) - pvb_im1_k)) +
                                   prs * own));
                 t = t + dif * (UF(-1, 0) + UF(1, 0) + UF(0, -1) + UF(0, 1) - 4.0 * UF(0, 0));      // dif >= 0; 0 adds nothing
                 if (TURB) t = t + tbu;
@@ -693,7 +786,7 @@ __global__ __launch_bounds__(FTI *TJ) void k_momentum_dma(Geo g, Ptrs p, int gbx
                 const double us_jm1 = U(0, -1) + U(1, -1), us = U(0, 0) + U(1, 0);
                 t = t + (cov_jm1 * us_jm1 * (kc_jm1 + us_jm1 * hsin_jm1) + cov_c * us * (kc_c + us * hsin_c));
                 t = t + ((phi - SM(S_PHI, 0, -1)) * pgv_a +
-                         pgv_b * ((SM(S_POTT, 0, -1) * c_rds[k]) * (svb1 * (pvb_jm1_kp1 - SM(S_PVTF, 0, -1)) + svb * (SM(S_PVTF, 0, -1) - pvb_jm1_k)) +
+                         pgv_b * ((SM(S_POTT, 0, -1) * rds) * (svb1 * (pvb_jm1_kp1 - SM(S_PVTF, 0, -1)) + svb * (SM(S_PVTF, 0, -1) - pvb_jm1_k)) +
                                   prs * own));
                 t = t + dif * (VF(-1, 0) + VF(1, 0) + VF(0, -1) + VF(0, 1) - 4.0 * VF(0, 0));
                 if (TURB) t = t + tbv;
@@ -706,8 +799,13 @@ __global__ __launch_bounds__(FTI *TJ) void k_momentum_dma(Geo g, Ptrs p, int gbx
             u_km1 = u; v_km1 = v; uo_km1 = uo; vo_km1 = vo;
             pvb_k = pvb_kp1; pvb_im1_k = pvb_im1_kp1; pvb_jm1_k = pvb_jm1_kp1;
         }
-        if (k + 1 < k1) flux_own((k + 1) & 1);
-        __syncthreads();       // level k+1 has landed for every wave; buffer k&1 is free again
+        // this wave's part of level k+1 has landed (the deeper prefetch stays in flight); form its flux entries
+        if (k + 1 < k1 && DYC_MOM_MODE != 2) {
+            wait_vmcnt((DEPTH == 2 && k + 2 < k1) ? n_issue : 0);
+            flux_own(slot1, (k + 1) & 1);
+        }
+        lds_barrier();         // level k+1 is in LDS for every wave; slot `slot` is free again
+        slot = slot1;
     }
     // ---- the last level of the chunk: its lower interface is k1 (WWIND*U = 0 at the surface) ----
     if (active) {
@@ -722,7 +820,6 @@ __global__ __launch_bounds__(FTI *TJ) void k_momentum_dma(Geo g, Ptrs p, int gbx
     }
 #undef SM
 }
-
 // ------------------------------------------------------------------------------------
 // k_turb_tendencies: the vertical-turbulence terms of the momentum, temperature and moisture
 // tendencies for the fused step of a turbulence-coupled handle (i_turb), evaluated once per substep

@@ -38,6 +38,8 @@ ABI_SYMBOLS = [
     'dycore_step_begin', 'dycore_substep_part', 'dycore_use_stream', 'dycore_get_stream', 'dycore_overlap_parts', 'dycore_flux_from_winds', 'dycore_rows_size', 'dycore_pack_rows',
     'dycore_unpack_rows', 'dycore_substep_field',
     'dycore_profile', 'dycore_n_kernels', 'dycore_kernel_stats',
+    'dycore_bands_unique_id', 'dycore_bands_create_rccl', 'dycore_bands_create_local', 'dycore_bands_connect',
+    'dycore_bands_step_matsuno', 'dycore_bands_destroy',
 ]
 
 _lib = None
@@ -121,6 +123,12 @@ def load_library(path=None):
     lib.dycore_rows_size.argtypes = [hp, C.c_int32, cpp, C.POINTER(C.c_int64)]
     lib.dycore_pack_rows.argtypes = [hp, C.c_int32, cpp, C.POINTER(C.c_int32), C.c_void_p]
     lib.dycore_unpack_rows.argtypes = [hp, C.c_int32, cpp, C.POINTER(C.c_int32), C.c_void_p]
+    lib.dycore_bands_unique_id.argtypes = [C.c_void_p, C.c_int32]
+    lib.dycore_bands_create_rccl.argtypes = [hp, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(hp)]
+    lib.dycore_bands_create_local.argtypes = [C.POINTER(hp), C.c_int32, C.POINTER(hp)]
+    lib.dycore_bands_connect.argtypes = [hp]
+    lib.dycore_bands_step_matsuno.argtypes = [hp, C.c_double, C.c_int32, C.c_int32]
+    lib.dycore_bands_destroy.argtypes = [hp]
     lib.dycore_profile.argtypes = [hp, C.c_int32]
     lib.dycore_kernel_stats.argtypes = [hp, C.c_int32, C.POINTER(C.c_char_p), C.POINTER(C.c_int64),
                                         C.POINTER(C.c_double)]
@@ -344,3 +352,69 @@ class HipDycore:
             self._check(self.lib.dycore_kernel_stats(self._h, idx, C.byref(name), C.byref(n), C.byref(ms)))
             out[name.value.decode()] = (n.value, ms.value)
         return out
+
+
+UNIQUE_ID_BYTES = 128       # sizeof(ncclUniqueId)
+
+
+def bands_unique_id():
+    """The 128-byte RCCL rendezvous id (rank 0 obtains it, every rank passes it to NativeBands.rccl)."""
+    lib = load_library()
+    buf = C.create_string_buffer(UNIQUE_ID_BYTES)
+    rc = lib.dycore_bands_unique_id(buf, UNIQUE_ID_BYTES)
+    if rc != 0:
+        raise DycoreError('libdycore_hip: %s (code %d)' % (lib.dycore_last_error().decode(), rc))
+    return buf.raw
+
+
+class NativeBands:
+    """The band step inside the library (include/dycore.h, dycore_bands_*): schedule, packing, streams, events and
+    the transport -- RCCL send / recv, or device copies between the bands of one process -- behind one call per
+    step sequence."""
+
+    def __init__(self, lib, handle, cores):
+        self.lib, self._b, self.cores = lib, handle, cores
+
+    @classmethod
+    def local(cls, cores):
+        lib = load_library()
+        arr = (C.c_void_p * len(cores))(*[c._h for c in cores])
+        b = C.c_void_p()
+        rc = lib.dycore_bands_create_local(arr, len(cores), C.byref(b))
+        if rc != 0:
+            raise DycoreError('libdycore_hip: %s (code %d)' % (lib.dycore_last_error().decode(), rc))
+        return cls(lib, b, list(cores))
+
+    @classmethod
+    def rccl(cls, core, unique_id, rank, nranks, south, north):
+        lib = load_library()
+        if len(unique_id) != UNIQUE_ID_BYTES:
+            raise ValueError('the RCCL id has %d bytes' % UNIQUE_ID_BYTES)
+        b = C.c_void_p()
+        rc = lib.dycore_bands_create_rccl(core._h, C.c_char_p(bytes(unique_id)), UNIQUE_ID_BYTES, int(rank), int(nranks),
+                                          -1 if south is None else int(south), -1 if north is None else int(north), C.byref(b))
+        if rc != 0:
+            raise DycoreError('libdycore_hip: %s (code %d)' % (lib.dycore_last_error().decode(), rc))
+        return cls(lib, b, [core])
+
+    def _check(self, rc):
+        if rc != 0:
+            raise DycoreError('libdycore_hip: %s (code %d)' % (self.lib.dycore_last_error().decode(), rc))
+
+    def connect(self):
+        self._check(self.lib.dycore_bands_connect(self._b))
+
+    def step_matsuno(self, dt, nsteps=1, with_rho=None):
+        with_rho = self.cores[0].i_turb if with_rho is None else with_rho
+        self._check(self.lib.dycore_bands_step_matsuno(self._b, float(dt), int(nsteps), int(bool(with_rho))))
+
+    def close(self):
+        if getattr(self, '_b', None) and self._b.value:
+            self.lib.dycore_bands_destroy(self._b)
+            self._b = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

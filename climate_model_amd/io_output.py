@@ -73,8 +73,10 @@ def _put(ncf, name, dims, data):
     v[0] = np.asarray(data, dtype=np.float32)
 
 
-def output_to_NC(GR, F, output_path, count=None, output_fields=None, i_radiation=None):
-    """io_nc_output.py:30-317.  Downloads what it writes; returns the file name."""
+def output_to_NC(GR, F, output_path, count=None, output_fields=None, i_radiation=None, refresh_diag=True):
+    """io_nc_output.py:30-317.  Downloads what it writes; returns the file name.  `refresh_diag`: re-diagnose TAIR,
+    PAIR, RHO, WIND from the current state first; the reference writes what the loop's last secondary_diag call left
+    (the state before the last step's dynamics, solver.py:98-101 vs :152-164), which is what solver.run asks for."""
     of = dict(OUTPUT_FIELDS if output_fields is None else output_fields)
     i_radiation = GR.nl.i_radiation if i_radiation is None else i_radiation
     count = getattr(GR, 'nc_output_count', 0) + 1 if count is None else count      # solver.py:162
@@ -85,7 +87,8 @@ def output_to_NC(GR, F, output_path, count=None, output_fields=None, i_radiation
         want |= set(RADIATION_OUT) | {'dPOTTdt_RAD'}
     if not moist:
         want -= {'QV', 'QC', 'dQVdt', 'dQVdt_TURB'}
-    core.secondary_diag()
+    if refresh_diag:
+        core.secondary_diag()
     for n in sorted(want):
         core.download(n, F.host[n])
     h = F.host

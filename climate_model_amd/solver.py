@@ -150,7 +150,7 @@ def run(GR, F, nts, nth_ts_print_diag=None, fused=True, fused_steps=1, out=print
 
         if out_nth_ts and GR.ts % out_nth_ts == 0:      # solver.py:152-164: the counter first, then the file
             GR.timer.start('IO')
-            io_output.output_to_NC(GR, F, output_path, count=GR.nc_output_count + 1)
+            io_output.output_to_NC(GR, F, output_path, count=GR.nc_output_count + 1, refresh_diag=False)
             GR.timer.stop('IO')
         if rst_nth_ts and GR.ts % rst_nth_ts == 0:
             GR.timer.start('IO')

@@ -186,6 +186,32 @@ int dycore_pack_rows(dycore_t *h, int32_t n, const char *const *names, const int
 int dycore_unpack_rows(dycore_t *h, int32_t n, const char *const *names, const int32_t *rows,
                        const void *dev_buf);
 
+/* ---- the band step inside the library ------------------------------------------------
+ * The schedule above (continuity, exchange AB2 behind the inner momentum tiles, edge tiles, exchange B1 behind the
+ * temperature kernel, ...) issued by ONE call per step sequence, with the transport inside the library:
+ *   dycore_bands_create_rccl   one band per process / GPU; neighbour exchange = ncclSend / ncclRecv (RCCL over xGMI)
+ *                              on the library's comm stream.  `id` = the 128 bytes rank 0 obtained from
+ *                              dycore_bands_unique_id and passed to every rank by whatever bootstrap the host has
+ *                              (torch.distributed, MPI, a file); south_rank / north_rank = the ranks holding the
+ *                              adjacent bands, -1 on the side where this band touches a pole.  librccl.so is
+ *                              resolved at run time (dlopen), so a single-GPU host does not need it.
+ *   dycore_bands_create_local  all bands are handles of THIS process on one stream (south to north); exchange =
+ *                              device-to-device copies.  Rehearsal of the same schedule on one GPU.
+ *   dycore_bands_connect       one transport of the send buffers, nothing unpacked (peer connections up before a
+ *                              timed region); every rank calls it.
+ *   dycore_bands_step_matsuno  nsteps Matsuno steps; returns with every halo row of the final state in place and
+ *                              the comm stream joined into the handles' stream.
+ * Needs handles whose step is the fused one with split parts (dycore_overlap_parts, dycore_flux_from_winds != 0).
+ * An N-band run equals the single-domain run bit for bit. */
+typedef struct dycore_bands dycore_bands_t;
+int dycore_bands_unique_id(void *id, int32_t nbytes);                 /* nbytes = 128 */
+int dycore_bands_create_rccl(dycore_t *h, const void *id, int32_t nbytes, int32_t rank, int32_t nranks,
+                             int32_t south_rank, int32_t north_rank, dycore_bands_t **out);
+int dycore_bands_create_local(dycore_t *const *handles, int32_t n, dycore_bands_t **out);
+int dycore_bands_connect(dycore_bands_t *b);
+int dycore_bands_step_matsuno(dycore_bands_t *b, double dt, int32_t nsteps, int32_t with_rho);
+int dycore_bands_destroy(dycore_bands_t *b);
+
 /* ---- measurement ------------------------------------------------------------------- */
 /* Runs nsteps Matsuno steps bracketed by HIP events on the handle's stream and returns
  * the elapsed device time in milliseconds (synchronises). */

@@ -53,12 +53,17 @@ def _single(GR, state, i_turb, nsteps, i_moist=0, check=None):
     return out
 
 
-@pytest.mark.parametrize('overlap', [False, True])
+@pytest.mark.parametrize('overlap', [False, True, 'native'])
 @pytest.mark.parametrize('nbands', [2, 3, 5])
 @pytest.mark.parametrize('i_turb,i_moist', [(0, 0), (1, 0), (0, 1), (1, 1)])
 def test_local_bands_bitwise_equal_single(nbands, i_turb, i_moist, overlap):
     """overlap=True: the exchanges run on a second stream behind the inner rows (the schedule of
-    the multi-GPU run); overlap=False: plain part / exchange sequence with host synchronisation."""
+    the multi-GPU run); overlap=False: plain part / exchange sequence with host synchronisation;
+    'native': the same overlapped schedule issued by the library itself (dycore_bands_step_matsuno)."""
+    native = overlap == 'native'
+    if native and i_turb:
+        pytest.skip('the in-library band step covers the fused dry / moist step')
+    overlap = bool(overlap)
     import torch
     stream = torch.cuda.Stream()
     GR, state = _initial_state(4, 8, i_turb, i_moist)
@@ -74,9 +79,11 @@ def test_local_bands_bitwise_equal_single(nbands, i_turb, i_moist, overlap):
             c.upload(n, L.slice_rows(a, r, FIELD_TABLE[n][1]))
         c.primary_diag()
         cores.append(c)
-    lb = LocalBands(cores, L, torch.device('cuda:0'), overlap=overlap)
+    lb = LocalBands(cores, L, torch.device('cuda:0'), overlap=overlap, native=native)
     assert lb.overlap == (overlap and not i_turb)     # the staged (turbulence-coupled) step is not split
-    lb.step_matsuno(GR.dt, 3)
+    assert (lb.native is not None) == native
+    lb.step_matsuno(GR.dt, 2)
+    lb.step_matsuno(GR.dt, 1)          # a second call continues from halo rows the first one left in place
     for n in check:
         got = gather_global(L, [c.download(n) for c in cores], n)
         np.testing.assert_array_equal(got, ref[n], err_msg='%s incl. halos (%d bands)' % (n, nbands))
@@ -132,6 +139,16 @@ def test_bench_self_launch_propagates_failure():
     cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '0', '--dlat', '90', '--nz', '4']
     r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert r.returncode != 0
+
+
+@pytest.mark.parametrize('i_moist', [0, 1])
+def test_native_band_step_over_rccl(i_moist):
+    """dycore_bands_create_rccl / dycore_bands_step_matsuno: ncclSend / ncclRecv issued by the library on its comm
+    stream (tests/native_rccl_worker.py: a band that is its own neighbour, against the device-copy transport)."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'tests', 'native_rccl_worker.py'), str(i_moist)], env=env, cwd=ROOT,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and 'NATIVE_RCCL_OK' in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
 
 
 def test_rccl_transport_self_exchange():

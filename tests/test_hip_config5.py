@@ -151,8 +151,9 @@ def test_turbulent_moist_full_size_vs_oracle():
     core.close()
 
 
+@pytest.mark.parametrize('native', [False, True])
 @pytest.mark.parametrize('i_moist', [0, 1])
-def test_eight_bands_full_size_bitwise(i_moist):
+def test_eight_bands_full_size_bitwise(i_moist, native):
     """0.25 deg x 64 cut into 8 latitude bands of 90 rows (the decomposition of BASELINE configs 4 / 5): two
     steps on the overlapped schedule = the single-domain run, bit for bit."""
     import torch
@@ -185,8 +186,8 @@ def test_eight_bands_full_size_bitwise(i_moist):
             c.upload(n, L.slice_rows(F.host[n], r, FIELD_TABLE[n][1]))
         c.primary_diag()
         cores.append(c)
-    lb = LocalBands(cores, L, torch.device('cuda:0'), overlap=True)
-    assert lb.overlap
+    lb = LocalBands(cores, L, torch.device('cuda:0'), overlap=True, native=native)
+    assert lb.overlap and (lb.native is not None) == native
     lb.step_matsuno(GR.dt, 2)
     for n in check:
         got = gather_global(L, [c.download(n) for c in cores], n)

@@ -325,7 +325,8 @@ def main():
         'config': {'workload': ('moist (QV, QC advected) ' if args.moist else 'dry ') + ('with radiative heating ' if args.radiation else '') + 'hydrostatic dycore, Matsuno step, %g deg lat-lon (%d x %d) x %d sigma levels, '
                                'dt=%.4g s' % (args.dlat, GR.nx, GR.ny, GR.nz, GR.dt),
                    'cells': cells, 'parallelism': 'latitude bands x%d' % world if world > 1 else 'single GPU',
-                   'exchange': ('overlapped, 2 per substep' if bands.overlap else 'plain, 2 per substep') if bands is not None else None},
+                   'exchange': (('overlapped, 2 per substep' if bands.overlap else 'plain, 2 per substep') +
+                                (', RCCL send/recv issued by the library' if getattr(bands, 'native', None) is not None else ', torch.distributed P2P')) if bands is not None else None},
         'roofline': roof,
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.moist and not args.radiation:

@@ -287,10 +287,17 @@ class DistributedBands:
             native = os.environ.get('DYCORE_BANDS_NATIVE', '1') != '0'
         if (native and str(device) != 'cpu' and dist.get_backend(group) == 'nccl' and getattr(core, 'overlap_parts', False)
                 and getattr(core, 'flux_from_winds', False) and layout.nbands > 1):
-            from .hip_backend import NativeBands, bands_unique_id
-            ids = [bands_unique_id() if rank == 0 else None]
+            from .hip_backend import NativeBands, bands_unique_id, DycoreError
+            ids = [None]
+            if rank == 0:
+                try:
+                    ids = [bands_unique_id()]
+                except DycoreError as e:        # no usable librccl: every rank falls back together
+                    import sys
+                    print('climate_model_amd.bands: in-library RCCL transport unavailable (%s); using torch.distributed' % e, file=sys.stderr)
             dist.broadcast_object_list(ids, src=0, group=group)
-            self.native = NativeBands.rccl(core, ids[0], rank, layout.nbands, self.south, self.north)
+            if ids[0] is not None:
+                self.native = NativeBands.rccl(core, ids[0], rank, layout.nbands, self.south, self.north)
         self.halo = BandHalo(core, layout.ny(rank), self.south is not None, self.north is not None)
         self.bufs = _TorchBuffers(self.halo, device)
         on_gpu = str(device) != 'cpu'

@@ -136,12 +136,14 @@ struct dycore {
     std::vector<double> h_dsigma, h_sigma_vb, h_uvdif;      // host copies of the vertical grid (-> Ptrs::mom_c)
     size_t stage_elems = 0;
     int grid_set = 0;
+    bool zonal = true;              // lat_rad, lat_is_rad, corf, corf_is do not vary along a row (the fused momentum kernel keeps them per wavefront)
     bool fused = true;              // production kernels in dycore_step_matsuno (DYCORE_FUSED=0: stage kernels)
     bool lazy = true;               // fused step leaves FLXDIV / PHIVB to be derived on demand (DYCORE_LAZY=0: store them)
     bool fused_turb = true;         // DYCORE_FUSED_TURB=0: a turbulence-coupled handle steps on the stage kernels
     int fw_mask = 7;                // DYCORE_FW_MASK (debug): 1 continuity stores no fluxes, 2 momentum, 4 temperature/moisture re-form them
     bool lazy_flx = true;           // ... nor UFLX / VFLX: consumers re-form them from the winds (DYCORE_LAZY_FLX=0: store them)
-    bool stale_flxdiv = false, stale_phivb = false, stale_uvflx = false;
+    bool stale_flxdiv = false, stale_phivb = false, stale_uvflx = false, stale_pvtf = false;
+    bool lazy_pvtf = true;          // ... nor PVTF (DYCORE_LAZY_PVTF=0: store it); only where the momentum kernel forms its own (flux_from_winds, no i_turb)
     const double *flx_u = nullptr, *flx_v = nullptr;   // winds the last fused continuity evaluated on
     bool winds_bc_dirty = true;     // UWIND / VWIND came from the host: their lateral BC images (column nx+2!) may be unset
     int n_cu = 256;                 // compute units of the device
@@ -228,7 +230,7 @@ int check_ready(dycore *h)
 }
 
 int join_side(dycore *h);
-enum { LAZY_FLX = 1, LAZY_FLXDIV = 2, LAZY_PHIVB = 4, LAZY_ALL = 7 };
+enum { LAZY_FLX = 1, LAZY_FLXDIV = 2, LAZY_PHIVB = 4, LAZY_PVTF = 8, LAZY_ALL = 15 };
 int refresh_lazy(dycore *h, int need = LAZY_ALL);
 // stage entry points read what the side stream may still be writing and what the fused step
 // left to be derived (`need`: which of the derived fields the stage reads)
@@ -342,6 +344,7 @@ int do_diag(dycore *h, const Ptrs &p)
 {
     Scope s(h, K_DIAG);
     hipLaunchKernelGGL(k_primary_diag, grid_for(h->g, h->g.nx + 2, h->g.ny + 2), dim3(TI, TJ), 0, h->stream, h->g, p);
+    if (&p == &h->p || p.PVTF == h->p.PVTF) { h->stale_pvtf = false; h->stale_phivb = false; }      // it writes both, whole array
     return launch_check("k_primary_diag");
 }
 int do_rho(dycore *h, const Ptrs &p)
@@ -382,6 +385,12 @@ bool flux_from_winds(const dycore *h)
 {
     const int nz = h->g.nz;
     return h->lazy && h->lazy_flx && h->mom_dma == 1 && nz <= DMAXZ && (nz == 8 || nz == 16 || nz == 32 || nz == 64);
+}
+// the fused step leaves PVTF to be derived on demand: only where every kernel of that step that needs it forms its own
+// (LDS-DMA momentum kernel on fluxes re-formed from the winds, no turbulence coupling, every re-forming switch on)
+bool pvtf_on_demand(const dycore *h)
+{
+    return h->lazy && h->lazy_pvtf && !h->g.i_turb && flux_from_winds(h) && h->fw_mask == 7;
 }
 int do_continuity_fused(dycore *h, const Ptrs &p, double dt)
 {
@@ -425,9 +434,10 @@ int do_continuity_fused(dycore *h, const Ptrs &p, double dt)
 int refresh_lazy(dycore *h, int need)
 {
     if (need & LAZY_FLXDIV) need |= LAZY_FLX;          // FLXDIV is derived from UFLX, VFLX
+    if ((need & LAZY_PHIVB) && h->stale_phivb) need |= LAZY_PVTF;      // PHIVB from PHI, POTT, PVTFVB and PVTF
     const bool d_flx = h->stale_uvflx && (need & LAZY_FLX), d_div = h->stale_flxdiv && (need & LAZY_FLXDIV),
-               d_phivb = h->stale_phivb && (need & LAZY_PHIVB);
-    if (!d_flx && !d_div && !d_phivb) return 0;
+               d_phivb = h->stale_phivb && (need & LAZY_PHIVB), d_pvtf = h->stale_pvtf && (need & LAZY_PVTF);
+    if (!d_flx && !d_div && !d_phivb && !d_pvtf) return 0;
     int rc = join_side(h);
     if (rc) return rc;
     Scope s(h, K_DERIVE);
@@ -441,6 +451,11 @@ int refresh_lazy(dycore *h, int need)
         hipLaunchKernelGGL(k_derive_flxdiv, grid_for(h->g, h->g.nx, h->g.ny), dim3(TI, TJ), 0, h->stream, h->g, h->p);
         if ((rc = launch_check("k_derive_flxdiv"))) return rc;
         h->stale_flxdiv = false;
+    }
+    if (d_pvtf) {
+        hipLaunchKernelGGL(k_derive_pvtf, grid_for(h->g, h->g.nx + 2, h->g.ny + 2), dim3(TI, TJ), 0, h->stream, h->g, h->p);
+        if ((rc = launch_check("k_derive_pvtf"))) return rc;
+        h->stale_pvtf = false;
     }
     if (d_phivb) {
         hipLaunchKernelGGL(k_derive_phivb, grid_for(h->g, h->g.nx + 2, h->g.ny + 2), dim3(TI, TJ), 0, h->stream, h->g, h->p);
@@ -475,6 +490,10 @@ int do_momentum_fused(dycore *h, const Ptrs &p, const double *u_old, const doubl
     if (!dma) {
         if (mode == ROWS_INNER) return 0;
         mode = ROWS_ALL;
+    }
+    if (!(dma && flux_from_winds(h) && (h->fw_mask & 2))) {       // every other momentum kernel reads the stored PVTF
+        int rc = refresh_lazy(h, LAZY_PVTF);
+        if (rc) return rc;
     }
     Scope s(h, dma ? K_MOM_DMA : K_MOM_FUSED);      // stats under the name of the kernel that runs
     const int gbx = (h->g.nx + FTI - 1) / FTI, gby = (h->g.ny + FTJ - 1) / FTJ;
@@ -556,15 +575,16 @@ int do_pott_fused(dycore *h, const Ptrs &p, const double *pott_old, double *pott
     Scope s(h, K_POTT_FUSED);
     const dim3 gr = grid_cells(h), bl(TI, TJ);
     const int lin = cells_linear(h);
-#define POTT_LAUNCH(W_, F_, T_) hipLaunchKernelGGL((k_pott_fused<W_, F_, T_>), gr, bl, 0, h->stream, h->g, p, pott_old, pott_out, dt, lin)
+#define POTT_LAUNCH(W_, F_, T_, V_) hipLaunchKernelGGL((k_pott_fused<W_, F_, T_, V_>), gr, bl, 0, h->stream, h->g, p, pott_old, pott_out, dt, lin)
     if (h->g.i_turb) {                  // fused turbulence-coupled step: PHIVB is an input of k_turb_tendencies, so it is stored
-        POTT_LAUNCH(true, true, true);
+        POTT_LAUNCH(true, true, true, true);
     } else if (h->lazy) {
-        if (flux_from_winds(h) && (h->fw_mask & 4)) POTT_LAUNCH(false, true, false);
-        else POTT_LAUNCH(false, false, false);
+        if (pvtf_on_demand(h)) { POTT_LAUNCH(false, true, false, false); h->stale_pvtf = true; }
+        else if (flux_from_winds(h) && (h->fw_mask & 4)) POTT_LAUNCH(false, true, false, true);
+        else POTT_LAUNCH(false, false, false, true);
         h->stale_phivb = true;
     } else
-        POTT_LAUNCH(true, false, false);
+        POTT_LAUNCH(true, false, false, true);
 #undef POTT_LAUNCH
     return launch_check("k_pott_fused");
 }
@@ -652,7 +672,7 @@ int do_momentum(dycore *h, const Ptrs &p)
 // neighbours (after continuity, after the Euler step); a single band runs them back to back.
 // the turbulence-coupled fused step needs the kernels that re-form the fluxes from the winds (LDS-DMA
 // momentum, register continuity); otherwise an i_turb handle steps on the stage kernels
-bool fused_path(const dycore *h) { return h->fused && (!h->g.i_turb || (h->fused_turb && flux_from_winds(h) && h->fw_mask == 7)); }
+bool fused_path(const dycore *h) { return h->fused && h->zonal && (!h->g.i_turb || (h->fused_turb && flux_from_winds(h) && h->fw_mask == 7)); }
 
 // Fused (production, dry) scheme -- no time-level swaps: X holds the state S0 at step start
 // through the predictor, X_EST receives the estimate S1, the corrector evaluates on X_EST and
@@ -664,7 +684,7 @@ int step_begin(dycore *h, int with_rho)
 {
     int rc;
     Ptrs &p = h->p;
-    if (with_rho && ((rc = join_side(h)) || (rc = do_rho(h, p)))) return rc;
+    if (with_rho && ((rc = join_side(h)) || (rc = refresh_lazy(h, LAZY_PVTF)) || (rc = do_rho(h, p)))) return rc;
     if (fused_path(h)) {
         if (h->g.i_turb) {
             // dyn_org_discretizations.py:195-196, 212-216: lateral BC of the K field and the surface momentum
@@ -730,8 +750,8 @@ int substep_part(dycore *h, double dt, int sub, int part)
             if (h->g.i_moist && (rc = do_moist(h, q, p.QV, p.QC, qv_out, qc_out, dt))) return rc;
             const int nz = h->g.nz;
             if (h->g.i_moist && (rc = do_halo(h, {{qv_out, 0, 0, nz}, {qc_out, 0, 0, nz}}))) return rc;
-            std::vector<HaloSpec> hl = {{t_out, 0, 0, nz}, {p.PVTF, 0, 0, nz}, {p.PVTFVB, 0, 0, nz + 1},
-                                        {p.PHI, 0, 0, nz}, {p.POTTVB, 0, 0, nz + 1}};
+            std::vector<HaloSpec> hl = {{t_out, 0, 0, nz}, {p.PVTFVB, 0, 0, nz + 1}, {p.PHI, 0, 0, nz}, {p.POTTVB, 0, 0, nz + 1}};
+            if (!pvtf_on_demand(h)) hl.push_back({p.PVTF, 0, 0, nz});
             if (!h->lazy || h->g.i_turb) hl.push_back({p.PHIVB, 0, 0, nz + 1});
             hl.push_back({u_out, 1, 0, nz});   // owned rows and pole rows only: rows in flight from a neighbour are not touched
             hl.push_back({v_out, 0, 1, nz});
@@ -817,6 +837,7 @@ int dycore_create(const DycoreConfig *cfg, dycore_t **out)
     if (const char *e = getenv("DYCORE_MOM_DMA")) h->mom_dma = atoi(e);
     if (const char *e = getenv("DYCORE_LAZY")) h->lazy = atoi(e) != 0;
     if (const char *e = getenv("DYCORE_LAZY_FLX")) h->lazy_flx = atoi(e) != 0;
+    if (const char *e = getenv("DYCORE_LAZY_PVTF")) h->lazy_pvtf = atoi(e) != 0;
     if (const char *e = getenv("DYCORE_FUSED_TURB")) h->fused_turb = atoi(e) != 0;
     if (const char *e = getenv("DYCORE_FW_MASK")) h->fw_mask = atoi(e);
     if (const char *e = getenv("DYCORE_MOM_KS")) h->mom_ks = atoi(e);
@@ -1006,6 +1027,13 @@ int dycore_set_grid(dycore_t *h, const char *name, const double *host, int32_t n
         if (n0 != e0 || n1 != e1 || n2 != 1)
             return fail(DYCORE_EINVAL, "grid array '%s': expected shape (%d,%d,1), got (%d,%d,%d)", name, e0, e1, n0, n1, n2);
         const size_t n = (size_t)n0 * n1;
+        if (d.member == &Ptrs::lat_rad || d.member == &Ptrs::lat_is_rad || d.member == &Ptrs::corf || d.member == &Ptrs::corf_is) {
+            // a latitude-longitude grid: these depend on the row only (main_grid.py:132-189, 229-240).  The fused
+            // momentum kernel relies on it; anything else steps on the stage kernels
+            for (int j = 1; j <= g.ny && h->zonal; j++)
+                for (int i = 2; i <= g.nx + d.stgx; i++)
+                    if (host[(size_t)i * n1 + j] != host[(size_t)1 * n1 + j]) { h->zonal = false; break; }
+        }
         HIP_TRY(hipMemcpyAsync(h->stage, host, n * sizeof(double), hipMemcpyHostToDevice, h->stream));
         hipLaunchKernelGGL(k_to_device, dim3((n0 + 31) / 32, 1, n1), dim3(32, 8), 0, h->stream, g, h->stage, dev, n0, n1, 1);
         int rc = launch_check("k_to_device");
@@ -1052,7 +1080,7 @@ int dycore_upload(dycore_t *h, const char *name, const double *host)
     if (rc) return rc;
     if (!host) return fail(DYCORE_EINVAL, "null host pointer");
     if (d->member == &Ptrs::UWIND || d->member == &Ptrs::VWIND) h->winds_bc_dirty = true;
-    if (d->member == &Ptrs::UFLX || d->member == &Ptrs::VFLX || d->member == &Ptrs::FLXDIV || d->member == &Ptrs::PHIVB)
+    if (d->member == &Ptrs::UFLX || d->member == &Ptrs::VFLX || d->member == &Ptrs::FLXDIV || d->member == &Ptrs::PHIVB || d->member == &Ptrs::PVTF)
         if ((rc = refresh_lazy(h))) return rc;      // a caller's value must not be overwritten by a later derivation
     const Geo &g = h->g;
     const int n0 = g.nx + 2 + d->stgx, n1 = g.ny + 2 + d->stgy, n2 = h->nk_of(d->nk);
@@ -1071,6 +1099,7 @@ static int lazy_need(const FieldDesc *d)
     if (d->member == &Ptrs::UFLX || d->member == &Ptrs::VFLX) return LAZY_FLX;
     if (d->member == &Ptrs::FLXDIV) return LAZY_FLXDIV;
     if (d->member == &Ptrs::PHIVB) return LAZY_PHIVB;
+    if (d->member == &Ptrs::PVTF) return LAZY_PVTF;
     return 0;
 }
 
@@ -1141,8 +1170,8 @@ int dycore_moist_tendency(dycore_t *h)
 }
 int dycore_euler_forward(dycore_t *h, double dt) { int rc = ready_join(h); return rc ? rc : do_euler(h, h->p, dt); }
 int dycore_primary_diag(dycore_t *h) { int rc = ready_join(h); return rc ? rc : do_diag(h, h->p); }
-int dycore_secondary_diag_rho(dycore_t *h) { int rc = ready_join(h, 0); return rc ? rc : do_rho(h, h->p); }
-int dycore_secondary_diag(dycore_t *h) { int rc = ready_join(h, 0); return rc ? rc : do_secondary(h, h->p); }
+int dycore_secondary_diag_rho(dycore_t *h) { int rc = ready_join(h, LAZY_PVTF); return rc ? rc : do_rho(h, h->p); }
+int dycore_secondary_diag(dycore_t *h) { int rc = ready_join(h, LAZY_PVTF); return rc ? rc : do_secondary(h, h->p); }
 int dycore_compute_turbulence(dycore_t *h) { int rc = ready_join(h, LAZY_PHIVB); return rc ? rc : do_turbulence(h, h->p); }
 
 int dycore_radiation(dycore_t *h, double solar_constant, int32_t nbins, const double *lambdas_center, const double *dlambdas)

@@ -340,12 +340,19 @@ constexpr int DMAXZ = 160;                        // levels up to which the LDS-
 
 // Tile rows a staged field needs from row j0-1 on: UFLX, UWIND, WWIND j-1..j+1 (TJ+2 rows), VFLX (and VWIND
 // when VFLX is re-formed from it) j-1..j+2 (TJ+3), PHI / POTT / PVTF / PVTFVB only j-1 and j (TJ+1).
+// With `fw` (the production instances) PVTF is not staged either: the mid-level Exner value is
+// (PVTFVB[k+1] p[k+1] - PVTFVB[k] p[k]) / ((1 + kappa) (p[k+1] - p[k])) (dyn_diagnostics.py:146-153) and p[k+1] - p[k] =
+// dsigma[k] COLP, so the three values a thread needs cost it a dozen multiply-adds from the PVTFVB values it
+// holds anyway, with a per-column reciprocal 1 / ((1 + kappa) COLP) and 1 / dsigma[k]: 58 instead of 67 tile rows
+// through the DMA per level.  The kernel's time is its data movement (profiles/r02_notes.md), the arithmetic
+// rides along.  The quotient differs from the stored PVTF by the rounding of p[k+1] - p[k] (~4e-15 relative).
 enum { S_UF = 0, S_VF, S_UW, S_VW, S_W, S_PHI, S_POTT, S_PVTF, S_PVB };
 constexpr int mom_rows(int f, int tj, bool fw)
 {
 #ifdef DYC_MOM_NOHALO       // experiment builds only (wrong results): no halo rows staged
     return tj;
 #endif
+    if (f == S_PVTF && fw) return 0;        // formed in the thread from PVTFVB and the column pressure (below)
     return f == S_UF ? tj + 2 : f == S_VF ? tj + 3 : f == S_UW ? tj + 2 : f == S_VW ? (fw ? tj + 3 : tj + 2) : f == S_W ? tj + 2 : tj + 1;
 }
 // LDS layout (doubles).  A DMA slot holds the staged fields of one level back to back (each rows x FTW), then the
@@ -358,11 +365,12 @@ constexpr int mom_off(int f, int tj, bool fw)     // offset of field f inside it
     for (int g = (fw ? 2 : 0); g < f; g++) o += mom_rows(g, tj, fw) * FTW;
     return o;
 }
-constexpr int mom_dma_slot(int tj, bool fw, bool cur) { return mom_off(FNF, tj, fw) + (cur ? 0 : 2 * FTW * tj); }
+constexpr int mom_dma_slot(int tj, bool fw, bool cur) { return mom_off(FNF, tj, fw) + (cur ? 0 : 2 * FTI * tj); }   // step-start tiles: own cells only, FTI wide
 constexpr int mom_flux_slot(int tj, bool fw) { return fw ? (2 * tj + 5) * FTW : 0; }
+// ... then (fw) two factor tiles, dyis (tj+2 rows) and dxjs (tj+3 rows), shaped like the UFLX / VFLX tiles
 constexpr size_t dma_lds_bytes(int tj, bool fw, bool cur, int depth)
 {
-    return ((size_t)(depth + 1) * mom_dma_slot(tj, fw, cur) + 2 * (size_t)mom_flux_slot(tj, fw)) * sizeof(double);
+    return ((size_t)(depth + 1) * mom_dma_slot(tj, fw, cur) + 3 * (size_t)mom_flux_slot(tj, fw)) * sizeof(double);
 }
 
 #ifndef DYC_DMA_AUX
@@ -370,6 +378,13 @@ constexpr size_t dma_lds_bytes(int tj, bool fw, bool cur, int depth)
 #endif
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef const __attribute__((address_space(1))) void gbl_void_t;
+
+// a double that is the same in every lane of the wavefront, moved to scalar registers
+__device__ __forceinline__ double wave_uniform(double x)
+{
+    const int lo = __builtin_amdgcn_readfirstlane(__double2loint(x)), hi = __builtin_amdgcn_readfirstlane(__double2hiint(x));
+    return __hiloint2double(hi, lo);
+}
 
 // `s_waitcnt vmcnt(n)` for a wave-uniform run-time n (the instruction takes an immediate)
 __device__ __forceinline__ void wait_vmcnt(int n)
@@ -415,7 +430,8 @@ __global__ __launch_bounds__(FTI *TJ) void k_momentum_dma(Geo g, Ptrs p, int gbx
     const int ksplit = seg_b ? plan.ks_b : plan.ks_a;
     const int gby = trows.n;            // tile rows of this segment (a subset of the band's, see RowSet)
     constexpr int NCH = (TJ + 3) * FTW / 2, NSL = (NCH + 63) / 64;     // 16-B chunks of the tallest tile, 64-chunk slices
-    constexpr int ON = FTW * TJ, ONCH = ON / 2, ONSL = (ONCH + 63) / 64;   // step-start ("old") tiles
+    constexpr int ON = FTI * TJ, ONSL = ON / 2 / 64;                    // step-start ("old") tiles: own cells, FTI wide; 64-chunk slices
+    static_assert(ON % 128 == 0, "whole slices");
     constexpr int NS = DEPTH + 1;                                       // slots of the DMA ring
     constexpr int DSLOT = mom_dma_slot(TJ, FROM_WINDS, OLD_IS_CUR), FSLOT = mom_flux_slot(TJ, FROM_WINDS);
     constexpr int OFF_OLD = mom_off(FNF, TJ, FROM_WINDS);
@@ -450,20 +466,9 @@ __global__ __launch_bounds__(FTI *TJ) void k_momentum_dma(Geo g, Ptrs p, int gbx
         for (int f = (FROM_WINDS ? 2 : 0); f < FNF; f++)
             if (wave * 64 < mom_rows(f, TJ, FROM_WINDS) * (FTW / 2)) n_issue++;
     }
-    int ooff[ONSL];
-    bool oon[ONSL];
-#pragma unroll
-    for (int s5 = 0; s5 < ONSL; s5++) { ooff[s5] = 0; oon[s5] = false; }
-    if (!OLD_IS_CUR && wave >= TJ - 2) {
-#pragma unroll
-        for (int s5 = 0; s5 < ONSL; s5++) {
-            const int oc = s5 * 64 + lane;
-            oon[s5] = oc < ONCH;
-            const int e = 2 * (oon[s5] ? oc : 0), r = e / FTW, c2 = e - r * FTW;
-            ooff[s5] = min(j0 + r, g.NJ - 1) * P + min(i0 - 2 + c2, P - 2);
-        }
-        n_issue = ONSL;
-    }
+    // a slice of a step-start tile = two rows of 32 chunks (16 B each, i0 is 16-B aligned): lane -> (row, column)
+    const int orow = lane >> 5, ocol = i0 + 2 * (lane & 31);
+    if (!OLD_IS_CUR && wave >= TJ - 2) n_issue = ONSL;
     const double *src[FNF] = {p.UFLX, p.VFLX, p.UWIND, p.VWIND, p.WWIND, p.PHI, p.POTT, p.PVTF, p.PVTFVB};
     const int kofs[FNF] = {0, 0, 0, 0, 1, 0, 0, 0, 1};
     const double *osrc = (wave == TJ - 2) ? u_old : v_old;
@@ -483,11 +488,10 @@ __global__ __launch_bounds__(FTI *TJ) void k_momentum_dma(Geo g, Ptrs p, int gbx
         } else if (!OLD_IS_CUR && wave >= TJ - 2) {
             double *ob = buf + OFF_OLD + (wave - (TJ - 2)) * ON;
 #pragma unroll
-            for (int s5 = 0; s5 < ONSL; s5++)
-                if (oon[s5]) {
-                    const double *gp = osrc + (size_t)k * g.plane + ooff[s5];
-                    __builtin_amdgcn_global_load_lds((gbl_void_t *)gp, (lds_void_t *)(ob + s5 * 128), 16, 0, DYC_DMA_AUX);
-                }
+            for (int s5 = 0; s5 < ONSL; s5++) {
+                const double *gp = osrc + (size_t)k * g.plane + min(j0 + 2 * s5 + orow, g.NJ - 1) * P + ocol;
+                __builtin_amdgcn_global_load_lds((gbl_void_t *)gp, (lds_void_t *)(ob + s5 * 128), 16, 0, DYC_DMA_AUX);
+            }
         }
     };
 
@@ -509,11 +513,14 @@ __global__ __launch_bounds__(FTI *TJ) void k_momentum_dma(Geo g, Ptrs p, int gbx
             ca[b][a] = p.COLP_NEW[q2] * p.A[q2];
         }
     const double colp = p.COLP[c], colp_im1 = p.COLP[c - 1], colp_jm1 = p.COLP[c - P];
+    // Latitude and Coriolis parameter depend on the row only (a wavefront is one row of a latitude-longitude grid;
+    // dycore_set_grid checks it and sends a handle with zonally varying arrays to the stage kernels): the six
+    // Coriolis / metric factors live in scalar registers
     const double lat_is = p.lat_is_rad[c];
-    const double kc_is = p.corf_is[c] * CON_RE * cos(lat_is), sin_is = sin(lat_is);
+    const double kc_is = wave_uniform(p.corf_is[c] * CON_RE * cos(lat_is)), sin_is = wave_uniform(sin(lat_is));
     const double lat = p.lat_rad[c], lat_jm1 = p.lat_rad[c - P];
-    const double kc_c = p.corf[c] * CON_RE * cos(lat), sin_c = sin(lat);
-    const double kc_jm1 = p.corf[c - P] * CON_RE * cos(lat_jm1), sin_jm1 = sin(lat_jm1);
+    const double kc_c = wave_uniform(p.corf[c] * CON_RE * cos(lat)), sin_c = wave_uniform(sin(lat));
+    const double kc_jm1 = wave_uniform(p.corf[c - P] * CON_RE * cos(lat_jm1)), sin_jm1 = wave_uniform(sin(lat_jm1));
     // per-column factors of the Coriolis / metric and pressure-gradient terms (formed once; the "/ 2" of the
     // reference's means are folded in exactly, the products are associated differently: <= 1 ulp each)
     const double hsin_is = 0.5 * sin_is, hsin_c = 0.5 * sin_c, hsin_jm1 = 0.5 * sin_jm1;
@@ -570,6 +577,8 @@ __global__ __launch_bounds__(FTI *TJ) void k_momentum_dma(Geo g, Ptrs p, int gbx
     const double eu1 = cao_is * (1.0 / ca_is), eu2 = dt * (1.0 / ca_is), ev1 = cao_js * (1.0 / ca_js), ev2 = dt * (1.0 / ca_js);
     const size_t c0 = c + (size_t)k0 * g.plane;
     double pvb_k = p.PVTFVB[c0], pvb_im1_k = p.PVTFVB[c0 - 1], pvb_jm1_k = p.PVTFVB[c0 - P];
+    // PVTF in the thread (FROM_WINDS): 1 / ((1 + kappa) COLP) at the own cell and its western / southern neighbour
+    const double rcp_c = 1.0 / ((1.0 + CON_KAPPA) * colp), rcp_im1 = 1.0 / ((1.0 + CON_KAPPA) * colp_im1), rcp_jm1 = 1.0 / ((1.0 + CON_KAPPA) * colp_jm1);
 
     const int lx = tx + 2, ly = ty + 1;   // tile column 0 is longitude i0-2 (16-B aligned in HBM)
     // field f of the level being computed: `db` = its DMA slot, `fb` = its flux slot
@@ -599,21 +608,30 @@ __global__ __launch_bounds__(FTI *TJ) void k_momentum_dma(Geo g, Ptrs p, int gbx
     typedef const __attribute__((address_space(4))) double cdouble_t;
     cdouble_t *c_wa = (cdouble_t *)p.mom_c, *c_wb = c_wa + cs, *c_rds = c_wa + 2 * cs, *c_svb = c_wa + 3 * cs, *c_dif = c_wa + 4 * cs;
     // factors of the flux-tile entries this lane forms (FROM_WINDS), same element -> grid cell map as its DMA chunks
-    double f_uc[2] = {0.0, 0.0}, f_dy[2] = {0.0, 0.0}, f_vc[2] = {0.0, 0.0}, f_dx[2] = {0.0, 0.0};
-    if (FROM_WINDS && wave < NSL && dma_on) {
-#pragma unroll
-        for (int d = 0; d < 2; d++) {
-            const int e = 2 * ch + d;
+    // (the column pressures in registers, the metric factors dyis / dxjs in two LDS tiles: the register file is full)
+    double f_uc[2] = {0.0, 0.0}, f_vc[2] = {0.0, 0.0};
+    double *fac = dsm + NS * DSLOT + 2 * FSLOT;
+    if (FROM_WINDS) {
+        for (int e = tid; e < (TJ + 3) * FTW; e += FTI * TJ) {
             const int r = e / FTW, cc = e - r * FTW, c2 = cc & ~1;
             const int gi = min(i0 - 2 + c2, P - 2) + (cc - c2);
             const int o = min(j0 - 1 + r, g.NJ - 1) * P + gi;
-            f_uc[d] = p.UCOL[o];
             // the reference never fills column nx+2 of its x-staggered grid arrays (main_grid.py:317-357):
             // take the periodic image the UFLX halo copy would have delivered
-            f_dy[d] = p.dyis[gi == g.nx + 2 ? o - g.nx : o];
-            f_vc[d] = p.VCOL[o];
-            f_dx[d] = p.dxjs[o];
+            if (e < (TJ + 2) * FTW) fac[mom_off(S_UF, TJ, true) + e] = p.dyis[gi == g.nx + 2 ? o - g.nx : o];
+            fac[mom_off(S_VF, TJ, true) + e] = p.dxjs[o];
         }
+        if (wave < NSL && dma_on) {
+#pragma unroll
+            for (int d = 0; d < 2; d++) {
+                const int e = 2 * ch + d;
+                const int r = e / FTW, cc = e - r * FTW, c2 = cc & ~1;
+                const int o = min(j0 - 1 + r, g.NJ - 1) * P + min(i0 - 2 + c2, P - 2) + (cc - c2);
+                f_uc[d] = p.UCOL[o];
+                f_vc[d] = p.VCOL[o];
+            }
+        }
+        lds_barrier();          // the factor tiles are complete before the first flux entries are formed
     }
     // flux tiles of a level (FROM_WINDS): every DMA lane turns the chunks IT moved into UFLX / VFLX
     // entries as soon as its own loads have landed -- no barrier between the DMA and this step, the one at
@@ -625,8 +643,8 @@ __global__ __launch_bounds__(FTI *TJ) void k_momentum_dma(Geo g, Ptrs p, int gbx
             const int e = 2 * ch;
 #pragma unroll
             for (int d = 0; d < 2; d++) {
-                if (e + d < (TJ + 2) * FTW) nf[mom_off(S_UF, TJ, true) + e + d] = f_uc[d] * nb[mom_off(S_UW, TJ, true) + e + d] * f_dy[d];
-                nf[mom_off(S_VF, TJ, true) + e + d] = f_vc[d] * nb[mom_off(S_VW, TJ, true) + e + d] * f_dx[d];
+                if (e + d < (TJ + 2) * FTW) nf[mom_off(S_UF, TJ, true) + e + d] = f_uc[d] * nb[mom_off(S_UW, TJ, true) + e + d] * fac[mom_off(S_UF, TJ, true) + e + d];
+                nf[mom_off(S_VF, TJ, true) + e + d] = f_vc[d] * nb[mom_off(S_VW, TJ, true) + e + d] * fac[mom_off(S_VF, TJ, true) + e + d];
             }
         }
     };
@@ -660,14 +678,14 @@ __global__ __launch_bounds__(FTI *TJ) void k_momentum_dma(Geo g, Ptrs p, int gbx
             if (active) {
                 const size_t qm = c + (size_t)k * g.plane;
                 u_out[qm] = SM(S_UW, 0, 0) + SM(S_PHI, 0, 0) + SM(S_UF, 1, 0);
-                if (v_on) v_out[qm] = SM(S_VW, 0, 0) + SM(S_PVB, 0, 0) + SM(S_VF, 0, 1) + (OLD_IS_CUR ? 0.0 : db[OFF_OLD + ty * FTW + lx] + db[OFF_OLD + ON + ty * FTW + lx]);
+                if (v_on) v_out[qm] = SM(S_VW, 0, 0) + SM(S_PVB, 0, 0) + SM(S_VF, 0, 1) + (OLD_IS_CUR ? 0.0 : db[OFF_OLD + ty * FTI + tx] + db[OFF_OLD + ON + ty * FTI + tx]);
             }
         } else if (active) {
             u = SM(S_UW, 0, 0); v = SM(S_VW, 0, 0);
             uo = u; vo = v;
             if (!OLD_IS_CUR) {
-                uo = db[OFF_OLD + ty * FTW + lx];
-                vo = db[OFF_OLD + ON + ty * FTW + lx];
+                uo = db[OFF_OLD + ty * FTI + tx];
+                vo = db[OFF_OLD + ON + ty * FTI + tx];
             }
             // ---- interface k closes level k-1 ----
             if (k >= 1) {
@@ -723,7 +741,18 @@ __global__ __launch_bounds__(FTI *TJ) void k_momentum_dma(Geo g, Ptrs p, int gbx
             const double dif = c_dif[k];
             const double rds = c_rds[k];
             const double pvb_kp1 = SM(S_PVB, 0, 0), pvb_im1_kp1 = SM(S_PVB, -1, 0), pvb_jm1_kp1 = SM(S_PVB, 0, -1);
-            const double phi = SM(S_PHI, 0, 0), pott = SM(S_POTT, 0, 0), pvtf = SM(S_PVTF, 0, 0);
+            const double phi = SM(S_PHI, 0, 0), pott = SM(S_POTT, 0, 0);
+            double pvtf, pvtf_im1, pvtf_jm1;
+            if (FROM_WINDS) {
+                const double pk_c = g.pair_top + svb * colp, pk1_c = g.pair_top + svb1 * colp;
+                const double pk_w = g.pair_top + svb * colp_im1, pk1_w = g.pair_top + svb1 * colp_im1;
+                const double pk_s = g.pair_top + svb * colp_jm1, pk1_s = g.pair_top + svb1 * colp_jm1;
+                pvtf = (pvb_kp1 * pk1_c - pvb_k * pk_c) * (rcp_c * rds);
+                pvtf_im1 = (pvb_im1_kp1 * pk1_w - pvb_im1_k * pk_w) * (rcp_im1 * rds);
+                pvtf_jm1 = (pvb_jm1_kp1 * pk1_s - pvb_jm1_k * pk_s) * (rcp_jm1 * rds);
+            } else {
+                pvtf = SM(S_PVTF, 0, 0); pvtf_im1 = SM(S_PVTF, -1, 0); pvtf_jm1 = SM(S_PVTF, 0, -1);
+            }
             // ---- the sixteen Arakawa-C flux means B,C,D,E / R,Q,S,T (dyn_UVFLX_prepare.py:249-439) from shared pair
             // sums of the UFLX (3 x 4) and VFLX (4 x 3) neighbourhoods.  They carry HALF their weight (1/24, 1/48):
             // the "/ 2" of the wind mean in every advective term is applied here, where it is free -- a power of
@@ -761,7 +790,7 @@ __global__ __launch_bounds__(FTI *TJ) void k_momentum_dma(Geo g, Ptrs p, int gbx
                 // pressure gradient (dyn_functions.py:177-207) with the per-column factors pg_a = -dy (COLP + COLP[i-1]) / 2,
                 // pg_b = -dy (COLP - COLP[i-1]) cp / 2 formed once and POTT / dsigma as POTT * (1 / dsigma)
                 t = t + ((phi - SM(S_PHI, -1, 0)) * pgu_a +
-                         pgu_b * ((SM(S_POTT, -1, 0) * rds) * (svb1 * (pvb_im1_kp1 - SM(S_PVTF, -1, 0)) + svb * (SM(S_PVTF, -1, 0) - pvb_im1_k)) +
+                         pgu_b * ((SM(S_POTT, -1, 0) * rds) * (svb1 * (pvb_im1_kp1 - pvtf_im1) + svb * (pvtf_im1 - pvb_im1_k)) +
                                   prs * own));
                 t = t + dif * (UF(-1, 0) + UF(1, 0) + UF(0, -1) + UF(0, 1) - 4.0 * UF(0, 0));      // dif >= 0; 0 adds nothing
                 if (TURB) t = t + tbu;
@@ -786,7 +815,7 @@ __global__ __launch_bounds__(FTI *TJ) void k_momentum_dma(Geo g, Ptrs p, int gbx
                 const double us_jm1 = U(0, -1) + U(1, -1), us = U(0, 0) + U(1, 0);
                 t = t + (cov_jm1 * us_jm1 * (kc_jm1 + us_jm1 * hsin_jm1) + cov_c * us * (kc_c + us * hsin_c));
                 t = t + ((phi - SM(S_PHI, 0, -1)) * pgv_a +
-                         pgv_b * ((SM(S_POTT, 0, -1) * rds) * (svb1 * (pvb_jm1_kp1 - SM(S_PVTF, 0, -1)) + svb * (SM(S_PVTF, 0, -1) - pvb_jm1_k)) +
+                         pgv_b * ((SM(S_POTT, 0, -1) * rds) * (svb1 * (pvb_jm1_kp1 - pvtf_jm1) + svb * (pvtf_jm1 - pvb_jm1_k)) +
                                   prs * own));
                 t = t + dif * (VF(-1, 0) + VF(1, 0) + VF(0, -1) + VF(0, 1) - 4.0 * VF(0, 0));
                 if (TURB) t = t + tbv;
@@ -1010,6 +1039,22 @@ __global__ __launch_bounds__(TI *TJ) void k_derive_flxdiv(Geo g, Ptrs p)
         p.FLXDIV[q] = (p.UFLX[q + 1] - p.UFLX[q] + p.VFLX[q + g.P] - p.VFLX[q]) * p.dsigma[k] / area;
     }
 }
+// PVTF (dyn_diagnostics.py:146-153) from PVTFVB and COLP: whole array including halos, the expression of diag_level_pre
+__global__ __launch_bounds__(TI *TJ) void k_derive_pvtf(Geo g, Ptrs p)
+{
+#pragma clang fp contract(off)
+    DYC_IJ(0, 0)
+    if (i > g.nx + 1 || j > g.ny + 1) return;
+    const size_t c = at2(g, i, j);
+    const double colp = p.COLP[c];
+    double p_km12 = interface_pressure(g.pair_top, p.sigma_vb[0], colp), pvb_k = p.PVTFVB[c];
+    for (int k = 0; k < g.nz; k++) {
+        const size_t q = c + (size_t)k * g.plane;
+        const double p_kp12 = interface_pressure(g.pair_top, p.sigma_vb[k + 1], colp), pvb_kp1 = p.PVTFVB[q + g.plane];
+        p.PVTF[q] = 1.0 / (1.0 + CON_KAPPA) * (pvb_kp1 * p_kp12 - pvb_k * p_km12) / (p_kp12 - p_km12);
+        p_km12 = p_kp12; pvb_k = pvb_kp1;
+    }
+}
 __global__ __launch_bounds__(TI *TJ) void k_derive_phivb(Geo g, Ptrs p)
 {
     DYC_IJ(0, 0)
@@ -1041,7 +1086,9 @@ __global__ __launch_bounds__(TI *TJ) void k_derive_phivb(Geo g, Ptrs p)
 __device__ __forceinline__ double ldb(const double *base, unsigned boff) { return *(const double *)((const char *)base + boff); }
 __device__ __forceinline__ void stb(double *base, unsigned boff, double v) { *(double *)((char *)base + boff) = v; }
 
-template <bool WRITE_PHIVB, bool FROM_WINDS, bool TURB = false>
+// WRITE_PVTF = false: PVTF is not stored either -- the production momentum kernel forms it from PVTFVB and COLP, every
+// other reader gets it on demand (k_derive_pvtf, the formula of diag_level_pre on the stored PVTFVB: the same bits).
+template <bool WRITE_PHIVB, bool FROM_WINDS, bool TURB = false, bool WRITE_PVTF = true>
 __global__ __launch_bounds__(TI *TJ) void k_pott_fused(Geo g, Ptrs p, const double *pott_old, double *pott_out, double dt, int lin)
 {
     int i, j;
@@ -1123,7 +1170,7 @@ __global__ __launch_bounds__(TI *TJ) void k_pott_fused(Geo g, Ptrs p, const doub
             pvb_up = exner_vb(p_up);
         }
         const double p_km12 = dl.p_km12, pvb_k = dl.pvb_k, pvtf = dl.pvtf, phi = dl.phi, phivb = dl.phivb;
-        stb(p.PVTF, q, pvtf);
+        if (WRITE_PVTF) stb(p.PVTF, q, pvtf);
         stb(p.PVTFVB, q, pvb_k);
         stb(p.PHI, q, phi);
         if (WRITE_PHIVB) stb(p.PHIVB, q, phivb);

@@ -94,7 +94,8 @@ def load_library(path=None):
     lib.dycore_sync.argtypes = [hp]
     lib.dycore_set_grid.argtypes = [hp, C.c_char_p, dp, C.c_int32, C.c_int32, C.c_int32]
     lib.dycore_field_shape.argtypes = [hp, C.c_char_p, C.POINTER(C.c_int32 * 3)]
-    lib.dycore_has_field.argtypes = [hp, C.c_char_p]
+    if hasattr(lib, 'dycore_has_field'):
+        lib.dycore_has_field.argtypes = [hp, C.c_char_p]
     lib.dycore_upload.argtypes = [hp, C.c_char_p, dp]
     lib.dycore_download.argtypes = [hp, C.c_char_p, dp]
     lib.dycore_field_ptr.argtypes = [hp, C.c_char_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int64),
@@ -123,12 +124,13 @@ def load_library(path=None):
     lib.dycore_rows_size.argtypes = [hp, C.c_int32, cpp, C.POINTER(C.c_int64)]
     lib.dycore_pack_rows.argtypes = [hp, C.c_int32, cpp, C.POINTER(C.c_int32), C.c_void_p]
     lib.dycore_unpack_rows.argtypes = [hp, C.c_int32, cpp, C.POINTER(C.c_int32), C.c_void_p]
-    lib.dycore_bands_unique_id.argtypes = [C.c_void_p, C.c_int32]
-    lib.dycore_bands_create_rccl.argtypes = [hp, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(hp)]
-    lib.dycore_bands_create_local.argtypes = [C.POINTER(hp), C.c_int32, C.POINTER(hp)]
-    lib.dycore_bands_connect.argtypes = [hp]
-    lib.dycore_bands_step_matsuno.argtypes = [hp, C.c_double, C.c_int32, C.c_int32]
-    lib.dycore_bands_destroy.argtypes = [hp]
+    if hasattr(lib, 'dycore_bands_step_matsuno'):       # absent from older builds loaded through DYCORE_LIB for A/B timing
+        lib.dycore_bands_unique_id.argtypes = [C.c_void_p, C.c_int32]
+        lib.dycore_bands_create_rccl.argtypes = [hp, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(hp)]
+        lib.dycore_bands_create_local.argtypes = [C.POINTER(hp), C.c_int32, C.POINTER(hp)]
+        lib.dycore_bands_connect.argtypes = [hp]
+        lib.dycore_bands_step_matsuno.argtypes = [hp, C.c_double, C.c_int32, C.c_int32]
+        lib.dycore_bands_destroy.argtypes = [hp]
     lib.dycore_profile.argtypes = [hp, C.c_int32]
     lib.dycore_kernel_stats.argtypes = [hp, C.c_int32, C.POINTER(C.c_char_p), C.POINTER(C.c_int64),
                                         C.POINTER(C.c_double)]

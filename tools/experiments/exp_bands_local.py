@@ -28,7 +28,7 @@ for nb in [1, 2, 4, 8]:
             c.upload(n, L.slice_rows(F.host[n], r, FIELD_TABLE[n][1]))
         c.primary_diag()
         cores.append(c)
-    lb = LocalBands(cores, L, torch.device('cuda:0'), overlap=bool(int(os.environ.get('OVERLAP', '1'))))
+    lb = LocalBands(cores, L, torch.device('cuda:0'), overlap=bool(int(os.environ.get('OVERLAP', '1'))), native=bool(int(os.environ.get('NATIVE', '0'))))
     lb.step_matsuno(GR.dt, 1)
     for c in cores: c.profile(True)
     lb.step_matsuno(GR.dt, steps)

@@ -21,7 +21,7 @@ for nb in (1, 2):
         for n in names:
             c.upload(n, L.slice_rows(F.host[n], r, FIELD_TABLE[n][1]))
         c.primary_diag(); cores.append(c)
-    lb = LocalBands(cores, L, torch.device('cuda:0'))
+    lb = LocalBands(cores, L, torch.device('cuda:0'), native=bool(int(os.environ.get('NATIVE', '0'))))
     lb.step_matsuno(GR.dt, 5)
     torch.cuda.synchronize(); t0 = time.perf_counter()
     n = 200

@@ -45,9 +45,9 @@ KERNEL_PASSES = {
     'k_continuity': 5, 'k_continuity_reg': 3,   # fused: R UWIND,VWIND W WWIND (UFLX, VFLX are not stored)
     'k_prepare': 15, 'k_uflx_tendency': 13, 'k_vflx_tendency': 13,
     'k_pott_tendency': 6, 'k_euler_forward': 9, 'k_primary_diag': 5, 'k_diag_rho': 6,
-    'k_momentum_dma': 10.0,      # R UWIND,VWIND,WWIND,PHI,POTT,PVTF,PVTFVB (+2 old in the corrector) W UWIND,VWIND
-    'k_momentum_fused': 10.0,    # its register-staged fallback (nz > 160): same fields
-    'k_pott_fused': 10.5,        # R POTT,UWIND,VWIND,WWIND,POTTVB (+1 old) W POTT,PVTF,PVTFVB,PHI,POTTVB
+    'k_momentum_dma': 9.0,       # R UWIND,VWIND,WWIND,PHI,POTT,PVTFVB (+2 old in the corrector) W UWIND,VWIND (PVTF is formed in the thread)
+    'k_momentum_fused': 10.0,    # its register-staged fallback (nz > 160): the same fields + PVTF
+    'k_pott_fused': 9.5,         # R POTT,UWIND,VWIND,WWIND,POTTVB (+1 old) W POTT,PVTFVB,PHI,POTTVB (PVTF is derived on demand)
     'k_moist': 8.0,              # R QV,QC,UWIND,VWIND,WWIND (+2 old) W QV,QC
     'k_turb_tendencies': 16.0,   # R UWIND,VWIND,PHI,PHIVB,RHO,RHOVB,KMOM,KHEAT,POTT(,QV,QC) W TURB_U,V,T(,QV,QC)
 }

@@ -4,8 +4,8 @@
 // One band per GPU / process.  Per substep a band refreshes its north / south halo rows from its neighbours twice,
 // each time behind a kernel that does not need the rows:
 //
-//   main:  |B1  continuity - pack AB2 - momentum inner tiles - |AB2 - momentum edge tiles - pack B1 - temperature(+moisture)
-//   comm:                     AB2: transport, unpack, diag rows                               B1: transport, unpack
+//   main:  |B1  continuity ---- momentum inner tiles - |AB2 - momentum edge tiles ---- temperature(+moisture)
+//   comm:                  AB2: pack, transport, unpack, diag rows                   B1: pack, transport, unpack
 //
 //   AB2 = 2-D column pressures at the u- / v-points, WWIND, COLP_NEW of this substep + the POTT (QV, QC) rows of the
 //         state it evaluates on;  B1 = the new winds;  B2 = the POTT (QV, QC) rows of the last substep of a call.
@@ -221,15 +221,21 @@ int bands_transport(dycore_bands *B, int ph)
 // rows); one event per phase marks "halo rows of this phase are in place"
 int bands_exchange(dycore_bands *B, int ph, int sub, double dt)
 {
-    int rc;
+    int rc = 0;
     const int src = ph == PH_AB2 ? 1 - sub : sub;
-    for (BandMember &b : B->m)
-        if ((rc = rows_move(b.h, b.msg[ph].send_s, b.has_s, b.msg[ph].send_n, b.has_n, src, b.msg[ph].send, 0))) return rc;
+    // everything of an exchange runs on the comm stream, the pack included: the rows it reads are complete when the
+    // event below is recorded, and no kernel the main stream issues before it waits for this exchange's successor
+    // writes them -- the main stream goes straight on to the kernel that hides the exchange
     HIP_TRY(hipEventRecord(B->ev_main, B->main));
     HIP_TRY(hipStreamWaitEvent(B->comm, B->ev_main, 0));
-    if ((rc = bands_transport(B, ph))) return rc;
     for (BandMember &b : B->m) b.h->stream = B->comm;
-    rc = 0;
+    for (BandMember &b : B->m)
+        if ((rc = rows_move(b.h, b.msg[ph].send_s, b.has_s, b.msg[ph].send_n, b.has_n, src, b.msg[ph].send, 0))) break;
+    if (!rc) rc = bands_transport(B, ph);
+    if (rc) {
+        for (BandMember &b : B->m) b.h->stream = b.h->home;
+        return rc;
+    }
     for (BandMember &b : B->m) {
         if ((rc = rows_move(b.h, b.msg[ph].recv_s, b.has_s, b.msg[ph].recv_n, b.has_n, src, b.msg[ph].recv, 1))) break;
         if (ph != PH_B1 && (rc = substep_part(b.h, dt, src, 2))) break;      // diagnostics of the received POTT rows

@@ -242,7 +242,12 @@ def _overlapped_step(cores, streams, deliver, dt, nsteps, with_rho):
             streams.done[ph].record(streams.comm)
         streams.pending[ph] = True
 
-    for _ in range(nsteps):
+    # a turbulence-coupled step re-diagnoses RHO / RHOVB of the whole band, halo rows included, when it begins: the POTT
+    # rows of the state it starts from must be in place then, so they go out alone at the end of every step
+    turb = bool(getattr(C0, 'i_turb', False))
+    for step in range(nsteps):
+        if turb:
+            streams.wait('B2')
         for c in cores:
             c.step_begin(with_rho)
         for sub in (0, 1):
@@ -259,6 +264,8 @@ def _overlapped_step(cores, streams, deliver, dt, nsteps, with_rho):
             on_comm('B1', sub)
             for c in cores:
                 c.substep_part(dt, sub, C0.PART_TEMP)
+        if turb and step < nsteps - 1:
+            on_comm('B2', 1)
     on_comm('B2', 1)        # leave with the halo rows of the final state in place and every stream joined
     streams.wait('B1')
     streams.wait('B2')
@@ -302,8 +309,8 @@ class DistributedBands:
         self.bufs = _TorchBuffers(self.halo, device)
         on_gpu = str(device) != 'cpu'
         self.staged = dist.get_backend(group) != 'nccl' and on_gpu
-        # the split parts exist for the fused (dry / moist) step; the turbulence-coupled staged step
-        # keeps the plain sequence
+        # the split parts exist for the fused step (dry, moist, turbulence-coupled); a handle that steps on the stage
+        # kernels keeps the plain sequence
         if overlap is None:
             import os
             overlap = on_gpu and os.environ.get('DYCORE_BANDS_OVERLAP', '1') != '0'

@@ -259,8 +259,8 @@ int bands_finish_create(dycore_bands *B)
 {
     // every member: the fused step with split parts and fluxes re-formed from the winds (the message plan above)
     for (BandMember &b : B->m) {
-        if (!fused_path(b.h) || b.h->g.i_turb || !flux_from_winds(b.h))
-            return fail(DYCORE_ESTATE, "the in-library band step needs the fused dry / moist step (dycore_overlap_parts, dycore_flux_from_winds)");
+        if (!fused_path(b.h) || !flux_from_winds(b.h))
+            return fail(DYCORE_ESTATE, "the in-library band step needs the fused step (dycore_overlap_parts, dycore_flux_from_winds)");
         if (b.h->home != B->main) return fail(DYCORE_EINVAL, "all bands of one process must launch on the same stream");
         build_plan(b);
     }
@@ -390,7 +390,11 @@ int dycore_bands_step_matsuno(dycore_bands_t *B, double dt, int32_t nsteps, int3
         return 0;
     }
 #define ALL(call) for (BandMember &b : B->m) { dycore *h = b.h; if ((rc = (call))) return rc; }
+    // a turbulence-coupled step re-diagnoses RHO / RHOVB of the whole band, halo rows included, when it begins: the POTT
+    // rows of the state it starts from go out alone at the end of every step and must have arrived by then
+    const bool turb = B->m[0].h->g.i_turb != 0;
     for (int s = 0; s < nsteps; s++) {
+        if (turb && (rc = bands_wait(B, PH_B2))) return rc;
         ALL(step_begin(h, with_rho))
         for (int sub = 0; sub < 2; sub++) {
             if ((rc = bands_wait(B, PH_B1)) || (rc = bands_wait(B, PH_B2))) return rc;
@@ -402,6 +406,7 @@ int dycore_bands_step_matsuno(dycore_bands_t *B, double dt, int32_t nsteps, int3
             if ((rc = bands_exchange(B, PH_B1, sub, dt))) return rc;
             ALL(substep_part(h, dt, sub, DYCORE_PART_TEMP))
         }
+        if (turb && s < nsteps - 1 && (rc = bands_exchange(B, PH_B2, 1, dt))) return rc;
     }
 #undef ALL
     if (nsteps > 0) {       // leave with the halo rows of the final state in place and every stream joined

@@ -589,13 +589,18 @@ int do_pott_fused(dycore *h, const Ptrs &p, const double *pott_old, double *pott
     return launch_check("k_pott_fused");
 }
 // the turbulent tendencies of the fused turbulence-coupled step (one launch per substep)
-int do_turb_tendencies(dycore *h, const Ptrs &p)
+// `mode`: all rows, or -- for a band that hides its exchange -- the rows clear of the neighbours' rows (INNER) and the
+// one row next to each neighbour (EDGE)
+int do_turb_tendencies(dycore *h, const Ptrs &p, int mode = ROWS_ALL)
 {
-    int rc;
-    const int nz = h->g.nz;
-    (void)rc; (void)nz;
+    RowSet rs;
+    if (!row_subset(h->g.ny, h->g.pole_s ? 0 : 1, h->g.pole_n ? 0 : 1, mode, rs)) return 0;
     Scope s(h, K_TURB_TEND);
-    hipLaunchKernelGGL(k_turb_tendencies, grid_cells(h), dim3(TI, TJ), 0, h->stream, h->g, p, h->g.pole_s ? 2 : 1, cells_linear(h));
+    const int lin = cells_linear(h);
+    long long n;
+    if (lin & 1) n = ((long long)h->g.nx * rs.n + TI * TJ - 1) / (TI * TJ);
+    else n = (long long)((h->g.nx + TI - 1) / TI) * ((rs.n + TJ - 1) / TJ);
+    hipLaunchKernelGGL(k_turb_tendencies, dim3((unsigned)(8 * ((n + 7) / 8))), dim3(TI, TJ), 0, h->stream, h->g, p, h->g.pole_s ? 2 : 1, lin, rs);
     return launch_check("k_turb_tendencies");
 }
 // dQVdt, dQCdt (stage) or the new QV, QC directly (fused): dyn_moist.py
@@ -728,12 +733,12 @@ int substep_part(dycore *h, double dt, int sub, int part)
         switch (part) {
         case 0:                     // -> UFLX, VFLX, WWIND, COLP_NEW halo rows
             return do_continuity_fused(h, q, dt);
-        case DYCORE_PART_MOM_INNER:
-            if (h->g.i_turb) return fail(DYCORE_ESTATE, "split parts are not available on a turbulence-coupled handle (dycore_overlap_parts)");
+        case DYCORE_PART_MOM_INNER:     // turbulence-coupled: the turbulent tendencies of the same rows first
+            if (h->g.i_turb && (rc = do_turb_tendencies(h, q, ROWS_INNER))) return rc;
             return do_momentum_fused(h, q, p.UWIND, p.VWIND, u_out, v_out, dt, ROWS_INNER);
         case DYCORE_PART_MOM_EDGE:  // -> new winds complete: their rows can travel while part TEMP runs
-            if (h->g.i_turb) return fail(DYCORE_ESTATE, "split parts are not available on a turbulence-coupled handle (dycore_overlap_parts)");
             if ((rc = join_side(h))) return rc;
+            if (h->g.i_turb && (rc = do_turb_tendencies(h, q, ROWS_EDGE))) return rc;
             // the rows that leave now are packed with their periodic images (k_rows); the lateral halo of
             // the new winds is refreshed with everything else at the end of part TEMP
             return do_momentum_fused(h, q, p.UWIND, p.VWIND, u_out, v_out, dt, ROWS_EDGE);
@@ -743,8 +748,7 @@ int substep_part(dycore *h, double dt, int sub, int part)
                 if ((rc = join_side(h))) return rc;
                 if (h->g.i_turb && (rc = do_turb_tendencies(h, q))) return rc;
                 if ((rc = do_momentum_fused(h, q, p.UWIND, p.VWIND, u_out, v_out, dt))) return rc;
-            } else if (h->g.i_turb)
-                return fail(DYCORE_ESTATE, "split parts are not available on a turbulence-coupled handle (dycore_overlap_parts)");
+            }
             if ((rc = do_pott_fused(h, q, p.POTT, t_out, dt))) return rc;
             double *qv_out = sub == 0 ? p.QV_EST : p.QV, *qc_out = sub == 0 ? p.QC_EST : p.QC;
             if (h->g.i_moist && (rc = do_moist(h, q, p.QV, p.QC, qv_out, qc_out, dt))) return rc;
@@ -970,7 +974,7 @@ int dycore_use_stream(dycore_t *h, void *stream)
     return 0;
 }
 void *dycore_get_stream(dycore_t *h) { return h ? (void *)h->home : nullptr; }
-int dycore_overlap_parts(dycore_t *h) { return h && fused_path(h) && !h->g.i_turb ? 1 : 0; }
+int dycore_overlap_parts(dycore_t *h) { return h && fused_path(h) && flux_from_winds(h) ? 1 : 0; }
 int dycore_flux_from_winds(dycore_t *h) { return h && fused_path(h) && flux_from_winds(h) ? 1 : 0; }
 int dycore_sync(dycore_t *h)
 {

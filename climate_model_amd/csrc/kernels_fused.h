@@ -858,11 +858,17 @@ __global__ __launch_bounds__(FTI *TJ) void k_momentum_dma(Geo g, Ptrs p, int gbx
 //                    + dyn_UFLX.py:158-167 / dyn_VFLX.py:157-166 -- the expressions of k_prepare<true> and
 //                    k_uflx/vflx_tendency<true>, the interface values carried instead of stored
 //   TURB_T, TURB_QV, TURB_QC : dyn_functions.py:26-67 (turb_flux) as in k_pott_tendency<true>, k_moist<true>
-// One thread per owned column, levels top-down.
-__global__ __launch_bounds__(TI *TJ) void k_turb_tendencies(Geo g, Ptrs p, int jv_lo, int lin)
+// One thread per owned column, levels top-down.  `rs`: the rows of this launch (a latitude band evaluates the rows
+// next to a neighbour once that neighbour's rows have arrived: every term reads rows j-1 .. j+1 at most).
+__global__ __launch_bounds__(TI *TJ) void k_turb_tendencies(Geo g, Ptrs p, int jv_lo, int lin, RowSet rs)
 {
     int i, j;
-    if (!owned_cell(g, lin, i, j)) return;
+    {
+        Geo gs = g;
+        gs.ny = rs.n;                       // owned_cell over the nx x rs.n cells of the launch
+        if (!owned_cell(gs, lin, i, j)) return;
+        j = 1 + rowset_row(rs, j - 1);
+    }
     const int P = g.P, nz = g.nz;
     const size_t c = at2(g, i, j), pl = (size_t)g.plane;
     const int jg = j + g.joff;

@@ -157,6 +157,9 @@ int dycore_step_matsuno(dycore_t *h, double dt, int32_t nsteps, int32_t with_rho
  *                          previous part 2)      -> the new UWIND, VWIND rows can be exchanged
  *   DYCORE_PART_TEMP       temperature (+ moisture), COLP<-COLP_NEW: does not touch the winds, so the
  *                          wind rows travel meanwhile -> exchange POTT (QV, QC) rows, then part 2
+ * On a turbulence-coupled handle the two momentum pieces evaluate the turbulent tendencies of the same rows first, and
+ * dycore_step_begin(with_rho) needs the POTT halo rows of the state the step starts from (exchange them at the end of
+ * every step, not only behind the last one).
  * Part 0 of the next substep needs the wind rows only.
  * dycore_use_stream redirects every subsequent launch of the handle to another HIP stream (NULL:
  * back to the handle's own stream) so that pack/unpack and part 2 can be queued on the stream the
@@ -201,7 +204,8 @@ int dycore_unpack_rows(dycore_t *h, int32_t n, const char *const *names, const i
  *                              timed region); every rank calls it.
  *   dycore_bands_step_matsuno  nsteps Matsuno steps; returns with every halo row of the final state in place and
  *                              the comm stream joined into the handles' stream.
- * Needs handles whose step is the fused one with split parts (dycore_overlap_parts, dycore_flux_from_winds != 0).
+ * Needs handles whose step is the fused one with split parts (dycore_overlap_parts, dycore_flux_from_winds != 0): dry,
+ * moist or turbulence-coupled.
  * An N-band run equals the single-domain run bit for bit. */
 typedef struct dycore_bands dycore_bands_t;
 int dycore_bands_unique_id(void *id, int32_t nbytes);                 /* nbytes = 128 */

@@ -61,8 +61,6 @@ def test_local_bands_bitwise_equal_single(nbands, i_turb, i_moist, overlap):
     the multi-GPU run); overlap=False: plain part / exchange sequence with host synchronisation;
     'native': the same overlapped schedule issued by the library itself (dycore_bands_step_matsuno)."""
     native = overlap == 'native'
-    if native and i_turb:
-        pytest.skip('the in-library band step covers the fused dry / moist step')
     overlap = bool(overlap)
     import torch
     stream = torch.cuda.Stream()
@@ -80,7 +78,7 @@ def test_local_bands_bitwise_equal_single(nbands, i_turb, i_moist, overlap):
         c.primary_diag()
         cores.append(c)
     lb = LocalBands(cores, L, torch.device('cuda:0'), overlap=overlap, native=native)
-    assert lb.overlap == (overlap and not i_turb)     # the staged (turbulence-coupled) step is not split
+    assert lb.overlap == overlap        # the split parts exist for the turbulence-coupled fused step too
     assert (lb.native is not None) == native
     lb.step_matsuno(GR.dt, 2)
     lb.step_matsuno(GR.dt, 1)          # a second call continues from halo rows the first one left in place

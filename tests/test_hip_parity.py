@@ -457,7 +457,7 @@ def test_fused_turbulent_step_equals_stage_kernels(monkeypatch, i_moist):
         for n, a in state.items():
             core.upload(n, a)
         core.primary_diag()
-        assert core.flux_from_winds == (fused == '1') and not core.overlap_parts
+        assert core.flux_from_winds == (fused == '1') and core.overlap_parts == (fused == '1')
         core.step_matsuno(GR.dt, 3)
         out[fused] = {n: core.download(n) for n in check}
         core.close()

@@ -80,6 +80,7 @@ def parse():
     ap.add_argument('--nz', type=int, default=64)
     ap.add_argument('--moist', action='store_true', help='also advect QV/QC (dyn_moist; BASELINE config 5 without radiation); not the headline workload')
     ap.add_argument('--radiation', action='store_true', help='radiation heating in the temperature tendency (i_POTT_radiation) with one radiation call before the timed steps; with --moist this is BASELINE config 5')
+    ap.add_argument('--f32', action='store_true', help="working_precision = 'float32' (libdycore_hip_f32.so): a secondary line, never the headline")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-seconds', type=float, default=15.0, help='CPU baseline budget')
     return ap.parse_args()
@@ -191,7 +192,8 @@ def main():
     state = {n: F.host[n] for n in names}
     core = HipDycore(GR.nx, L.ny(rank), GR.nz, pair_top=GR.nl.pair_top, device=local_rank,
                      ny_global=GR.ny, j_offset=L.j_offset(rank), stream=stream.cuda_stream, i_moist=int(args.moist),
-                     i_radiation=int(args.radiation))
+                     i_radiation=int(args.radiation), dtype=np.float32 if args.f32 else np.float64)
+    esize = 4 if args.f32 else 8
     core.set_grid(band_grid_arrays(GR.GRF['HIP'], L, rank))
     for n in names:
         core.upload(n, L.slice_rows(state[n], rank, FIELD_TABLE[n][1]))
@@ -245,7 +247,7 @@ def main():
     # measured device-to-device copy ceiling of this GPU (reported next to the 8 TB/s spec peak)
     copy_gbs = None
     try:
-        nbytes = min(core.field_shape('UWIND')[0] * core.field_shape('UWIND')[1] * core.field_shape('UWIND')[2] * 8, 1 << 30)
+        nbytes = min(core.field_shape('UWIND')[0] * core.field_shape('UWIND')[1] * core.field_shape('UWIND')[2] * esize, 1 << 30)
         a = torch.empty(nbytes // 8, dtype=torch.float64, device='cuda')
         b = torch.empty_like(a)
         b.copy_(a)
@@ -276,7 +278,7 @@ def main():
             dom, dom_n, dom_ms = k, n, tot
     roof = None
     if dom:
-        per_launch_bytes = KERNEL_PASSES[dom] * band_cells * 8
+        per_launch_bytes = KERNEL_PASSES[dom] * band_cells * esize
         # a band runs the kernel as two launches per substep (inner rows behind the exchange, edge
         # rows after it): price the pair as the one pass over the band it is
         if world > 1:
@@ -290,7 +292,7 @@ def main():
             if k not in KERNEL_PASSES:
                 continue
             nl_ = launches_per_step[k]
-            gb = KERNEL_PASSES[k] * band_cells * 8 / 1e9
+            gb = KERNEL_PASSES[k] * band_cells * esize / 1e9
             if world > 1 and k in ('k_momentum_dma',):
                 nl_ = nl_ / 2.0         # inner + edge launch = one pass over the band
             step_bytes += gb * nl_
@@ -312,7 +314,7 @@ def main():
                 'algorithmic_bytes_per_launch': per_launch_bytes, 'avg_launch_ms': dom_ms / dom_n,
                 'launches': dom_n,
                 'step_compulsory_GB': step_bytes, 'step_achieved': step_ach, 'step_frac': step_ach / HBM_PEAK_GBS,
-                'step_survey_130pass_GBs': PASSES_PER_STEP * 8 * value / 1e9 / world,
+                'step_survey_130pass_GBs': PASSES_PER_STEP * esize * value / 1e9 / world,
                 'measured_copy_GBs': copy_gbs,
                 'kernels': kern,
                 'kernels_ms_per_step': breakdown}
@@ -321,7 +323,7 @@ def main():
         'metric': 'cell-updates/sec per Matsuno step at 0.25deg x 64L (achieved HBM GB/s in roofline)',
         'value': value, 'unit': 'cell-updates/s', 'n_gpus': world, 'steps': args.steps,
         'warmup': args.warmup, 'ms_per_step': ms_per_step, 'higher_is_better': True,
-        'scaling': 'strong', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
+        'scaling': 'strong', 'vs_baseline': None, 'dtype': 'f32' if args.f32 else 'f64', 'data': 'synthetic',
         'config': {'workload': ('moist (QV, QC advected) ' if args.moist else 'dry ') + ('with radiative heating ' if args.radiation else '') + 'hydrostatic dycore, Matsuno step, %g deg lat-lon (%d x %d) x %d sigma levels, '
                                'dt=%.4g s' % (args.dlat, GR.nx, GR.ny, GR.nz, GR.dt),
                    'cells': cells, 'parallelism': 'latitude bands x%d' % world if world > 1 else 'single GPU',
@@ -329,7 +331,7 @@ def main():
                                 (', RCCL send/recv issued by the library' if getattr(bands, 'native', None) is not None else ', torch.distributed P2P')) if bands is not None else None},
         'roofline': roof,
     }
-    if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.moist and not args.radiation:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.moist and not args.radiation and not args.f32:
         core.close()
         try:
             line['cpu_baseline'] = cpu_baseline(GR, state, args.cpu_seconds)

@@ -69,12 +69,12 @@ enum { PH_AB2 = 0, PH_B1 = 1, PH_B2 = 2, PH_COUNT = 3 };
 
 // one row of one field inside a message; `est` != nullptr marks a state field (UWIND, VWIND, POTT, QV, QC), which the
 // fused step keeps in its *_EST scratch buffer after the predictor
-struct MsgItem { double *Ptrs::*plain; double *Ptrs::*est; int row, nk; };
+struct MsgItem { real *Ptrs::*plain; real *Ptrs::*est; int row, nk; };
 
 struct Msg {
     std::vector<MsgItem> send_s, send_n, recv_s, recv_n;
     size_t ss = 0, sn = 0, rs = 0, rn = 0;      // doubles
-    double *send = nullptr, *recv = nullptr;    // [south part | north part]
+    real *send = nullptr, *recv = nullptr;    // [south part | north part]
 };
 
 struct BandMember {
@@ -95,7 +95,7 @@ struct dycore_bands {
     RcclApi *rccl = nullptr;
     ncclComm_t nccl = nullptr;
     int rank = 0, nranks = 1, south = -1, north = -1;
-    std::vector<double *> allocs;
+    std::vector<real *> allocs;
 };
 
 namespace {
@@ -153,7 +153,7 @@ void build_plan(BandMember &b)
 // pack (unpack = 0) / unpack (1) the south + north lists of one message on the handle's current stream.
 // `src` = the substep whose output the state fields are taken from (0: the *_EST buffers)
 int rows_move(dycore *h, const std::vector<MsgItem> &south, bool with_s, const std::vector<MsgItem> &north, bool with_n,
-              int src, double *buf, int unpack)
+              int src, real *buf, int unpack)
 {
     RowList rl;
     rl.n = 0;
@@ -207,11 +207,11 @@ int bands_transport(dycore_bands *B, int ph)
         Msg &m = B->m[r].msg[ph];
         if (r > 0) {            // from the southern neighbour: its north part
             Msg &o = B->m[r - 1].msg[ph];
-            HIP_TRY(hipMemcpyAsync(m.recv, o.send + o.ss, m.rs * sizeof(double), hipMemcpyDeviceToDevice, B->comm));
+            HIP_TRY(hipMemcpyAsync(m.recv, o.send + o.ss, m.rs * sizeof(real), hipMemcpyDeviceToDevice, B->comm));
         }
         if (r < n - 1) {        // from the northern neighbour: its south part
             Msg &o = B->m[r + 1].msg[ph];
-            HIP_TRY(hipMemcpyAsync(m.recv + m.rs, o.send, m.rn * sizeof(double), hipMemcpyDeviceToDevice, B->comm));
+            HIP_TRY(hipMemcpyAsync(m.recv + m.rs, o.send, m.rn * sizeof(real), hipMemcpyDeviceToDevice, B->comm));
         }
     }
     return 0;
@@ -219,7 +219,7 @@ int bands_transport(dycore_bands *B, int ph)
 
 // pack on the main stream, then on the comm stream: transport, unpack (+ the primary diagnostics of received POTT
 // rows); one event per phase marks "halo rows of this phase are in place"
-int bands_exchange(dycore_bands *B, int ph, int sub, double dt)
+int bands_exchange(dycore_bands *B, int ph, int sub, real dt)
 {
     int rc = 0;
     const int src = ph == PH_AB2 ? 1 - sub : sub;
@@ -271,10 +271,10 @@ int bands_finish_create(dycore_bands *B)
     for (BandMember &b : B->m)
         for (int ph = 0; ph < PH_COUNT; ph++) {
             Msg &m = b.msg[ph];
-            double *d = nullptr;
-            HIP_TRY(hipMalloc((void **)&d, (m.ss + m.sn + 1) * sizeof(double)));
+            real *d = nullptr;
+            HIP_TRY(hipMalloc((void **)&d, (m.ss + m.sn + 1) * sizeof(real)));
             B->allocs.push_back(d); m.send = d;
-            HIP_TRY(hipMalloc((void **)&d, (m.rs + m.rn + 1) * sizeof(double)));
+            HIP_TRY(hipMalloc((void **)&d, (m.rs + m.rn + 1) * sizeof(real)));
             B->allocs.push_back(d); m.recv = d;
         }
     return 0;
@@ -356,7 +356,7 @@ int dycore_bands_destroy(dycore_bands_t *B)
     if (B->comm) (void)hipStreamSynchronize(B->comm);
     if (B->main) (void)hipStreamSynchronize(B->main);
     if (B->nccl && B->rccl) (void)B->rccl->CommDestroy(B->nccl);
-    for (double *d : B->allocs) (void)hipFree(d);
+    for (real *d : B->allocs) (void)hipFree(d);
     if (B->ev_main) (void)hipEventDestroy(B->ev_main);
     for (int ph = 0; ph < PH_COUNT; ph++)
         if (B->done[ph]) (void)hipEventDestroy(B->done[ph]);

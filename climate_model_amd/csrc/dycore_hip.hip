@@ -50,7 +50,7 @@ struct FieldDesc {
     const char *name;
     int stgx, stgy;
     int nk;                         // 0 -> nz, -1 -> nz+1, 1 -> 1
-    double *Ptrs::*member;
+    real *Ptrs::*member;
     int rad;                        // 1: exists only on handles created with i_radiation; 2: only with i_turb
 };
 
@@ -92,7 +92,7 @@ struct GridDesc {
     const char *name;
     int stgx, stgy;                 // 2-D: staggering; 1-D: stgx = -1
     int nk;                         // 1-D: 0 -> nz, -1 -> nz+1
-    const double *Ptrs::*member;
+    const real *Ptrs::*member;
 };
 #define G_(n, sx, sy, nk) {#n, sx, sy, nk, &Ptrs::n}
 const GridDesc kGrid[] = {
@@ -129,11 +129,11 @@ struct dycore {
     hipEvent_t ev_main = nullptr, ev_side = nullptr;
     bool side_pending = false;
     std::unordered_map<std::string, int> field_idx, grid_idx;
-    std::vector<double *> allocs;
-    double *rad_ws = nullptr;       // workspace of the radiation columns, [element][column]
+    std::vector<real *> allocs;
+    double *rad_ws = nullptr;     // workspace of the radiation columns, [element][column] (the column solves run in double in either precision)
     long long rad_ws_cols = 0;
-    double *stage = nullptr;        // staging buffer for the layout adaptor
-    std::vector<double> h_dsigma, h_sigma_vb, h_uvdif;      // host copies of the vertical grid (-> Ptrs::mom_c)
+    real *stage = nullptr;        // staging buffer for the layout adaptor
+    std::vector<real> h_dsigma, h_sigma_vb, h_uvdif;      // host copies of the vertical grid (-> Ptrs::mom_c)
     size_t stage_elems = 0;
     int grid_set = 0;
     bool zonal = true;              // lat_rad, lat_is_rad, corf, corf_is do not vary along a row (the fused momentum kernel keeps them per wavefront)
@@ -144,7 +144,7 @@ struct dycore {
     bool lazy_flx = true;           // ... nor UFLX / VFLX: consumers re-form them from the winds (DYCORE_LAZY_FLX=0: store them)
     bool stale_flxdiv = false, stale_phivb = false, stale_uvflx = false, stale_pvtf = false;
     bool lazy_pvtf = true;          // ... nor PVTF (DYCORE_LAZY_PVTF=0: store it); only where the momentum kernel forms its own (flux_from_winds, no i_turb)
-    const double *flx_u = nullptr, *flx_v = nullptr;   // winds the last fused continuity evaluated on
+    const real *flx_u = nullptr, *flx_v = nullptr;   // winds the last fused continuity evaluated on
     bool winds_bc_dirty = true;     // UWIND / VWIND came from the host: their lateral BC images (column nx+2!) may be unset
     int n_cu = 256;                 // compute units of the device
     int cell_lin = -1;              // DYCORE_CELL_LINEAR: column-kernel launch, bit 0 = cell runs, bit 1 = XCD-aware order (default 3 or 2)
@@ -250,14 +250,14 @@ int launch_check(const char *what)
 }
 
 // lateral halo (misc_boundaries.py:22-42) of up to 12 fields in one launch
-struct HaloSpec { double *ptr; int stgx, stgy, nk; };
-int do_halo_noscope(dycore *h, const std::vector<HaloSpec> &fields, double *copy_dst = nullptr, const double *copy_src = nullptr, size_t copy_n = 0);
-int do_halo(dycore *h, const std::vector<HaloSpec> &fields, double *copy_dst = nullptr, const double *copy_src = nullptr, size_t copy_n = 0)
+struct HaloSpec { real *ptr; int stgx, stgy, nk; };
+int do_halo_noscope(dycore *h, const std::vector<HaloSpec> &fields, real *copy_dst = nullptr, const real *copy_src = nullptr, size_t copy_n = 0);
+int do_halo(dycore *h, const std::vector<HaloSpec> &fields, real *copy_dst = nullptr, const real *copy_src = nullptr, size_t copy_n = 0)
 {
     Scope s(h, K_HALO_MULTI);
     return do_halo_noscope(h, fields, copy_dst, copy_src, copy_n);
 }
-int do_halo_noscope(dycore *h, const std::vector<HaloSpec> &fields, double *copy_dst, const double *copy_src, size_t copy_n)
+int do_halo_noscope(dycore *h, const std::vector<HaloSpec> &fields, real *copy_dst, const real *copy_src, size_t copy_n)
 {
     HaloList l;
     l.copy_dst = copy_dst; l.copy_src = copy_src; l.copy_n = (long long)copy_n;
@@ -276,7 +276,7 @@ int do_halo_noscope(dycore *h, const std::vector<HaloSpec> &fields, double *copy
 }
 
 // ---- stage launches -------------------------------------------------------------------
-int do_continuity(dycore *h, const Ptrs &p, double dt)
+int do_continuity(dycore *h, const Ptrs &p, real dt)
 {
     {
         Scope s(h, K_CONTINUITY);
@@ -327,7 +327,7 @@ int do_pott(dycore *h, const Ptrs &p)
     else hipLaunchKernelGGL(k_pott_tendency<false>, gr, dim3(TI, TJ), 0, h->stream, h->g, p);
     return launch_check("k_pott_tendency");
 }
-int do_euler(dycore *h, const Ptrs &p, double dt)
+int do_euler(dycore *h, const Ptrs &p, real dt)
 {
     {
         Scope s(h, K_EULER);
@@ -365,17 +365,17 @@ int do_turbulence(dycore *h, const Ptrs &p)
     hipLaunchKernelGGL(k_turbulence, grid_for(h->g, h->g.nx + 2, h->g.ny + 2), dim3(TI, TJ), 0, h->stream, h->g, p);
     return launch_check("k_turbulence");
 }
-int do_exchange(dycore *h, double *F, int stgx, int stgy, int nk)
+int do_exchange(dycore *h, real *F, int stgx, int stgy, int nk)
 {
     Scope s(h, K_EXCHANGE);
     const int fnx = h->g.nx + 2 + stgx, fny = h->g.ny + 2 + stgy;
     hipLaunchKernelGGL(k_exchange_bc, dim3((fnx + 255) / 256, fny, nk), dim3(256), 0, h->stream, h->g, F, stgx, stgy, nk);
     return launch_check("k_exchange_bc");
 }
-int do_copy(dycore *h, double *dst, const double *src, size_t elems)
+int do_copy(dycore *h, real *dst, const real *src, size_t elems)
 {
     Scope s(h, K_COPY);
-    HIP_TRY(hipMemcpyAsync(dst, src, elems * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+    HIP_TRY(hipMemcpyAsync(dst, src, elems * sizeof(real), hipMemcpyDeviceToDevice, h->stream));
     return 0;
 }
 
@@ -392,7 +392,7 @@ bool pvtf_on_demand(const dycore *h)
 {
     return h->lazy && h->lazy_pvtf && !h->g.i_turb && flux_from_winds(h) && h->fw_mask == 7;
 }
-int do_continuity_fused(dycore *h, const Ptrs &p, double dt)
+int do_continuity_fused(dycore *h, const Ptrs &p, real dt)
 {
     const int nz = h->g.nz;
     if (!h->lazy || !(nz == 8 || nz == 16 || nz == 32 || nz == 64)) return do_continuity(h, p, dt);
@@ -401,7 +401,7 @@ int do_continuity_fused(dycore *h, const Ptrs &p, double dt)
         // Re-forming UFLX(nx+2), VFLX(ny+2) reads the winds' own boundary images.  The reference's host-side
         // initialisation leaves column nx+2 of x-staggered arrays unset (main_grid.py:317-357) and reaches it
         // only through the exchange of UFLX; apply the winds' lateral BC (misc_boundaries.py:22-42) once.
-        int rc = do_halo(h, {{const_cast<double *>(p.UWIND), 1, 0, nz}, {const_cast<double *>(p.VWIND), 0, 1, nz}});
+        int rc = do_halo(h, {{const_cast<real *>(p.UWIND), 1, 0, nz}, {const_cast<real *>(p.VWIND), 0, 1, nz}});
         if (rc) return rc;
         h->winds_bc_dirty = false;
     }
@@ -482,8 +482,8 @@ bool row_subset(int n, int dep_s, int dep_n, int mode, RowSet &rs)
 }
 
 // prepare + dUFLXdt + dVFLXdt (+ Euler step of the winds when u_out != nullptr)
-int do_momentum_fused(dycore *h, const Ptrs &p, const double *u_old, const double *v_old,
-                      double *u_out, double *v_out, double dt, int mode = ROWS_ALL)
+int do_momentum_fused(dycore *h, const Ptrs &p, const real *u_old, const real *v_old,
+                      real *u_out, real *v_out, real dt, int mode = ROWS_ALL)
 {
     // only the LDS-DMA kernel takes a tile-row subset; the others run whole with the edge part
     const bool dma = u_out && h->mom_dma == 1 && h->g.nz <= DMAXZ;
@@ -570,7 +570,7 @@ int do_momentum_fused(dycore *h, const Ptrs &p, const double *u_old, const doubl
         hipLaunchKernelGGL(k_momentum_fused<false>, gr, bl, 0, h->stream, h->g, p, gbx, gby, jv_lo, u_old, v_old, u_out, v_out, dt);
     return launch_check(dma ? "k_momentum_dma" : "k_momentum_fused");
 }
-int do_pott_fused(dycore *h, const Ptrs &p, const double *pott_old, double *pott_out, double dt)
+int do_pott_fused(dycore *h, const Ptrs &p, const real *pott_old, real *pott_out, real dt)
 {
     Scope s(h, K_POTT_FUSED);
     const dim3 gr = grid_cells(h), bl(TI, TJ);
@@ -604,7 +604,7 @@ int do_turb_tendencies(dycore *h, const Ptrs &p, int mode = ROWS_ALL)
     return launch_check("k_turb_tendencies");
 }
 // dQVdt, dQCdt (stage) or the new QV, QC directly (fused): dyn_moist.py
-int do_moist(dycore *h, const Ptrs &p, const double *qv_old, const double *qc_old, double *qv_out, double *qc_out, double dt)
+int do_moist(dycore *h, const Ptrs &p, const real *qv_old, const real *qc_old, real *qv_out, real *qc_out, real dt)
 {
     Scope s(h, K_MOIST);
     const dim3 gr = grid_cells(h), bl(TI, TJ);
@@ -638,7 +638,7 @@ int do_diag_band_halo(dycore *h, const Ptrs &p)
     if (h->g.pole_s && h->g.pole_n) return 0;
     const int row_a = h->g.pole_s ? -1 : 0, row_b = h->g.pole_n ? -1 : h->g.ny + 1;
     const dim3 gr((h->g.nx + 2 + 63) / 64, 2);
-    const size_t lds = (size_t)(h->g.nz + 1) * 64 * sizeof(double);
+    const size_t lds = (size_t)(h->g.nz + 1) * 64 * sizeof(real);
     if (h->prof == 1 || !h->side) { // full profiling brackets every launch on the main stream
         Scope s(h, K_DIAG_ROWS);
         hipLaunchKernelGGL(k_primary_diag_rows, gr, dim3(256), lds, h->stream, h->g, p, row_a, row_b);
@@ -721,15 +721,15 @@ Ptrs substep_view(dycore *h, int sub)
     }
     return q;
 }
-int substep_part(dycore *h, double dt, int sub, int part)
+int substep_part(dycore *h, real dt, int sub, int part)
 {
     int rc;
     Ptrs &p = h->p;
     const Ptrs q = substep_view(h, sub);
     if (fused_path(h)) {
-        double *u_out = sub == 0 ? p.UWIND_EST : p.UWIND;
-        double *v_out = sub == 0 ? p.VWIND_EST : p.VWIND;
-        double *t_out = sub == 0 ? p.POTT_EST : p.POTT;
+        real *u_out = sub == 0 ? p.UWIND_EST : p.UWIND;
+        real *v_out = sub == 0 ? p.VWIND_EST : p.VWIND;
+        real *t_out = sub == 0 ? p.POTT_EST : p.POTT;
         switch (part) {
         case 0:                     // -> UFLX, VFLX, WWIND, COLP_NEW halo rows
             return do_continuity_fused(h, q, dt);
@@ -750,7 +750,7 @@ int substep_part(dycore *h, double dt, int sub, int part)
                 if ((rc = do_momentum_fused(h, q, p.UWIND, p.VWIND, u_out, v_out, dt))) return rc;
             }
             if ((rc = do_pott_fused(h, q, p.POTT, t_out, dt))) return rc;
-            double *qv_out = sub == 0 ? p.QV_EST : p.QV, *qc_out = sub == 0 ? p.QC_EST : p.QC;
+            real *qv_out = sub == 0 ? p.QV_EST : p.QV, *qc_out = sub == 0 ? p.QC_EST : p.QC;
             if (h->g.i_moist && (rc = do_moist(h, q, p.QV, p.QC, qv_out, qc_out, dt))) return rc;
             const int nz = h->g.nz;
             if (h->g.i_moist && (rc = do_halo(h, {{qv_out, 0, 0, nz}, {qc_out, 0, 0, nz}}))) return rc;
@@ -789,7 +789,7 @@ int substep_part(dycore *h, double dt, int sub, int part)
     }
     return fail(DYCORE_EINVAL, "substep part %d out of range", part);
 }
-int do_step(dycore *h, double dt, int with_rho)
+int do_step(dycore *h, real dt, int with_rho)
 {
     int rc;
     if ((rc = step_begin(h, with_rho))) return rc;
@@ -806,6 +806,7 @@ extern "C" {
 
 const char *dycore_last_error(void) { return g_err.c_str(); }
 int dycore_abi_version(void) { return DYCORE_ABI_VERSION; }
+int dycore_real_bytes(void) { return (int)sizeof(real); }
 
 int dycore_create(const DycoreConfig *cfg, dycore_t **out)
 {
@@ -816,7 +817,7 @@ int dycore_create(const DycoreConfig *cfg, dycore_t **out)
         return fail(DYCORE_EINVAL, "extents too small: nx=%d ny=%d nz=%d (need nx>=3, ny>=2, nz>=2)", cfg->nx, cfg->ny, cfg->nz);
     if (cfg->ny_global < cfg->ny || cfg->j_offset < 0 || cfg->j_offset + cfg->ny > cfg->ny_global)
         return fail(DYCORE_EINVAL, "band [%d,%d] outside the global grid of %d rows", cfg->j_offset + 1, cfg->j_offset + cfg->ny, cfg->ny_global);
-    if ((double)(((cfg->nx + 3 + 63) / 64) * 64) * (cfg->ny + 3) * (cfg->nz + 1) * sizeof(double) >= 4294967296.0)
+    if ((double)(((cfg->nx + 3 + 63) / 64) * 64) * (cfg->ny + 3) * (cfg->nz + 1) * sizeof(real) >= 4294967296.0)
         return fail(DYCORE_EINVAL, "a field of %d x %d x %d cells is 4 GiB or more: cut the grid into latitude bands", cfg->nx, cfg->ny, cfg->nz);
     int ndev = 0;
     HIP_TRY(hipGetDeviceCount(&ndev));
@@ -876,8 +877,8 @@ int dycore_create(const DycoreConfig *cfg, dycore_t **out)
     }
     h->home = h->stream;
     if (!(g.pole_s && g.pole_n)) {      // a band of a decomposed grid
-        if ((size_t)(g.nz + 1) * 64 * sizeof(double) > 65536 &&
-            hipFuncSetAttribute((const void *)k_primary_diag_rows, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((g.nz + 1) * 64 * sizeof(double))) != hipSuccess) {
+        if ((size_t)(g.nz + 1) * 64 * sizeof(real) > 65536 &&
+            hipFuncSetAttribute((const void *)k_primary_diag_rows, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((g.nz + 1) * 64 * sizeof(real))) != hipSuccess) {
             (void)hipGetLastError();
             delete h;
             return fail(DYCORE_EINVAL, "too many levels (%d) for the halo-row diagnostics of a latitude band", g.nz);
@@ -889,26 +890,27 @@ int dycore_create(const DycoreConfig *cfg, dycore_t **out)
             h->side = nullptr;
         }
     }
-    const double nan = std::numeric_limits<double>::quiet_NaN();
+    const real nan = std::numeric_limits<real>::quiet_NaN();
     // Every array is placed so that column i = 1 (the first owned longitude) of every row sits
     // on a 512-B boundary: a wavefront's 64 x 8 B row segment then covers exactly four 128-B
     // lines instead of straddling five (FETCH_SIZE -20 % on the column kernels).  The 63
     // doubles in front also absorb the i0-2 start of the first momentum tile.
-    auto alloc = [&](size_t elems, double **out_p) -> int {
+    auto alloc = [&](size_t elems, real **out_p) -> int {
         char *raw = nullptr;
-        const size_t bytes = (elems + 64 + 128) * sizeof(double) + 512;
+        constexpr size_t LEAD = 512 / sizeof(real) - 1;       // elements in front of i = 0, so that i = 1 sits on the 512-B boundary
+        const size_t bytes = (elems + LEAD + 1 + 128) * sizeof(real) + 512;
         hipError_t e = hipMalloc((void **)&raw, bytes);
         if (e != hipSuccess) return fail(DYCORE_ENOMEM, "hipMalloc of %zu bytes failed: %s", bytes, hipGetErrorString(e));
-        h->allocs.push_back((double *)raw);
+        h->allocs.push_back((real *)raw);
         char *al = (char *)(((uintptr_t)raw + 511) & ~(uintptr_t)511);
-        double *d = (double *)al + 63;
-        hipLaunchKernelGGL(k_fill, dim3(1024), dim3(256), 0, h->stream, (double *)al, elems + 64 + 128, nan);   // main_fields.py:484
+        real *d = (real *)al + LEAD;
+        hipLaunchKernelGGL(k_fill, dim3(1024), dim3(256), 0, h->stream, (real *)al, elems + LEAD + 1 + 128, nan);   // main_fields.py:484
         *out_p = d;
         return 0;
     };
     int rc = 0;
     for (int f = 0; f < kNFields && !rc; f++) {
-        double *d = nullptr;
+        real *d = nullptr;
         if (!kFields[f].rad || (kFields[f].rad == 1 && g.i_rad) || (kFields[f].rad == 2 && g.i_turb)) rc = alloc(h->field_elems(kFields[f].nk), &d);
         h->p.*(kFields[f].member) = d;
         h->field_idx[kFields[f].name] = f;
@@ -918,31 +920,32 @@ int dycore_create(const DycoreConfig *cfg, dycore_t **out)
         long long chunk = ((1LL << 27) / per) / 256 * 256;
         if (chunk < 256) chunk = 256;
         if (chunk > cols) chunk = (cols + 255) / 256 * 256;
-        double *d = nullptr;
-        rc = alloc((size_t)(chunk * per), &d);
-        h->rad_ws = d;
+        void *d = nullptr;          // doubles in either precision, outside the field registry
+        if (hipMalloc(&d, (size_t)(chunk * per) * sizeof(double)) != hipSuccess) rc = fail(DYCORE_ENOMEM, "hipMalloc of the radiation workspace failed");
+        else h->allocs.push_back((real *)d);
+        h->rad_ws = (double *)d;
         h->rad_ws_cols = chunk;
     }
     for (int f = 0; f < kNGrid && !rc; f++) {
-        double *d = nullptr;
+        real *d = nullptr;
         const size_t elems = kGrid[f].stgx < 0 ? (size_t)(g.nz + 1) : (size_t)g.plane;
         rc = alloc(elems, &d);
         h->p.*(kGrid[f].member) = d;
         h->grid_idx[kGrid[f].name] = f;
     }
     if (!rc) {
-        double *d = nullptr;
+        real *d = nullptr;
         rc = alloc((size_t)(g.nz + 1), &d);
         h->p.rdsigma = d;
     }
     if (!rc) {
-        double *d = nullptr;
+        real *d = nullptr;
         rc = alloc((size_t)(5 * (g.nz + 2)), &d);
         h->p.mom_c = d;
     }
     if (!rc) {
         h->stage_elems = (size_t)(g.nx + 3) * (g.ny + 3) * (g.nz + 1);
-        double *d = nullptr;
+        real *d = nullptr;
         rc = alloc(h->stage_elems, &d);
         h->stage = d;
     }
@@ -958,7 +961,7 @@ int dycore_destroy(dycore_t *h)
     (void)hipStreamSynchronize(h->stream);
     for (auto &r : h->recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     for (auto e : h->ev_pool) (void)hipEventDestroy(e);
-    for (double *d : h->allocs) (void)hipFree(d);
+    for (real *d : h->allocs) (void)hipFree(d);
     if (h->side) { (void)hipStreamSynchronize(h->side); (void)hipStreamDestroy(h->side); }
     if (h->ev_main) (void)hipEventDestroy(h->ev_main);
     if (h->ev_side) (void)hipEventDestroy(h->ev_side);
@@ -985,23 +988,23 @@ int dycore_sync(dycore_t *h)
     return 0;
 }
 
-int dycore_set_grid(dycore_t *h, const char *name, const double *host, int32_t n0, int32_t n1, int32_t n2)
+int dycore_set_grid(dycore_t *h, const char *name, const real *host, int32_t n0, int32_t n1, int32_t n2)
 {
     if (!h || !name || !host) return fail(DYCORE_EINVAL, "null argument");
     auto it = h->grid_idx.find(name);
     if (it == h->grid_idx.end()) return fail(DYCORE_EINVAL, "unknown grid array '%s'", name);
     const GridDesc &d = kGrid[it->second];
     const Geo &g = h->g;
-    double *dev = const_cast<double *>(h->p.*(d.member));
+    real *dev = const_cast<real *>(h->p.*(d.member));
     if (d.stgx < 0) {
         const int n = d.nk == 0 ? g.nz : g.nz + 1;
         if ((long long)n0 * n1 * n2 != n) return fail(DYCORE_EINVAL, "grid array '%s': expected %d elements, got %dx%dx%d", name, n, n0, n1, n2);
-        HIP_TRY(hipMemcpyAsync(dev, host, n * sizeof(double), hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(hipMemcpyAsync(dev, host, n * sizeof(real), hipMemcpyHostToDevice, h->stream));
         HIP_TRY(hipStreamSynchronize(h->stream));
         if (d.member == &Ptrs::dsigma) {
-            std::vector<double> r(n);
+            std::vector<real> r(n);
             for (int k = 0; k < n; k++) r[k] = 1.0 / host[k];
-            HIP_TRY(hipMemcpyAsync(const_cast<double *>(h->p.rdsigma), r.data(), n * sizeof(double), hipMemcpyHostToDevice, h->stream));
+            HIP_TRY(hipMemcpyAsync(const_cast<real *>(h->p.rdsigma), r.data(), n * sizeof(real), hipMemcpyHostToDevice, h->stream));
             HIP_TRY(hipStreamSynchronize(h->stream));
             h->h_dsigma.assign(host, host + n);
         }
@@ -1011,19 +1014,19 @@ int dycore_set_grid(dycore_t *h, const char *name, const double *host, int32_t n
             !h->h_dsigma.empty() && !h->h_sigma_vb.empty() && !h->h_uvdif.empty()) {
             // the momentum kernel's per-level constants (Ptrs::mom_c); plain IEEE operations, no contraction possible
             const int nz = g.nz, cs = nz + 2;
-            std::vector<double> m(5 * (size_t)cs, 0.0);
+            std::vector<real> m(5 * (size_t)cs, 0.0);
             for (int t = 0; t <= nz; t++) {
                 m[3 * cs + t] = h->h_sigma_vb[t];
                 if (t < nz) {
-                    const double ds = h->h_dsigma[t];
-                    const double rsum = t > 0 ? 1.0 / (ds + h->h_dsigma[t - 1]) : 0.0;
+                    const real ds = h->h_dsigma[t];
+                    const real rsum = t > 0 ? 1.0 / (ds + h->h_dsigma[t - 1]) : 0.0;
                     m[t] = ds * rsum;
                     m[cs + t] = t > 0 ? h->h_dsigma[t - 1] * rsum : 0.0;
                     m[2 * cs + t] = 1.0 / ds;
                     m[4 * cs + t] = h->h_uvdif[t];
                 }
             }
-            HIP_TRY(hipMemcpyAsync(const_cast<double *>(h->p.mom_c), m.data(), m.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
+            HIP_TRY(hipMemcpyAsync(const_cast<real *>(h->p.mom_c), m.data(), m.size() * sizeof(real), hipMemcpyHostToDevice, h->stream));
             HIP_TRY(hipStreamSynchronize(h->stream));
         }
     } else {
@@ -1038,7 +1041,7 @@ int dycore_set_grid(dycore_t *h, const char *name, const double *host, int32_t n
                 for (int i = 2; i <= g.nx + d.stgx; i++)
                     if (host[(size_t)i * n1 + j] != host[(size_t)1 * n1 + j]) { h->zonal = false; break; }
         }
-        HIP_TRY(hipMemcpyAsync(h->stage, host, n * sizeof(double), hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(hipMemcpyAsync(h->stage, host, n * sizeof(real), hipMemcpyHostToDevice, h->stream));
         hipLaunchKernelGGL(k_to_device, dim3((n0 + 31) / 32, 1, n1), dim3(32, 8), 0, h->stream, g, h->stage, dev, n0, n1, 1);
         int rc = launch_check("k_to_device");
         if (rc) return rc;
@@ -1077,7 +1080,7 @@ int dycore_field_shape(dycore_t *h, const char *name, int32_t shape[3])
     return 0;
 }
 
-int dycore_upload(dycore_t *h, const char *name, const double *host)
+int dycore_upload(dycore_t *h, const char *name, const real *host)
 {
     const FieldDesc *d;
     int rc = find_field(h, name, &d);
@@ -1089,7 +1092,7 @@ int dycore_upload(dycore_t *h, const char *name, const double *host)
     const Geo &g = h->g;
     const int n0 = g.nx + 2 + d->stgx, n1 = g.ny + 2 + d->stgy, n2 = h->nk_of(d->nk);
     const size_t n = (size_t)n0 * n1 * n2;
-    HIP_TRY(hipMemcpyAsync(h->stage, host, n * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipMemcpyAsync(h->stage, host, n * sizeof(real), hipMemcpyHostToDevice, h->stream));
     hipLaunchKernelGGL(k_to_device, dim3((n0 + 31) / 32, (n2 + 31) / 32, n1), dim3(32, 8), 0, h->stream,
                        g, h->stage, h->p.*(d->member), n0, n1, n2);
     if ((rc = launch_check("k_to_device"))) return rc;
@@ -1107,7 +1110,7 @@ static int lazy_need(const FieldDesc *d)
     return 0;
 }
 
-int dycore_download(dycore_t *h, const char *name, double *host)
+int dycore_download(dycore_t *h, const char *name, real *host)
 {
     const FieldDesc *d;
     int rc = find_field(h, name, &d);
@@ -1121,7 +1124,7 @@ int dycore_download(dycore_t *h, const char *name, double *host)
     hipLaunchKernelGGL(k_to_host, dim3((n0 + 31) / 32, (n2 + 31) / 32, n1), dim3(32, 8), 0, h->stream,
                        g, h->p.*(d->member), h->stage, n0, n1, n2);
     if ((rc = launch_check("k_to_host"))) return rc;
-    HIP_TRY(hipMemcpyAsync(host, h->stage, n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipMemcpyAsync(host, h->stage, n * sizeof(real), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
     return 0;
 }
@@ -1268,7 +1271,7 @@ static int rows_op(dycore_t *h, int32_t n, const char *const *names, const int32
         if (dev_buf && rl.n) {
             Scope s(h, K_HALO);
             hipLaunchKernelGGL(k_rows, dim3((h->g.nx + 3 + 255) / 256, maxk, rl.n), dim3(256), 0, h->stream,
-                               h->g, rl, (double *)dev_buf, unpack);
+                               h->g, rl, (real *)dev_buf, unpack);
             int rc = launch_check("k_rows");
             if (rc) return rc;
         }

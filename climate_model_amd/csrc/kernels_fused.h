@@ -25,7 +25,9 @@ namespace dyc {
 
 constexpr int FTI = 64;                // lanes along i per workgroup (one wavefront per row)
 constexpr int FTJ = 8;                 // rows per workgroup
-constexpr int FTW = 68;                // tile width: i-1 .. i+2 for 64 lanes (67), padded
+constexpr int VW = 16 / sizeof(real);   // values per 16-B DMA chunk: 2 (double), 4 (float)
+constexpr int FXO = VW;                // k_momentum_dma: tile column 0 is longitude i0 - FXO, a 16-B boundary (i = 1 sits on a 512-B one)
+constexpr int FTW = ((64 + FXO + 2 + VW - 1) / VW) * VW;    // tile width: i-1 .. i+2 for 64 lanes behind FXO-1 spare columns: 68 / 72
 constexpr int FTH = FTJ + 3;           // tile height: j-1 .. j+2
 constexpr int FTN = FTW * FTH;         // doubles per tile
 constexpr int FNT = FTI * FTJ;          // threads per workgroup
@@ -86,10 +88,10 @@ __device__ __forceinline__ bool xcd_tile_at(int b, int gbx, int gby, int &bx, in
 // In the corrector u_out aliases u_old (in-place update of the own cell), hence no __restrict__.
 template <bool EULER>
 __global__ __launch_bounds__(FNT) void k_momentum_fused(Geo g, Ptrs p, int gbx, int gby, int jv_lo,
-                                                        const double *u_old, const double *v_old,
-                                                        double *u_out, double *v_out, double dt)
+                                                        const real *u_old, const real *v_old,
+                                                        real *u_out, real *v_out, real dt)
 {
-    __shared__ double sm[FNF][FTN];
+    __shared__ real sm[FNF][FTN];
     int bx, by;
     if (!xcd_tile(gbx, gby, bx, by)) return;
     const int tx = threadIdx.x, ty = threadIdx.y;
@@ -113,7 +115,7 @@ __global__ __launch_bounds__(FNT) void k_momentum_fused(Geo g, Ptrs p, int gbx, 
             goff1 = gj * P + gi;
         }
     }
-    const double *src[FNF] = {p.UFLX, p.VFLX, p.UWIND, p.VWIND, p.WWIND, p.PHI, p.POTT, p.PVTF, p.PVTFVB};
+    const real *src[FNF] = {p.UFLX, p.VFLX, p.UWIND, p.VWIND, p.WWIND, p.PHI, p.POTT, p.PVTF, p.PVTFVB};
     // WWIND and PVTFVB are staged at interface k+1
     const int kofs[FNF] = {0, 0, 0, 0, 1, 0, 0, 0, 1};
     enum { S_UF = 0, S_VF, S_UW, S_VW, S_W, S_PHI, S_POTT, S_PVTF, S_PVB };
@@ -123,7 +125,7 @@ __global__ __launch_bounds__(FNT) void k_momentum_fused(Geo g, Ptrs p, int gbx, 
     const int jg = j + g.joff;
     const bool lo = (jg == 1), hi = (jg == g.ny_global);
     const bool v_on = active && (j >= jv_lo);            // dVFLXdt row owned and not a pole
-    double ca[3][3];                                     // COLP_NEW * A at (i+a-1, j+b-1)
+    real ca[3][3];                                     // COLP_NEW * A at (i+a-1, j+b-1)
 #pragma unroll
     for (int b = 0; b < 3; b++)
 #pragma unroll
@@ -131,17 +133,17 @@ __global__ __launch_bounds__(FNT) void k_momentum_fused(Geo g, Ptrs p, int gbx, 
             const size_t q2 = c + (b - 1) * P + (a - 1);
             ca[b][a] = p.COLP_NEW[q2] * p.A[q2];
         }
-    const double colp = p.COLP[c], colp_im1 = p.COLP[c - 1], colp_jm1 = p.COLP[c - P];
-    const double corf_is = p.corf_is[c], lat_is = p.lat_is_rad[c];
-    const double cos_is = cos(lat_is), sin_is = sin(lat_is);
-    const double corf = p.corf[c], corf_jm1 = p.corf[c - P];
-    const double lat = p.lat_rad[c], lat_jm1 = p.lat_rad[c - P];
-    const double cos_c = cos(lat), sin_c = sin(lat), cos_jm1 = cos(lat_jm1), sin_jm1 = sin(lat_jm1);
-    const double dlon = p.dlon_rad[c], dlat = p.dlat_rad[c], dyis = p.dyis[c], dxjs = p.dxjs[c];
+    const real colp = p.COLP[c], colp_im1 = p.COLP[c - 1], colp_jm1 = p.COLP[c - P];
+    const real corf_is = p.corf_is[c], lat_is = p.lat_is_rad[c];
+    const real cos_is = cos(lat_is), sin_is = sin(lat_is);
+    const real corf = p.corf[c], corf_jm1 = p.corf[c - P];
+    const real lat = p.lat_rad[c], lat_jm1 = p.lat_rad[c - P];
+    const real cos_c = cos(lat), sin_c = sin(lat), cos_jm1 = cos(lat_jm1), sin_jm1 = sin(lat_jm1);
+    const real dlon = p.dlon_rad[c], dlat = p.dlat_rad[c], dyis = p.dyis[c], dxjs = p.dxjs[c];
     // pressure weights of the Euler step at the u- and v-point: dyn_timestep.py:42-79
-    double ca_is = 1.0, cao_is = 1.0, ca_js = 1.0, cao_js = 1.0;
+    real ca_is = 1.0, cao_is = 1.0, ca_js = 1.0, cao_js = 1.0;
     if (EULER) {
-        double co[3][3];                                 // COLP_OLD * A
+        real co[3][3];                                 // COLP_OLD * A
 #pragma unroll
         for (int b = 0; b < 3; b++)
 #pragma unroll
@@ -170,24 +172,24 @@ __global__ __launch_bounds__(FNT) void k_momentum_fused(Geo g, Ptrs p, int gbx, 
     const int lx = tx + 1, ly = ty + 1;                  // own cell inside the tile
 #define SM(f, a, b) sm[f][(ly + (b)) * FTW + (lx + (a))]
 
-    double wu_k = 0.0, wv_k = 0.0;                       // interface products at k (0 at the top)
-    double u_k = active ? p.UWIND[c] : 0.0, v_k = active ? p.VWIND[c] : 0.0;
-    double pvb_k = p.PVTFVB[c], pvb_im1_k = p.PVTFVB[c - 1], pvb_jm1_k = p.PVTFVB[c - P];
+    real wu_k = 0.0, wv_k = 0.0;                       // interface products at k (0 at the top)
+    real u_k = active ? p.UWIND[c] : 0.0, v_k = active ? p.VWIND[c] : 0.0;
+    real pvb_k = p.PVTFVB[c], pvb_im1_k = p.PVTFVB[c - 1], pvb_jm1_k = p.PVTFVB[c - P];
 
 #pragma unroll 1
     for (int k = 0; k < g.nz; k++) {
         // ---- stage the nine tiles of this level ----
-        double r0[FNF], r1[FNF];
+        real r0[FNF], r1[FNF];
 #pragma unroll
         for (int f = 0; f < FNF; f++) {
-            const double *s = src[f] + (size_t)(k + kofs[f]) * g.plane;
+            const real *s = src[f] + (size_t)(k + kofs[f]) * g.plane;
             r0[f] = s[goff0];
             r1[f] = has1 ? s[goff1] : 0.0;
         }
         // next level's own-cell winds (vertical interpolation to interface k+1)
         const bool last = (k == g.nz - 1);
         const size_t qn = c + (size_t)(last ? k : k + 1) * g.plane;
-        const double u_kp1 = p.UWIND[qn], v_kp1 = p.VWIND[qn];
+        const real u_kp1 = p.UWIND[qn], v_kp1 = p.VWIND[qn];
         __syncthreads();                                  // previous level fully consumed
 #pragma unroll
         for (int f = 0; f < FNF; f++) {
@@ -198,9 +200,9 @@ __global__ __launch_bounds__(FNT) void k_momentum_fused(Geo g, Ptrs p, int gbx, 
 
         if (active) {
             const size_t q = c + (size_t)k * g.plane;
-            const double ds = p.dsigma[k];
+            const real ds = p.dsigma[k];
             // ---- UFLX (i-1..i+2, j-1..j+1) and VFLX (i-1..i+1, j-1..j+2) neighbourhoods ----
-            double uf[3][4], vf[4][3];
+            real uf[3][4], vf[4][3];
 #pragma unroll
             for (int b = 0; b < 3; b++)
 #pragma unroll
@@ -212,7 +214,7 @@ __global__ __launch_bounds__(FNT) void k_momentum_fused(Geo g, Ptrs p, int gbx, 
 #define UF(a, b) uf[(b) + 1][(a) + 1]
 #define VF(a, b) vf[(b) + 1][(a) + 1]
             // wind neighbourhoods
-            double uw[3][3], vw[3][3];
+            real uw[3][3], vw[3][3];
 #pragma unroll
             for (int b = 0; b < 3; b++)
 #pragma unroll
@@ -220,40 +222,40 @@ __global__ __launch_bounds__(FNT) void k_momentum_fused(Geo g, Ptrs p, int gbx, 
 #define U(a, b) uw[(b) + 1][(a) + 1]
 #define V(a, b) vw[(b) + 1][(a) + 1]
             // ---- interface k+1: WWIND*U, WWIND*V (dyn_functions.py:211-270) ----
-            double wu_kp1 = 0.0, wv_kp1 = 0.0;
+            real wu_kp1 = 0.0, wv_kp1 = 0.0;
             if (!last) {
-                const double ds1 = p.dsigma[k + 1];
+                const real ds1 = p.dsigma[k + 1];
 #define WT(a, b) (ca[(b) + 1][(a) + 1] * SM(S_W, a, b))
 #define WT2(a, b) (2.0 * ca[(b) + 1][(a) + 1] * SM(S_W, a, b))
-                double s;
+                real s;
                 if (lo) s = 0.25 * (WT(-1, 1) + WT(0, 1) + WT(-1, 0) + WT(0, 0));
                 else if (hi) s = 0.25 * (WT(-1, 0) + WT(0, 0) + WT(-1, -1) + WT(0, -1));
                 else s = 0.125 * (WT(-1, 1) + WT(0, 1) + WT2(-1, 0) + WT2(0, 0) + WT(-1, -1) + WT(0, -1));
                 wu_kp1 = s * ((ds1 * u_k + ds * u_kp1) / (ds1 + ds));
-                const double sv = 0.125 * (WT(1, -1) + WT(1, 0) + WT2(0, -1) + WT2(0, 0) + WT(-1, -1) + WT(-1, 0));
+                const real sv = 0.125 * (WT(1, -1) + WT(1, 0) + WT2(0, -1) + WT2(0, 0) + WT(-1, -1) + WT(-1, 0));
                 wv_kp1 = sv * ((ds1 * v_k + ds * v_kp1) / (ds1 + ds));
 #undef WT
 #undef WT2
             }
-            const double svb = p.sigma_vb[k], svb1 = p.sigma_vb[k + 1];
-            const double dif = p.UVFLX_dif_coef[k];
-            const double pvb_kp1 = SM(S_PVB, 0, 0), pvb_im1_kp1 = SM(S_PVB, -1, 0), pvb_jm1_kp1 = SM(S_PVB, 0, -1);
-            const double phi = SM(S_PHI, 0, 0), pott = SM(S_POTT, 0, 0), pvtf = SM(S_PVTF, 0, 0);
+            const real svb = p.sigma_vb[k], svb1 = p.sigma_vb[k + 1];
+            const real dif = p.UVFLX_dif_coef[k];
+            const real pvb_kp1 = SM(S_PVB, 0, 0), pvb_im1_kp1 = SM(S_PVB, -1, 0), pvb_jm1_kp1 = SM(S_PVB, 0, -1);
+            const real phi = SM(S_PHI, 0, 0), pott = SM(S_POTT, 0, 0), pvtf = SM(S_PVTF, 0, 0);
 
             // =============================== dUFLXdt ===============================
             {
-                double bflx = 1.0 / 12.0 * (UF(0, -1) + UF(1, -1) + 2.0 * (UF(0, 0) + UF(1, 0)) + UF(0, 1) + UF(1, 1));
-                double bflx_im1 = 1.0 / 12.0 * (UF(-1, -1) + UF(0, -1) + 2.0 * (UF(-1, 0) + UF(0, 0)) + UF(-1, 1) + UF(0, 1));
-                double cflx = 1.0 / 12.0 * (VF(-1, -1) + VF(0, -1) + 2.0 * (VF(-1, 0) + VF(0, 0)) + VF(-1, 1) + VF(0, 1));
-                double cflx_jp1 = 1.0 / 12.0 * (VF(-1, 0) + VF(0, 0) + 2.0 * (VF(-1, 1) + VF(0, 1)) + VF(-1, 2) + VF(0, 2));
-                double dflx_im1 = 1.0 / 24.0 * (VF(-1, -1) + 2.0 * VF(-1, 0) + VF(-1, 1) + UF(-1, -1) + UF(-1, 0) + UF(0, -1) + UF(0, 0));
-                double dflx_jp1 = 1.0 / 24.0 * (VF(0, 0) + 2.0 * VF(0, 1) + VF(0, 2) + UF(0, 0) + UF(0, 1) + UF(1, 0) + UF(1, 1));
-                double eflx = 1.0 / 24.0 * (VF(0, -1) + 2.0 * VF(0, 0) + VF(0, 1) - UF(0, -1) - UF(0, 0) - UF(1, -1) - UF(1, 0));
-                double eflx_im1_jp1 = 1.0 / 24.0 * (VF(-1, 0) + 2.0 * VF(-1, 1) + VF(-1, 2) - UF(-1, 0) - UF(-1, 1) - UF(0, 0) - UF(0, 1));
+                real bflx = 1.0 / 12.0 * (UF(0, -1) + UF(1, -1) + 2.0 * (UF(0, 0) + UF(1, 0)) + UF(0, 1) + UF(1, 1));
+                real bflx_im1 = 1.0 / 12.0 * (UF(-1, -1) + UF(0, -1) + 2.0 * (UF(-1, 0) + UF(0, 0)) + UF(-1, 1) + UF(0, 1));
+                real cflx = 1.0 / 12.0 * (VF(-1, -1) + VF(0, -1) + 2.0 * (VF(-1, 0) + VF(0, 0)) + VF(-1, 1) + VF(0, 1));
+                real cflx_jp1 = 1.0 / 12.0 * (VF(-1, 0) + VF(0, 0) + 2.0 * (VF(-1, 1) + VF(0, 1)) + VF(-1, 2) + VF(0, 2));
+                real dflx_im1 = 1.0 / 24.0 * (VF(-1, -1) + 2.0 * VF(-1, 0) + VF(-1, 1) + UF(-1, -1) + UF(-1, 0) + UF(0, -1) + UF(0, 0));
+                real dflx_jp1 = 1.0 / 24.0 * (VF(0, 0) + 2.0 * VF(0, 1) + VF(0, 2) + UF(0, 0) + UF(0, 1) + UF(1, 0) + UF(1, 1));
+                real eflx = 1.0 / 24.0 * (VF(0, -1) + 2.0 * VF(0, 0) + VF(0, 1) - UF(0, -1) - UF(0, 0) - UF(1, -1) - UF(1, 0));
+                real eflx_im1_jp1 = 1.0 / 24.0 * (VF(-1, 0) + 2.0 * VF(-1, 1) + VF(-1, 2) - UF(-1, 0) - UF(-1, 1) - UF(0, 0) - UF(0, 1));
                 if (lo) { dflx_im1 = 0.0; cflx = 0.0; eflx = 0.0; }
                 if (hi) { dflx_jp1 = 0.0; cflx_jp1 = 0.0; eflx_im1_jp1 = 0.0; }
-                const double u = U(0, 0), u_im1 = U(-1, 0), u_ip1 = U(1, 0);
-                double t = 0.0;
+                const real u = U(0, 0), u_im1 = U(-1, 0), u_ip1 = U(1, 0);
+                real t = 0.0;
                 t = t + (+bflx_im1 * (u_im1 + u) / 2.0 - bflx * (u + u_ip1) / 2.0
                          + cflx * (U(0, -1) + u) / 2.0 - cflx_jp1 * (u + U(0, 1)) / 2.0
                          + dflx_im1 * (U(-1, -1) + u) / 2.0 - dflx_jp1 * (u + U(1, 1)) / 2.0
@@ -272,22 +274,22 @@ __global__ __launch_bounds__(FNT) void k_momentum_fused(Geo g, Ptrs p, int gbx, 
             }
             // =============================== dVFLXdt ===============================
             if (v_on) {
-                const double rflx = 1.0 / 12.0 * (VF(-1, 0) + VF(-1, 1) + 2.0 * (VF(0, 0) + VF(0, 1)) + VF(1, 0) + VF(1, 1));
-                const double rflx_jm1 = 1.0 / 12.0 * (VF(-1, -1) + VF(-1, 0) + 2.0 * (VF(0, -1) + VF(0, 0)) + VF(1, -1) + VF(1, 0));
-                const double qflx = 1.0 / 12.0 * (UF(-1, -1) + UF(-1, 0) + 2.0 * (UF(0, -1) + UF(0, 0)) + UF(1, -1) + UF(1, 0));
-                const double qflx_ip1 = 1.0 / 12.0 * (UF(0, -1) + UF(0, 0) + 2.0 * (UF(1, -1) + UF(1, 0)) + UF(2, -1) + UF(2, 0));
-                const double sflx_jm1 = 1.0 / 24.0 * (VF(-1, -1) + VF(-1, 0) + VF(0, -1) + VF(0, 0) + UF(-1, -1) + 2.0 * UF(0, -1) + UF(1, -1));
-                const double sflx_ip1 = 1.0 / 24.0 * (VF(0, 0) + VF(0, 1) + VF(1, 0) + VF(1, 1) + UF(0, 0) + 2.0 * UF(1, 0) + UF(2, 0));
-                const double tflx = 1.0 / 24.0 * (VF(-1, 0) + VF(-1, 1) + VF(0, 0) + VF(0, 1) - UF(-1, 0) - 2.0 * UF(0, 0) - UF(1, 0));
-                const double tflx_ip1_jm1 = 1.0 / 24.0 * (VF(0, -1) + VF(0, 0) + VF(1, -1) + VF(1, 0) - UF(0, -1) - 2.0 * UF(1, -1) - UF(2, -1));
-                const double v = V(0, 0);
-                double t = 0.0;
+                const real rflx = 1.0 / 12.0 * (VF(-1, 0) + VF(-1, 1) + 2.0 * (VF(0, 0) + VF(0, 1)) + VF(1, 0) + VF(1, 1));
+                const real rflx_jm1 = 1.0 / 12.0 * (VF(-1, -1) + VF(-1, 0) + 2.0 * (VF(0, -1) + VF(0, 0)) + VF(1, -1) + VF(1, 0));
+                const real qflx = 1.0 / 12.0 * (UF(-1, -1) + UF(-1, 0) + 2.0 * (UF(0, -1) + UF(0, 0)) + UF(1, -1) + UF(1, 0));
+                const real qflx_ip1 = 1.0 / 12.0 * (UF(0, -1) + UF(0, 0) + 2.0 * (UF(1, -1) + UF(1, 0)) + UF(2, -1) + UF(2, 0));
+                const real sflx_jm1 = 1.0 / 24.0 * (VF(-1, -1) + VF(-1, 0) + VF(0, -1) + VF(0, 0) + UF(-1, -1) + 2.0 * UF(0, -1) + UF(1, -1));
+                const real sflx_ip1 = 1.0 / 24.0 * (VF(0, 0) + VF(0, 1) + VF(1, 0) + VF(1, 1) + UF(0, 0) + 2.0 * UF(1, 0) + UF(2, 0));
+                const real tflx = 1.0 / 24.0 * (VF(-1, 0) + VF(-1, 1) + VF(0, 0) + VF(0, 1) - UF(-1, 0) - 2.0 * UF(0, 0) - UF(1, 0));
+                const real tflx_ip1_jm1 = 1.0 / 24.0 * (VF(0, -1) + VF(0, 0) + VF(1, -1) + VF(1, 0) - UF(0, -1) - 2.0 * UF(1, -1) - UF(2, -1));
+                const real v = V(0, 0);
+                real t = 0.0;
                 t = t + (+rflx_jm1 * (V(0, -1) + v) / 2.0 - rflx * (v + V(0, 1)) / 2.0
                          + qflx * (V(-1, 0) + v) / 2.0 - qflx_ip1 * (v + V(1, 0)) / 2.0
                          + sflx_jm1 * (V(-1, -1) + v) / 2.0 - sflx_ip1 * (v + V(1, 1)) / 2.0
                          + -1.0 * (+tflx * (V(-1, 1) + v) / 2.0 - tflx_ip1_jm1 * (v + V(1, -1)) / 2.0));
                 t = t + (wv_k - wv_kp1) / ds;
-                const double ub_jm1 = (U(0, -1) + U(1, -1)) / 2.0, ub = (U(0, 0) + U(1, 0)) / 2.0;
+                const real ub_jm1 = (U(0, -1) + U(1, -1)) / 2.0, ub = (U(0, 0) + U(1, 0)) / 2.0;
                 t = t + -CON_RE * dlon * dlat / 2.0 *
                             (colp_jm1 * ub_jm1 * (corf_jm1 * CON_RE * cos_jm1 + ub_jm1 * sin_jm1) +
                              colp * ub * (corf * CON_RE * cos_c + ub * sin_c));
@@ -370,7 +372,7 @@ constexpr int mom_flux_slot(int tj, bool fw) { return fw ? (2 * tj + 5) * FTW : 
 // ... then (fw) two factor tiles, dyis (tj+2 rows) and dxjs (tj+3 rows), shaped like the UFLX / VFLX tiles
 constexpr size_t dma_lds_bytes(int tj, bool fw, bool cur, int depth)
 {
-    return ((size_t)(depth + 1) * mom_dma_slot(tj, fw, cur) + 3 * (size_t)mom_flux_slot(tj, fw)) * sizeof(double);
+    return ((size_t)(depth + 1) * mom_dma_slot(tj, fw, cur) + 3 * (size_t)mom_flux_slot(tj, fw)) * sizeof(real);
 }
 
 #ifndef DYC_DMA_AUX
@@ -379,12 +381,13 @@ constexpr size_t dma_lds_bytes(int tj, bool fw, bool cur, int depth)
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef const __attribute__((address_space(1))) void gbl_void_t;
 
-// a double that is the same in every lane of the wavefront, moved to scalar registers
+// a real that is the same in every lane of the wavefront, moved to scalar registers
 __device__ __forceinline__ double wave_uniform(double x)
 {
     const int lo = __builtin_amdgcn_readfirstlane(__double2loint(x)), hi = __builtin_amdgcn_readfirstlane(__double2hiint(x));
     return __hiloint2double(hi, lo);
 }
+__device__ __forceinline__ float wave_uniform(float x) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(x))); }
 
 // `s_waitcnt vmcnt(n)` for a wave-uniform run-time n (the instruction takes an immediate)
 __device__ __forceinline__ void wait_vmcnt(int n)
@@ -419,8 +422,8 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 // formed by the library when the vertical grid is set) are wave-uniform scalar loads: they use neither LDS nor vmcnt.
 template <bool OLD_IS_CUR, int TJ, bool FROM_WINDS, bool TURB = false, int DEPTH = 1>
 __global__ __launch_bounds__(FTI *TJ) void k_momentum_dma(Geo g, Ptrs p, int gbx, MomPlan plan, int jv_lo,
-                                                      const double *u_old, const double *v_old,
-                                                      double *u_out, double *v_out, double dt)
+                                                      const real *u_old, const real *v_old,
+                                                      real *u_out, real *v_out, real dt)
 {
     static_assert(DEPTH == 1 || DEPTH == 2, "ring of 2 or 3 slots");
     static_assert(!(TURB && DEPTH != 1), "the turbulence-coupled variant keeps vector loads in the loop");
@@ -429,14 +432,15 @@ __global__ __launch_bounds__(FTI *TJ) void k_momentum_dma(Geo g, Ptrs p, int gbx
     const RowSet trows = seg_b ? plan.b : plan.a;
     const int ksplit = seg_b ? plan.ks_b : plan.ks_a;
     const int gby = trows.n;            // tile rows of this segment (a subset of the band's, see RowSet)
-    constexpr int NCH = (TJ + 3) * FTW / 2, NSL = (NCH + 63) / 64;     // 16-B chunks of the tallest tile, 64-chunk slices
-    constexpr int ON = FTI * TJ, ONSL = ON / 2 / 64;                    // step-start ("old") tiles: own cells, FTI wide; 64-chunk slices
-    static_assert(ON % 128 == 0, "whole slices");
+    constexpr int CPR = FTW / VW;                                       // 16-B chunks per tile row
+    constexpr int NCH = (TJ + 3) * CPR, NSL = (NCH + 63) / 64;          // chunks of the tallest tile, 64-chunk slices
+    constexpr int ON = FTI * TJ, OCPR = FTI / VW, ONSL = ON / VW / 64;  // step-start ("old") tiles: own cells, FTI wide; 64-chunk slices
+    static_assert(ON % (VW * 64) == 0, "whole slices");
     constexpr int NS = DEPTH + 1;                                       // slots of the DMA ring
     constexpr int DSLOT = mom_dma_slot(TJ, FROM_WINDS, OLD_IS_CUR), FSLOT = mom_flux_slot(TJ, FROM_WINDS);
     constexpr int OFF_OLD = mom_off(FNF, TJ, FROM_WINDS);
     static_assert(NSL + 2 <= TJ, "not enough wavefronts for the DMA slices");
-    extern __shared__ __attribute__((aligned(16))) double dsm[];
+    extern __shared__ __attribute__((aligned(16))) real dsm[];
     // workgroup -> (tile, level chunk): `ksplit` chunks of the k range per tile give a small
     // latitude band enough workgroups to balance over the CUs (one tile per CU otherwise)
     int bx, by;
@@ -460,37 +464,37 @@ __global__ __launch_bounds__(FTI *TJ) void k_momentum_dma(Geo g, Ptrs p, int gbx
     int n_issue = 0;                                // DMA instructions this wave issues per level (wave-uniform)
     if (wave < NSL) {
         dma_on = ch < NCH;
-        const int e = 2 * (dma_on ? ch : 0), r = e / FTW, c2 = e - r * FTW;
-        goff = min(j0 - 1 + r, g.NJ - 1) * P + min(i0 - 2 + c2, P - 2);
+        const int e = VW * (dma_on ? ch : 0), r = e / FTW, c2 = e - r * FTW;
+        goff = min(j0 - 1 + r, g.NJ - 1) * P + min(i0 - FXO + c2, P - VW);
 #pragma unroll
         for (int f = (FROM_WINDS ? 2 : 0); f < FNF; f++)
-            if (wave * 64 < mom_rows(f, TJ, FROM_WINDS) * (FTW / 2)) n_issue++;
+            if (wave * 64 < mom_rows(f, TJ, FROM_WINDS) * CPR) n_issue++;
     }
-    // a slice of a step-start tile = two rows of 32 chunks (16 B each, i0 is 16-B aligned): lane -> (row, column)
-    const int orow = lane >> 5, ocol = i0 + 2 * (lane & 31);
+    // a slice of a step-start tile = VW rows of OCPR chunks (16 B each, i0 is 16-B aligned): lane -> (row, column)
+    const int orow = lane / OCPR, ocol = i0 + VW * (lane % OCPR);
     if (!OLD_IS_CUR && wave >= TJ - 2) n_issue = ONSL;
-    const double *src[FNF] = {p.UFLX, p.VFLX, p.UWIND, p.VWIND, p.WWIND, p.PHI, p.POTT, p.PVTF, p.PVTFVB};
+    const real *src[FNF] = {p.UFLX, p.VFLX, p.UWIND, p.VWIND, p.WWIND, p.PHI, p.POTT, p.PVTF, p.PVTFVB};
     const int kofs[FNF] = {0, 0, 0, 0, 1, 0, 0, 0, 1};
-    const double *osrc = (wave == TJ - 2) ? u_old : v_old;
+    const real *osrc = (wave == TJ - 2) ? u_old : v_old;
 
     auto issue = [&](int k, int slot) {
-        double *buf = dsm + slot * DSLOT;
+        real *buf = dsm + slot * DSLOT;
         if (wave < NSL) {
             if (dma_on) {
 #pragma unroll
                 for (int f = (FROM_WINDS ? 2 : 0); f < FNF; f++) {
-                    if (ch < mom_rows(f, TJ, FROM_WINDS) * (FTW / 2)) {
-                        const double *gp = src[f] + (size_t)(k + kofs[f]) * g.plane + goff;
-                        __builtin_amdgcn_global_load_lds((gbl_void_t *)gp, (lds_void_t *)(buf + mom_off(f, TJ, FROM_WINDS) + wave * 128), 16, 0, DYC_DMA_AUX);
+                    if (ch < mom_rows(f, TJ, FROM_WINDS) * CPR) {
+                        const real *gp = src[f] + (size_t)(k + kofs[f]) * g.plane + goff;
+                        __builtin_amdgcn_global_load_lds((gbl_void_t *)gp, (lds_void_t *)(buf + mom_off(f, TJ, FROM_WINDS) + wave * 64 * VW), 16, 0, DYC_DMA_AUX);
                     }
                 }
             }
         } else if (!OLD_IS_CUR && wave >= TJ - 2) {
-            double *ob = buf + OFF_OLD + (wave - (TJ - 2)) * ON;
+            real *ob = buf + OFF_OLD + (wave - (TJ - 2)) * ON;
 #pragma unroll
             for (int s5 = 0; s5 < ONSL; s5++) {
-                const double *gp = osrc + (size_t)k * g.plane + min(j0 + 2 * s5 + orow, g.NJ - 1) * P + ocol;
-                __builtin_amdgcn_global_load_lds((gbl_void_t *)gp, (lds_void_t *)(ob + s5 * 128), 16, 0, DYC_DMA_AUX);
+                const real *gp = osrc + (size_t)k * g.plane + min(j0 + VW * s5 + orow, g.NJ - 1) * P + ocol;
+                __builtin_amdgcn_global_load_lds((gbl_void_t *)gp, (lds_void_t *)(ob + s5 * 64 * VW), 16, 0, DYC_DMA_AUX);
             }
         }
     };
@@ -502,9 +506,9 @@ __global__ __launch_bounds__(FTI *TJ) void k_momentum_dma(Geo g, Ptrs p, int gbx
     const bool v_on = active && (j >= jv_lo);
     // a wavefront is one latitude row: the polar-row switches of the C, D, E fluxes are wave-uniform weights
     const bool lo_u = __builtin_amdgcn_readfirstlane((int)lo) != 0, hi_u = __builtin_amdgcn_readfirstlane((int)hi) != 0;
-    const double w24_lo = lo_u ? 0.0 : 1.0 / 24.0, w48_lo = lo_u ? 0.0 : 1.0 / 48.0;
-    const double w24_hi = hi_u ? 0.0 : 1.0 / 24.0, w48_hi = hi_u ? 0.0 : 1.0 / 48.0;
-    double ca[3][3];
+    const real w24_lo = lo_u ? 0.0 : 1.0 / 24.0, w48_lo = lo_u ? 0.0 : 1.0 / 48.0;
+    const real w24_hi = hi_u ? 0.0 : 1.0 / 24.0, w48_hi = hi_u ? 0.0 : 1.0 / 48.0;
+    real ca[3][3];
 #pragma unroll
     for (int b = 0; b < 3; b++)
 #pragma unroll
@@ -512,31 +516,31 @@ __global__ __launch_bounds__(FTI *TJ) void k_momentum_dma(Geo g, Ptrs p, int gbx
             const size_t q2 = c + (b - 1) * P + (a - 1);
             ca[b][a] = p.COLP_NEW[q2] * p.A[q2];
         }
-    const double colp = p.COLP[c], colp_im1 = p.COLP[c - 1], colp_jm1 = p.COLP[c - P];
+    const real colp = p.COLP[c], colp_im1 = p.COLP[c - 1], colp_jm1 = p.COLP[c - P];
     // Latitude and Coriolis parameter depend on the row only (a wavefront is one row of a latitude-longitude grid;
     // dycore_set_grid checks it and sends a handle with zonally varying arrays to the stage kernels): the six
     // Coriolis / metric factors live in scalar registers
-    const double lat_is = p.lat_is_rad[c];
-    const double kc_is = wave_uniform(p.corf_is[c] * CON_RE * cos(lat_is)), sin_is = wave_uniform(sin(lat_is));
-    const double lat = p.lat_rad[c], lat_jm1 = p.lat_rad[c - P];
-    const double kc_c = wave_uniform(p.corf[c] * CON_RE * cos(lat)), sin_c = wave_uniform(sin(lat));
-    const double kc_jm1 = wave_uniform(p.corf[c - P] * CON_RE * cos(lat_jm1)), sin_jm1 = wave_uniform(sin(lat_jm1));
+    const real lat_is = p.lat_is_rad[c];
+    const real kc_is = wave_uniform(p.corf_is[c] * CON_RE * cos(lat_is)), sin_is = wave_uniform(sin(lat_is));
+    const real lat = p.lat_rad[c], lat_jm1 = p.lat_rad[c - P];
+    const real kc_c = wave_uniform(p.corf[c] * CON_RE * cos(lat)), sin_c = wave_uniform(sin(lat));
+    const real kc_jm1 = wave_uniform(p.corf[c - P] * CON_RE * cos(lat_jm1)), sin_jm1 = wave_uniform(sin(lat_jm1));
     // per-column factors of the Coriolis / metric and pressure-gradient terms (formed once; the "/ 2" of the
     // reference's means are folded in exactly, the products are associated differently: <= 1 ulp each)
-    const double hsin_is = 0.5 * sin_is, hsin_c = 0.5 * sin_c, hsin_jm1 = 0.5 * sin_jm1;
-    double cor_im1, cor_c, cov_jm1, cov_c, pgu_a, pgu_b, pgv_a, pgv_b;
+    const real hsin_is = 0.5 * sin_is, hsin_c = 0.5 * sin_c, hsin_jm1 = 0.5 * sin_jm1;
+    real cor_im1, cor_c, cov_jm1, cov_c, pgu_a, pgu_b, pgv_a, pgv_b;
     {
-        const double metric = CON_RE * p.dlon_rad[c] * p.dlat_rad[c] / 2.0;
-        const double dyis = p.dyis[c], dxjs = p.dxjs[c];
+        const real metric = CON_RE * p.dlon_rad[c] * p.dlat_rad[c] / 2.0;
+        const real dyis = p.dyis[c], dxjs = p.dxjs[c];
         cor_im1 = 0.5 * metric * colp_im1; cor_c = 0.5 * metric * colp;
         cov_jm1 = -0.5 * metric * colp_jm1; cov_c = -0.5 * metric * colp;
         pgu_a = -dyis * ((colp + colp_im1) / 2.0); pgu_b = -dyis * ((colp - colp_im1) * CON_CP / 2.0);
         pgv_a = -dxjs * ((colp + colp_jm1) / 2.0); pgv_b = -dxjs * ((colp - colp_jm1) * CON_CP / 2.0);
     }
-    double ca_is, cao_is, ca_js, cao_js;
-    double wu[6], wv[6];
+    real ca_is, cao_is, ca_js, cao_js;
+    real wu[6], wv[6];
     {
-        double co[3][3];
+        real co[3][3];
 #pragma unroll
         for (int b = 0; b < 3; b++)
 #pragma unroll
@@ -561,7 +565,7 @@ __global__ __launch_bounds__(FTI *TJ) void k_momentum_dma(Geo g, Ptrs p, int gbx
         // weights of the six-point COLP_NEW * A * WWIND means at the u- and v-point (dyn_functions.py:211-270)
         // with 1/8 (1/4 at a polar row, "rigid wall") and the doubled centre pair folded in: powers of two,
         // exact.  A polar row gives its two outside points weight 0 (their WWIND halo values are finite).
-        const double ws = lo ? 0.0 : (hi ? 0.25 : 0.125), wn = hi ? 0.0 : (lo ? 0.25 : 0.125);
+        const real ws = lo ? 0.0 : (hi ? 0.25 : 0.125), wn = hi ? 0.0 : (lo ? 0.25 : 0.125);
         wu[0] = wn * CA(-1, 1); wu[1] = wn * CA(0, 1); wu[2] = 0.25 * CA(-1, 0); wu[3] = 0.25 * CA(0, 0);
         wu[4] = ws * CA(-1, -1); wu[5] = ws * CA(0, -1);
         wv[0] = 0.125 * CA(1, -1); wv[1] = 0.125 * CA(1, 0); wv[2] = 0.25 * CA(0, -1); wv[3] = 0.25 * CA(0, 0);
@@ -574,21 +578,21 @@ __global__ __launch_bounds__(FTI *TJ) void k_momentum_dma(Geo g, Ptrs p, int gbx
     // (~80 instructions) less per level -- -9 % kernel time.  The stage kernels keep the divisions.
     // ... and the pressure-weighted Euler step X_new = X_old * P_old / P + dt * dX / P (dyn_timestep.py:34-79) as
     // X_old * eu1 + dX * eu2 with eu1 = P_old * (1 / P), eu2 = dt * (1 / P) per column
-    const double eu1 = cao_is * (1.0 / ca_is), eu2 = dt * (1.0 / ca_is), ev1 = cao_js * (1.0 / ca_js), ev2 = dt * (1.0 / ca_js);
+    const real eu1 = cao_is * (1.0 / ca_is), eu2 = dt * (1.0 / ca_is), ev1 = cao_js * (1.0 / ca_js), ev2 = dt * (1.0 / ca_js);
     const size_t c0 = c + (size_t)k0 * g.plane;
-    double pvb_k = p.PVTFVB[c0], pvb_im1_k = p.PVTFVB[c0 - 1], pvb_jm1_k = p.PVTFVB[c0 - P];
+    real pvb_k = p.PVTFVB[c0], pvb_im1_k = p.PVTFVB[c0 - 1], pvb_jm1_k = p.PVTFVB[c0 - P];
     // PVTF in the thread (FROM_WINDS): 1 / ((1 + kappa) COLP) at the own cell and its western / southern neighbour
-    const double rcp_c = 1.0 / ((1.0 + CON_KAPPA) * colp), rcp_im1 = 1.0 / ((1.0 + CON_KAPPA) * colp_im1), rcp_jm1 = 1.0 / ((1.0 + CON_KAPPA) * colp_jm1);
+    const real rcp_c = 1.0 / ((1.0 + CON_KAPPA) * colp), rcp_im1 = 1.0 / ((1.0 + CON_KAPPA) * colp_im1), rcp_jm1 = 1.0 / ((1.0 + CON_KAPPA) * colp_jm1);
 
-    const int lx = tx + 2, ly = ty + 1;   // tile column 0 is longitude i0-2 (16-B aligned in HBM)
+    const int lx = tx + FXO, ly = ty + 1; // tile column 0 is longitude i0 - FXO (16-B aligned in HBM)
     // field f of the level being computed: `db` = its DMA slot, `fb` = its flux slot
 #define SM(f, a, b) ((FROM_WINDS && (f) < 2) ? fb : db)[mom_off(f, TJ, FROM_WINDS) + (ly + (b)) * FTW + (lx + (a))]
 
     // carried across levels
-    double su_k = 0.0, sv_k = 0.0;          // six-point COLP_NEW*A*WWIND sums at interface k
-    double wu_km1 = 0.0, wv_km1 = 0.0;      // WWIND*U, WWIND*V at interface k-1
-    double u_km1 = 0.0, v_km1 = 0.0, uo_km1 = 0.0, vo_km1 = 0.0;
-    double tu_km1 = 0.0, tv_km1 = 0.0;      // tendencies of level k-1 without the vertical advection
+    real su_k = 0.0, sv_k = 0.0;          // six-point COLP_NEW*A*WWIND sums at interface k
+    real wu_km1 = 0.0, wv_km1 = 0.0;      // WWIND*U, WWIND*V at interface k-1
+    real u_km1 = 0.0, v_km1 = 0.0, uo_km1 = 0.0, vo_km1 = 0.0;
+    real tu_km1 = 0.0, tv_km1 = 0.0;      // tendencies of level k-1 without the vertical advection
     if (k0 > 0) {       // a chunk that starts inside the column: interface k0 and the winds above it
 #define WG(a, b) p.WWIND[c0 + (b) * P + (a)]
         su_k = wu[0] * WG(-1, 1) + wu[1] * WG(0, 1) + wu[2] * WG(-1, 0) + wu[3] * WG(0, 0) + wu[4] * WG(-1, -1) + wu[5] * WG(0, -1);
@@ -605,16 +609,18 @@ __global__ __launch_bounds__(FTI *TJ) void k_momentum_dma(Geo g, Ptrs p, int gbx
     // a plain global load unclobbered and would issue it as a VECTOR load -- whose wait (vmcnt is in order) drains the
     // DMA prefetch.  Constant-address-space loads at a wave-uniform index are scalar loads (s_load, lgkmcnt).
     const int cs = nz + 2;
-    typedef const __attribute__((address_space(4))) double cdouble_t;
+    typedef const __attribute__((address_space(4))) real cdouble_t;
     cdouble_t *c_wa = (cdouble_t *)p.mom_c, *c_wb = c_wa + cs, *c_rds = c_wa + 2 * cs, *c_svb = c_wa + 3 * cs, *c_dif = c_wa + 4 * cs;
     // factors of the flux-tile entries this lane forms (FROM_WINDS), same element -> grid cell map as its DMA chunks
     // (the column pressures in registers, the metric factors dyis / dxjs in two LDS tiles: the register file is full)
-    double f_uc[2] = {0.0, 0.0}, f_vc[2] = {0.0, 0.0};
-    double *fac = dsm + NS * DSLOT + 2 * FSLOT;
+    real f_uc[VW], f_vc[VW];
+#pragma unroll
+    for (int d = 0; d < VW; d++) { f_uc[d] = 0.0; f_vc[d] = 0.0; }
+    real *fac = dsm + NS * DSLOT + 2 * FSLOT;
     if (FROM_WINDS) {
         for (int e = tid; e < (TJ + 3) * FTW; e += FTI * TJ) {
-            const int r = e / FTW, cc = e - r * FTW, c2 = cc & ~1;
-            const int gi = min(i0 - 2 + c2, P - 2) + (cc - c2);
+            const int r = e / FTW, cc = e - r * FTW, c2 = cc - cc % VW;
+            const int gi = min(i0 - FXO + c2, P - VW) + (cc - c2);
             const int o = min(j0 - 1 + r, g.NJ - 1) * P + gi;
             // the reference never fills column nx+2 of its x-staggered grid arrays (main_grid.py:317-357):
             // take the periodic image the UFLX halo copy would have delivered
@@ -623,10 +629,10 @@ __global__ __launch_bounds__(FTI *TJ) void k_momentum_dma(Geo g, Ptrs p, int gbx
         }
         if (wave < NSL && dma_on) {
 #pragma unroll
-            for (int d = 0; d < 2; d++) {
-                const int e = 2 * ch + d;
-                const int r = e / FTW, cc = e - r * FTW, c2 = cc & ~1;
-                const int o = min(j0 - 1 + r, g.NJ - 1) * P + min(i0 - 2 + c2, P - 2) + (cc - c2);
+            for (int d = 0; d < VW; d++) {
+                const int e = VW * ch + d;
+                const int r = e / FTW, cc = e - r * FTW, c2 = cc - cc % VW;
+                const int o = min(j0 - 1 + r, g.NJ - 1) * P + min(i0 - FXO + c2, P - VW) + (cc - c2);
                 f_uc[d] = p.UCOL[o];
                 f_vc[d] = p.VCOL[o];
             }
@@ -638,11 +644,11 @@ __global__ __launch_bounds__(FTI *TJ) void k_momentum_dma(Geo g, Ptrs p, int gbx
     // the end of the level publishes both
     auto flux_own = [&](int slot, int fslot) {
         if (FROM_WINDS && wave < NSL && dma_on) {
-            const double *nb = dsm + slot * DSLOT;
-            double *nf = dsm + NS * DSLOT + fslot * FSLOT;
-            const int e = 2 * ch;
+            const real *nb = dsm + slot * DSLOT;
+            real *nf = dsm + NS * DSLOT + fslot * FSLOT;
+            const int e = VW * ch;
 #pragma unroll
-            for (int d = 0; d < 2; d++) {
+            for (int d = 0; d < VW; d++) {
                 if (e + d < (TJ + 2) * FTW) nf[mom_off(S_UF, TJ, true) + e + d] = f_uc[d] * nb[mom_off(S_UW, TJ, true) + e + d] * fac[mom_off(S_UF, TJ, true) + e + d];
                 nf[mom_off(S_VF, TJ, true) + e + d] = f_vc[d] * nb[mom_off(S_VW, TJ, true) + e + d] * fac[mom_off(S_VF, TJ, true) + e + d];
             }
@@ -651,7 +657,7 @@ __global__ __launch_bounds__(FTI *TJ) void k_momentum_dma(Geo g, Ptrs p, int gbx
     // ---- prologue: the first DEPTH levels go out; level k0 lands and its flux tiles are formed ----
     issue(k0, 0);
     if (DEPTH == 2 && k0 + 1 < k1) issue(k0 + 1, 1);
-    double tbu_nx = 0.0, tbv_nx = 0.0;  // turbulent tendencies of the next level
+    real tbu_nx = 0.0, tbv_nx = 0.0;  // turbulent tendencies of the next level
     if (TURB) { tbu_nx = p.TURB_U[c + (size_t)k0 * g.plane]; tbv_nx = v_on ? p.TURB_V[c + (size_t)k0 * g.plane] : 0.0; }
     wait_vmcnt((DEPTH == 2 && k0 + 1 < k1) ? n_issue : 0);
     flux_own(0, k0 & 1);
@@ -668,12 +674,12 @@ __global__ __launch_bounds__(FTI *TJ) void k_momentum_dma(Geo g, Ptrs p, int gbx
         // (below), so that every older vector-memory operation of the wave precedes it and `vmcnt(n_issue)` at the
         // end of the iteration means exactly "level k+1 has landed"
         if (DEPTH == 1 && k + 1 < k1 && DYC_MOM_MODE != 2) issue(k + 1, slot1);
-        const double tbu = tbu_nx, tbv = tbv_nx;
+        const real tbu = tbu_nx, tbv = tbv_nx;
         if (TURB && k + 1 < k1) { tbu_nx = p.TURB_U[c + (size_t)(k + 1) * g.plane]; tbv_nx = v_on ? p.TURB_V[c + (size_t)(k + 1) * g.plane] : 0.0; }
-        const double *db = dsm + slot * DSLOT;
-        const double *fb = dsm + NS * DSLOT + (k & 1) * FSLOT;
+        const real *db = dsm + slot * DSLOT;
+        const real *fb = dsm + NS * DSLOT + (k & 1) * FSLOT;
         (void)fb;
-        double u = 0.0, v = 0.0, uo = 0.0, vo = 0.0;
+        real u = 0.0, v = 0.0, uo = 0.0, vo = 0.0;
         if (DYC_MOM_MODE == 1) {
             if (active) {
                 const size_t qm = c + (size_t)k * g.plane;
@@ -689,16 +695,16 @@ __global__ __launch_bounds__(FTI *TJ) void k_momentum_dma(Geo g, Ptrs p, int gbx
             }
             // ---- interface k closes level k-1 ----
             if (k >= 1) {
-                const double wa = c_wa[k], wb = c_wb[k];
-                const double wu_k = su_k * (wa * u_km1 + wb * u);
-                const double wv_k = sv_k * (wa * v_km1 + wb * v);
+                const real wa = c_wa[k], wb = c_wb[k];
+                const real wu_k = su_k * (wa * u_km1 + wb * u);
+                const real wv_k = sv_k * (wa * v_km1 + wb * v);
                 if (k > k0) {
                     const size_t qm = c + (size_t)(k - 1) * g.plane;
-                    const double rds1 = c_rds[k - 1];
-                    const double tu = tu_km1 + (wu_km1 - wu_k) * rds1;
+                    const real rds1 = c_rds[k - 1];
+                    const real tu = tu_km1 + (wu_km1 - wu_k) * rds1;
                     u_out[qm] = uo_km1 * eu1 + tu * eu2;
                     if (v_on) {
-                        const double tv = tv_km1 + (wv_km1 - wv_k) * rds1;
+                        const real tv = tv_km1 + (wv_km1 - wv_k) * rds1;
                         v_out[qm] = vo_km1 * ev1 + tv * ev2;
                     }
                 }
@@ -714,7 +720,7 @@ __global__ __launch_bounds__(FTI *TJ) void k_momentum_dma(Geo g, Ptrs p, int gbx
             }
         }
         if (DYC_MOM_MODE != 1 && active) {
-            double uf[3][4], vf[4][3], uw[3][3], vw[3][3];
+            real uf[3][4], vf[4][3], uw[3][3], vw[3][3];
 #pragma unroll
             for (int b = 0; b < 3; b++)
 #pragma unroll
@@ -733,20 +739,21 @@ __global__ __launch_bounds__(FTI *TJ) void k_momentum_dma(Geo g, Ptrs p, int gbx
 #define V(a, b) vw[(b) + 1][(a) + 1]
             // ---- six-point sums at interface k+1 (dyn_functions.py:211-270) ----
             if (k + 1 < nz) {
-                const double w_c = SM(S_W, 0, 0), w_w = SM(S_W, -1, 0), w_s = SM(S_W, 0, -1), w_sw = SM(S_W, -1, -1);
+                const real w_c = SM(S_W, 0, 0), w_w = SM(S_W, -1, 0), w_s = SM(S_W, 0, -1), w_sw = SM(S_W, -1, -1);
                 su_k = wu[0] * SM(S_W, -1, 1) + wu[1] * SM(S_W, 0, 1) + wu[2] * w_w + wu[3] * w_c + wu[4] * w_sw + wu[5] * w_s;
                 sv_k = wv[0] * SM(S_W, 1, -1) + wv[1] * SM(S_W, 1, 0) + wv[2] * w_s + wv[3] * w_c + wv[4] * w_sw + wv[5] * w_w;
             }
-            const double svb = c_svb[k], svb1 = c_svb[k + 1];
-            const double dif = c_dif[k];
-            const double rds = c_rds[k];
-            const double pvb_kp1 = SM(S_PVB, 0, 0), pvb_im1_kp1 = SM(S_PVB, -1, 0), pvb_jm1_kp1 = SM(S_PVB, 0, -1);
-            const double phi = SM(S_PHI, 0, 0), pott = SM(S_POTT, 0, 0);
-            double pvtf, pvtf_im1, pvtf_jm1;
+            const real svb = c_svb[k], svb1 = c_svb[k + 1];
+            const real dif = c_dif[k];
+            const real rds = c_rds[k];
+            const real pvb_kp1 = SM(S_PVB, 0, 0), pvb_im1_kp1 = SM(S_PVB, -1, 0), pvb_jm1_kp1 = SM(S_PVB, 0, -1);
+            const real phi = SM(S_PHI, 0, 0), pott = SM(S_POTT, 0, 0);
+            real pvtf, pvtf_im1, pvtf_jm1;
             if (FROM_WINDS) {
-                const double pk_c = g.pair_top + svb * colp, pk1_c = g.pair_top + svb1 * colp;
-                const double pk_w = g.pair_top + svb * colp_im1, pk1_w = g.pair_top + svb1 * colp_im1;
-                const double pk_s = g.pair_top + svb * colp_jm1, pk1_s = g.pair_top + svb1 * colp_jm1;
+                // (double intermediates: the difference of the two products cancels five digits; a no-op in the double build)
+                const double pk_c = (double)g.pair_top + (double)svb * colp, pk1_c = (double)g.pair_top + (double)svb1 * colp;
+                const double pk_w = (double)g.pair_top + (double)svb * colp_im1, pk1_w = (double)g.pair_top + (double)svb1 * colp_im1;
+                const double pk_s = (double)g.pair_top + (double)svb * colp_jm1, pk1_s = (double)g.pair_top + (double)svb1 * colp_jm1;
                 pvtf = (pvb_kp1 * pk1_c - pvb_k * pk_c) * (rcp_c * rds);
                 pvtf_im1 = (pvb_im1_kp1 * pk1_w - pvb_im1_k * pk_w) * (rcp_im1 * rds);
                 pvtf_jm1 = (pvb_jm1_kp1 * pk1_s - pvb_jm1_k * pk_s) * (rcp_jm1 * rds);
@@ -758,29 +765,29 @@ __global__ __launch_bounds__(FTI *TJ) void k_momentum_dma(Geo g, Ptrs p, int gbx
             // the "/ 2" of the wind mean in every advective term is applied here, where it is free -- a power of
             // two passes through every rounding unchanged.  The sums are associated pairwise instead of left to
             // right (<= 1 ulp per sum from the reference's order); 80 instead of ~125 fp64 instructions.
-            const double hx_m_m = UF(-1, -1) + UF(0, -1), hx_0_m = UF(0, -1) + UF(1, -1), hx_p_m = UF(1, -1) + UF(2, -1);
-            const double hx_m_0 = UF(-1, 0) + UF(0, 0), hx_0_0 = UF(0, 0) + UF(1, 0), hx_p_0 = UF(1, 0) + UF(2, 0);
-            const double hx_m_p = UF(-1, 1) + UF(0, 1), hx_0_p = UF(0, 1) + UF(1, 1);
-            const double gy_m_m = VF(-1, -1) + VF(-1, 0), gy_0_m = VF(0, -1) + VF(0, 0), gy_p_m = VF(1, -1) + VF(1, 0);
-            const double gy_m_0 = VF(-1, 0) + VF(-1, 1), gy_0_0 = VF(0, 0) + VF(0, 1), gy_p_0 = VF(1, 0) + VF(1, 1);
-            const double gy_m_p = VF(-1, 1) + VF(-1, 2), gy_0_p = VF(0, 1) + VF(0, 2);
-            constexpr double W24 = 1.0 / 24.0, W48 = 1.0 / 48.0;
-            const double prs = pott * rds;                 // POTT / dsigma of the own cell (pressure-gradient terms)
-            const double own = svb1 * (pvb_kp1 - pvtf) + svb * (pvtf - pvb_k);
+            const real hx_m_m = UF(-1, -1) + UF(0, -1), hx_0_m = UF(0, -1) + UF(1, -1), hx_p_m = UF(1, -1) + UF(2, -1);
+            const real hx_m_0 = UF(-1, 0) + UF(0, 0), hx_0_0 = UF(0, 0) + UF(1, 0), hx_p_0 = UF(1, 0) + UF(2, 0);
+            const real hx_m_p = UF(-1, 1) + UF(0, 1), hx_0_p = UF(0, 1) + UF(1, 1);
+            const real gy_m_m = VF(-1, -1) + VF(-1, 0), gy_0_m = VF(0, -1) + VF(0, 0), gy_p_m = VF(1, -1) + VF(1, 0);
+            const real gy_m_0 = VF(-1, 0) + VF(-1, 1), gy_0_0 = VF(0, 0) + VF(0, 1), gy_p_0 = VF(1, 0) + VF(1, 1);
+            const real gy_m_p = VF(-1, 1) + VF(-1, 2), gy_0_p = VF(0, 1) + VF(0, 2);
+            constexpr real W24 = 1.0 / 24.0, W48 = 1.0 / 48.0;
+            const real prs = pott * rds;                 // POTT / dsigma of the own cell (pressure-gradient terms)
+            const real own = svb1 * (pvb_kp1 - pvtf) + svb * (pvtf - pvb_k);
             // =============================== dUFLXdt (level k, without vertical advection) ====
             {
-                const double gx_m = VF(-1, -1) + VF(0, -1), gx_0 = VF(-1, 0) + VF(0, 0), gx_p = VF(-1, 1) + VF(0, 1), gx_pp = VF(-1, 2) + VF(0, 2);
-                const double bflx = W24 * (hx_0_m + 2.0 * hx_0_0 + hx_0_p);
-                const double bflx_im1 = W24 * (hx_m_m + 2.0 * hx_m_0 + hx_m_p);
-                const double cflx = w24_lo * (gx_m + 2.0 * gx_0 + gx_p);          // 0 at the southern polar row (dyn_UFLX.py:377-384)
-                const double cflx_jp1 = w24_hi * (gx_0 + 2.0 * gx_p + gx_pp);     // 0 at the northern polar row
-                const double dflx_im1 = w48_lo * ((gy_m_m + gy_m_0) + (hx_m_m + hx_m_0));
-                const double dflx_jp1 = w48_hi * ((gy_0_0 + gy_0_p) + (hx_0_0 + hx_0_p));
-                const double eflx = w48_lo * ((gy_0_m + gy_0_0) - (hx_0_m + hx_0_0));
-                const double eflx_im1_jp1 = w48_hi * ((gy_m_0 + gy_m_p) - (hx_m_0 + hx_m_p));
-                const double u_im1 = U(-1, 0), u_ip1 = U(1, 0);
-                const double um = u_im1 + u, up = u + u_ip1;
-                double t = (+bflx_im1 * um - bflx * up
+                const real gx_m = VF(-1, -1) + VF(0, -1), gx_0 = VF(-1, 0) + VF(0, 0), gx_p = VF(-1, 1) + VF(0, 1), gx_pp = VF(-1, 2) + VF(0, 2);
+                const real bflx = W24 * (hx_0_m + 2.0 * hx_0_0 + hx_0_p);
+                const real bflx_im1 = W24 * (hx_m_m + 2.0 * hx_m_0 + hx_m_p);
+                const real cflx = w24_lo * (gx_m + 2.0 * gx_0 + gx_p);          // 0 at the southern polar row (dyn_UFLX.py:377-384)
+                const real cflx_jp1 = w24_hi * (gx_0 + 2.0 * gx_p + gx_pp);     // 0 at the northern polar row
+                const real dflx_im1 = w48_lo * ((gy_m_m + gy_m_0) + (hx_m_m + hx_m_0));
+                const real dflx_jp1 = w48_hi * ((gy_0_0 + gy_0_p) + (hx_0_0 + hx_0_p));
+                const real eflx = w48_lo * ((gy_0_m + gy_0_0) - (hx_0_m + hx_0_0));
+                const real eflx_im1_jp1 = w48_hi * ((gy_m_0 + gy_m_p) - (hx_m_0 + hx_m_p));
+                const real u_im1 = U(-1, 0), u_ip1 = U(1, 0);
+                const real um = u_im1 + u, up = u + u_ip1;
+                real t = (+bflx_im1 * um - bflx * up
                             + cflx * (U(0, -1) + u) - cflx_jp1 * (u + U(0, 1))
                             + dflx_im1 * (U(-1, -1) + u) - dflx_jp1 * (u + U(1, 1))
                             + (+eflx * (U(1, -1) + u) - eflx_im1_jp1 * (u + U(-1, 1))));
@@ -798,21 +805,21 @@ __global__ __launch_bounds__(FTI *TJ) void k_momentum_dma(Geo g, Ptrs p, int gbx
             }
             // =============================== dVFLXdt ===============================
             if (v_on) {
-                const double hy_m = UF(-1, -1) + UF(-1, 0), hy_0 = UF(0, -1) + UF(0, 0), hy_p = UF(1, -1) + UF(1, 0), hy_pp = UF(2, -1) + UF(2, 0);
-                const double rflx = W24 * (gy_m_0 + 2.0 * gy_0_0 + gy_p_0);
-                const double rflx_jm1 = W24 * (gy_m_m + 2.0 * gy_0_m + gy_p_m);
-                const double qflx = W24 * (hy_m + 2.0 * hy_0 + hy_p);
-                const double qflx_ip1 = W24 * (hy_0 + 2.0 * hy_p + hy_pp);
-                const double sflx_jm1 = W48 * ((gy_m_m + gy_0_m) + (hx_m_m + hx_0_m));
-                const double sflx_ip1 = W48 * ((gy_0_0 + gy_p_0) + (hx_0_0 + hx_p_0));
-                const double tflx = W48 * ((gy_m_0 + gy_0_0) - (hx_m_0 + hx_0_0));
-                const double tflx_ip1_jm1 = W48 * ((gy_0_m + gy_p_m) - (hx_0_m + hx_p_m));
-                double t = (+rflx_jm1 * (V(0, -1) + v) - rflx * (v + V(0, 1))
+                const real hy_m = UF(-1, -1) + UF(-1, 0), hy_0 = UF(0, -1) + UF(0, 0), hy_p = UF(1, -1) + UF(1, 0), hy_pp = UF(2, -1) + UF(2, 0);
+                const real rflx = W24 * (gy_m_0 + 2.0 * gy_0_0 + gy_p_0);
+                const real rflx_jm1 = W24 * (gy_m_m + 2.0 * gy_0_m + gy_p_m);
+                const real qflx = W24 * (hy_m + 2.0 * hy_0 + hy_p);
+                const real qflx_ip1 = W24 * (hy_0 + 2.0 * hy_p + hy_pp);
+                const real sflx_jm1 = W48 * ((gy_m_m + gy_0_m) + (hx_m_m + hx_0_m));
+                const real sflx_ip1 = W48 * ((gy_0_0 + gy_p_0) + (hx_0_0 + hx_p_0));
+                const real tflx = W48 * ((gy_m_0 + gy_0_0) - (hx_m_0 + hx_0_0));
+                const real tflx_ip1_jm1 = W48 * ((gy_0_m + gy_p_m) - (hx_0_m + hx_p_m));
+                real t = (+rflx_jm1 * (V(0, -1) + v) - rflx * (v + V(0, 1))
                             + qflx * (V(-1, 0) + v) - qflx_ip1 * (v + V(1, 0))
                             + sflx_jm1 * (V(-1, -1) + v) - sflx_ip1 * (v + V(1, 1))
                             - (+tflx * (V(-1, 1) + v) - tflx_ip1_jm1 * (v + V(1, -1))));
                 // dyn_VFLX.py:39-64; us = 2 x the mean u at the v-point, cov_* = -metric / 2 * COLP, hsin = sin / 2
-                const double us_jm1 = U(0, -1) + U(1, -1), us = U(0, 0) + U(1, 0);
+                const real us_jm1 = U(0, -1) + U(1, -1), us = U(0, 0) + U(1, 0);
                 t = t + (cov_jm1 * us_jm1 * (kc_jm1 + us_jm1 * hsin_jm1) + cov_c * us * (kc_c + us * hsin_c));
                 t = t + ((phi - SM(S_PHI, 0, -1)) * pgv_a +
                          pgv_b * ((SM(S_POTT, 0, -1) * rds) * (svb1 * (pvb_jm1_kp1 - pvtf_jm1) + svb * (pvtf_jm1 - pvb_jm1_k)) +
@@ -839,7 +846,7 @@ __global__ __launch_bounds__(FTI *TJ) void k_momentum_dma(Geo g, Ptrs p, int gbx
     // ---- the last level of the chunk: its lower interface is k1 (WWIND*U = 0 at the surface) ----
     if (active) {
         const size_t qm = c + (size_t)(k1 - 1) * g.plane;
-        double wu_k = 0.0, wv_k = 0.0;
+        real wu_k = 0.0, wv_k = 0.0;
         if (k1 < nz) {
             wu_k = su_k * (c_wa[k1] * u_km1 + c_wb[k1] * p.UWIND[qm + g.plane]);
             wv_k = sv_k * (c_wa[k1] * v_km1 + c_wb[k1] * p.VWIND[qm + g.plane]);
@@ -874,8 +881,8 @@ __global__ __launch_bounds__(TI *TJ) void k_turb_tendencies(Geo g, Ptrs p, int j
     const int jg = j + g.joff;
     const bool lo = (jg == 1), hi = (jg == g.ny_global);
     const bool v_on = j >= jv_lo;
-    const double colp = p.COLP[c];
-    constexpr double RG = 1.0 / CON_G;
+    const real colp = p.COLP[c];
+    constexpr real RG = 1.0 / CON_G;
     // Everything that depends on the column only is formed once: COLP * A of the 3 x 3 neighbourhood folded into the
     // weights of the six-point means at the u-point (columns i-1, i; rows j-1 .. j+1; four points with weight 1/4
     // at a polar row: zero weights) and at the v-point (rows j-1, j; columns i-1 .. i+1), and the plain six-point
@@ -883,10 +890,10 @@ __global__ __launch_bounds__(TI *TJ) void k_turb_tendencies(Geo g, Ptrs p, int j
     // multiplications by 1/g; the products are associated differently from the stage kernels (a few ulp).
     // point order u: (-1,1) (0,1) (-1,0) (0,0) (-1,-1) (0,-1);  v: (1,-1) (1,0) (0,-1) (0,0) (-1,-1) (-1,0)
     const int ou[6] = {P - 1, P, -1, 0, -P - 1, -P}, ov[6] = {-P + 1, 1, -P, 0, -P - 1, -1};
-    double wu[6], wv[6], ku[6], kv[6];
+    real wu[6], wv[6], ku[6], kv[6];
     {
-        const double wn = hi ? 0.0 : (lo ? 0.25 : 0.125), ws = lo ? 0.0 : (hi ? 0.25 : 0.125);
-        const double w6u[6] = {wn, wn, 0.25, 0.25, ws, ws}, w6v[6] = {0.125, 0.125, 0.25, 0.25, 0.125, 0.125};
+        const real wn = hi ? 0.0 : (lo ? 0.25 : 0.125), ws = lo ? 0.0 : (hi ? 0.25 : 0.125);
+        const real w6u[6] = {wn, wn, 0.25, 0.25, ws, ws}, w6v[6] = {0.125, 0.125, 0.25, 0.25, 0.125, 0.125};
 #pragma unroll
         for (int n = 0; n < 6; n++) {
             wu[n] = w6u[n] * RG; wv[n] = w6v[n] * RG;
@@ -896,63 +903,63 @@ __global__ __launch_bounds__(TI *TJ) void k_turb_tendencies(Geo g, Ptrs p, int j
     }
     // six-point means of a field at the u- / v-point with the given weights (a polar row gives its outside points
     // weight 0; their halo values are finite)
-    auto m6u = [&](const double *F, size_t q, const double *w) {
+    auto m6u = [&](const real *F, size_t q, const real *w) {
         return w[0] * F[q + ou[0]] + w[1] * F[q + ou[1]] + w[2] * F[q + ou[2]] + w[3] * F[q + ou[3]] + w[4] * F[q + ou[4]] + w[5] * F[q + ou[5]];
     };
-    auto m6v = [&](const double *F, size_t q, const double *w) {
+    auto m6v = [&](const real *F, size_t q, const real *w) {
         return w[0] * F[q + ov[0]] + w[1] * F[q + ov[1]] + w[2] * F[q + ov[2]] + w[3] * F[q + ov[3]] + w[4] * F[q + ov[4]] + w[5] * F[q + ov[5]];
     };
     // RHOVB * COLP * A * KMOM means (dyn_functions.py:276-377)
     auto k6u = [&](size_t q) {
-        double s = 0.0;
+        real s = 0.0;
 #pragma unroll
         for (int n = 0; n < 6; n++) s += ku[n] * (p.RHOVB[q + ou[n]] * p.KMOM[q + ou[n]]);
         return s;
     };
     auto k6v = [&](size_t q) {
-        double s = 0.0;
+        real s = 0.0;
 #pragma unroll
         for (int n = 0; n < 6; n++) s += kv[n] * (p.RHOVB[q + ov[n]] * p.KMOM[q + ov[n]]);
         return s;
     };
-    const double smom_is = m6u(p.SMOMXFLX, c, wu), smom_js = m6v(p.SMOMYFLX, c, wv);
-    const double surf_t = p.SSHFLX[c] / CON_CP, surf_q = g.i_moist ? p.SLHFLX[c] / CON_LH : 0.0;
+    const real smom_is = m6u(p.SMOMXFLX, c, wu), smom_js = m6v(p.SMOMYFLX, c, wv);
+    const real surf_t = p.SSHFLX[c] / CON_CP, surf_q = g.i_moist ? p.SLHFLX[c] / CON_LH : 0.0;
 
-    double kdu_k = 0.0, kdv_k = 0.0;                         // K dU/dz, K dV/dz at interface k (0 at the top)
-    double u_k = p.UWIND[c], v_k = p.VWIND[c];
-    double altu_k = m6u(p.PHI, c, wu), altv_k = m6v(p.PHI, c, wv);
-    double avu_k = m6u(p.PHIVB, c, wu) * RG, avv_k = m6v(p.PHIVB, c, wv) * RG;   // ALTVB at the u- / v-point (g twice: dyn_UFLX.py:141)
-    double pott_km1 = 0.0, qv_km1 = 0.0, qc_km1 = 0.0, alt_km1 = 0.0;
+    real kdu_k = 0.0, kdv_k = 0.0;                         // K dU/dz, K dV/dz at interface k (0 at the top)
+    real u_k = p.UWIND[c], v_k = p.VWIND[c];
+    real altu_k = m6u(p.PHI, c, wu), altv_k = m6v(p.PHI, c, wv);
+    real avu_k = m6u(p.PHIVB, c, wu) * RG, avv_k = m6v(p.PHIVB, c, wv) * RG;   // ALTVB at the u- / v-point (g twice: dyn_UFLX.py:141)
+    real pott_km1 = 0.0, qv_km1 = 0.0, qc_km1 = 0.0, alt_km1 = 0.0;
     for (int k = 0; k < nz; k++) {
         const size_t q = c + (size_t)k * pl, q1 = q + pl;
         const bool last = (k == nz - 1);
         // ---- momentum ----
-        double kdu_kp1 = 0.0, kdv_kp1 = 0.0, u_kp1 = 0.0, v_kp1 = 0.0, altu_kp1 = 0.0, altv_kp1 = 0.0;
+        real kdu_kp1 = 0.0, kdv_kp1 = 0.0, u_kp1 = 0.0, v_kp1 = 0.0, altu_kp1 = 0.0, altv_kp1 = 0.0;
         if (!last) {
             u_kp1 = p.UWIND[q1]; v_kp1 = p.VWIND[q1];
             altu_kp1 = m6u(p.PHI, q1, wu); altv_kp1 = m6v(p.PHI, q1, wv);
             kdu_kp1 = k6u(q1) * ((u_k - u_kp1) / (altu_k - altu_kp1));
             kdv_kp1 = k6v(q1) * ((v_k - v_kp1) / (altv_k - altv_kp1));
         }
-        const double avu_kp1 = m6u(p.PHIVB, q1, wu) * RG, avv_kp1 = m6v(p.PHIVB, q1, wv) * RG;
-        const double rho_is = m6u(p.RHO, q, wu), rho_js = m6v(p.RHO, q, wv);
-        const double du = (k == 0 ? 0.0 : kdu_k) - (last ? -smom_is : kdu_kp1);
-        const double dv = (k == 0 ? 0.0 : kdv_k) - (last ? -smom_js : kdv_kp1);
+        const real avu_kp1 = m6u(p.PHIVB, q1, wu) * RG, avv_kp1 = m6v(p.PHIVB, q1, wv) * RG;
+        const real rho_is = m6u(p.RHO, q, wu), rho_js = m6v(p.RHO, q, wv);
+        const real du = (k == 0 ? 0.0 : kdu_k) - (last ? -smom_is : kdu_kp1);
+        const real dv = (k == 0 ? 0.0 : kdv_k) - (last ? -smom_js : kdv_kp1);
         p.TURB_U[q] = du / ((avu_k - avu_kp1) * rho_is);
         if (v_on) p.TURB_V[q] = dv / ((avv_k - avv_kp1) * rho_js);
         kdu_k = kdu_kp1; kdv_k = kdv_kp1; u_k = u_kp1; v_k = v_kp1;
         altu_k = altu_kp1; altv_k = altv_kp1; avu_k = avu_kp1; avv_k = avv_kp1;
         // ---- scalars (dyn_functions.py:26-67): the three quotients that do not depend on the species once ----
-        const double alt = p.PHI[q] * RG, alt_kp1 = last ? 0.0 : p.PHI[q1] * RG;
-        const double thick = (p.PHIVB[q] * RG - p.PHIVB[q1] * RG) * p.RHO[q];
-        const double f_up = k == 0 ? 0.0 : p.RHOVB[q] * p.KHEAT[q] / (alt_km1 - alt);          // flux through interface k per unit difference
-        const double f_dn = last ? 0.0 : p.RHOVB[q1] * p.KHEAT[q1] / (alt - alt_kp1);          // ... through interface k+1
-        const double r_thick = colp / thick;
-        const double pt = p.POTT[q], pt_kp1 = last ? 0.0 : p.POTT[q1];
+        const real alt = p.PHI[q] * RG, alt_kp1 = last ? 0.0 : p.PHI[q1] * RG;
+        const real thick = (p.PHIVB[q] * RG - p.PHIVB[q1] * RG) * p.RHO[q];
+        const real f_up = k == 0 ? 0.0 : p.RHOVB[q] * p.KHEAT[q] / (alt_km1 - alt);          // flux through interface k per unit difference
+        const real f_dn = last ? 0.0 : p.RHOVB[q1] * p.KHEAT[q1] / (alt - alt_kp1);          // ... through interface k+1
+        const real r_thick = colp / thick;
+        const real pt = p.POTT[q], pt_kp1 = last ? 0.0 : p.POTT[q1];
         p.TURB_T[q] = r_thick * ((pott_km1 - pt) * f_up - (pt - pt_kp1) * f_dn + (last ? surf_t : 0.0));
         pott_km1 = pt;
         if (g.i_moist) {
-            const double qv = p.QV[q], qv_kp1 = last ? 0.0 : p.QV[q1], qc = p.QC[q], qc_kp1 = last ? 0.0 : p.QC[q1];
+            const real qv = p.QV[q], qv_kp1 = last ? 0.0 : p.QV[q1], qc = p.QC[q], qc_kp1 = last ? 0.0 : p.QC[q1];
             p.TURB_QV[q] = r_thick * ((qv_km1 - qv) * f_up - (qv - qv_kp1) * f_dn + (last ? surf_q : 0.0));
             p.TURB_QC[q] = r_thick * ((qc_km1 - qc) * f_up - (qc - qc_kp1) * f_dn);
             qv_km1 = qv; qc_km1 = qc;
@@ -971,42 +978,42 @@ __global__ __launch_bounds__(TI *TJ) void k_turb_tendencies(Geo g, Ptrs p, int j
 // (UFLX = UCOL * UWIND * dyis, VFLX = VCOL * VWIND * dxjs, the same operations in the same order),
 // which leaves WWIND as the only 3-D output: 2 reads + 1 write per cell.
 template <int NZ, bool STORE_FLX>
-__global__ __launch_bounds__(TI *TJ) void k_continuity_reg(Geo g, Ptrs p, double dt, int lin)
+__global__ __launch_bounds__(TI *TJ) void k_continuity_reg(Geo g, Ptrs p, real dt, int lin)
 {
     int i, j;
     if (!owned_cell(g, lin, i, j)) return;
     const size_t c = at2(g, i, j);
-    const double colp = p.COLP[c];
-    const double c_im1 = p.COLP[c - 1], c_ip1 = p.COLP[c + 1];
-    const double c_jm1 = p.COLP[c - g.P], c_jp1 = p.COLP[c + g.P];
-    const double dy_i = p.dyis[c], dy_ip1 = p.dyis[c + 1];
-    const double dx_j = p.dxjs[c], dx_jp1 = p.dxjs[c + g.P];
-    const double area = p.A[c];
+    const real colp = p.COLP[c];
+    const real c_im1 = p.COLP[c - 1], c_ip1 = p.COLP[c + 1];
+    const real c_jm1 = p.COLP[c - g.P], c_jp1 = p.COLP[c + g.P];
+    const real dy_i = p.dyis[c], dy_ip1 = p.dyis[c + 1];
+    const real dx_j = p.dxjs[c], dx_jp1 = p.dxjs[c + g.P];
+    const real area = p.A[c];
     // inputs and outputs never alias: lets the compiler issue the loads of later levels ahead
     // of the stores of earlier ones in the unrolled loop
-    const double *__restrict__ uw = p.UWIND;
-    const double *__restrict__ vw = p.VWIND;
-    double *__restrict__ uflx = p.UFLX;
-    double *__restrict__ vflx = p.VFLX;
-    double pre[NZ];                     // pre[k] = sum of FLXDIV over the levels above k
-    double run = 0.0;
+    const real *__restrict__ uw = p.UWIND;
+    const real *__restrict__ vw = p.VWIND;
+    real *__restrict__ uflx = p.UFLX;
+    real *__restrict__ vflx = p.VFLX;
+    real pre[NZ];                     // pre[k] = sum of FLXDIV over the levels above k
+    real run = 0.0;
 #pragma unroll
     for (int k = 0; k < NZ; k++) {
         const size_t q = c + (size_t)k * g.plane;
-        const double uflx_i = (c_im1 + colp) / 2.0 * uw[q] * dy_i;
-        const double uflx_ip1 = (colp + c_ip1) / 2.0 * uw[q + 1] * dy_ip1;
-        const double vflx_j = (c_jm1 + colp) / 2.0 * vw[q] * dx_j;
-        const double vflx_jp1 = (colp + c_jp1) / 2.0 * vw[q + g.P] * dx_jp1;
+        const real uflx_i = (c_im1 + colp) / 2.0 * uw[q] * dy_i;
+        const real uflx_ip1 = (colp + c_ip1) / 2.0 * uw[q + 1] * dy_ip1;
+        const real vflx_j = (c_jm1 + colp) / 2.0 * vw[q] * dx_j;
+        const real vflx_jp1 = (colp + c_jp1) / 2.0 * vw[q + g.P] * dx_jp1;
         if (STORE_FLX) {
             uflx[q] = uflx_i;
             vflx[q] = vflx_j;
         }
-        const double div = (uflx_ip1 - uflx_i + vflx_jp1 - vflx_j) * p.dsigma[k] / area;
+        const real div = (uflx_ip1 - uflx_i + vflx_jp1 - vflx_j) * p.dsigma[k] / area;
         pre[k] = run;
         run += div;
     }
-    const double dcolpdt = -run;
-    const double colp_new = p.COLP_OLD[c] + dt * dcolpdt;
+    const real dcolpdt = -run;
+    const real colp_new = p.COLP_OLD[c] + dt * dcolpdt;
     p.dCOLPdt[c] = dcolpdt;
     p.COLP_NEW[c] = colp_new;
     p.UCOL[c] = (c_im1 + colp) / 2.0;
@@ -1022,12 +1029,12 @@ __global__ __launch_bounds__(TI *TJ) void k_continuity_reg(Geo g, Ptrs p, double
 // UFLX, VFLX (dyn_continuity.py:40-45) from the winds the last continuity call read and UCOL, VCOL;
 // FLXDIV (dyn_continuity.py:46-47) from UFLX, VFLX;  PHIVB (dyn_diagnostics.py:160-174) from
 // PHI, POTT, PVTF, PVTFVB, HSURF -- whole array including halos, like diag_PHI.
-__global__ __launch_bounds__(TI *TJ) void k_derive_uvflx(Geo g, Ptrs p, const double *uw, const double *vw)
+__global__ __launch_bounds__(TI *TJ) void k_derive_uvflx(Geo g, Ptrs p, const real *uw, const real *vw)
 {
     DYC_IJ(1, 1)
     if (i > g.nx || j > g.ny) return;
     const size_t c = at2(g, i, j);
-    const double ucol = p.UCOL[c], vcol = p.VCOL[c], dy = p.dyis[c], dx = p.dxjs[c];
+    const real ucol = p.UCOL[c], vcol = p.VCOL[c], dy = p.dyis[c], dx = p.dxjs[c];
     for (int k = 0; k < g.nz; k++) {
         const size_t q = c + (size_t)k * g.plane;
         p.UFLX[q] = ucol * uw[q] * dy;
@@ -1039,7 +1046,7 @@ __global__ __launch_bounds__(TI *TJ) void k_derive_flxdiv(Geo g, Ptrs p)
     DYC_IJ(1, 1)
     if (i > g.nx || j > g.ny) return;
     const size_t c = at2(g, i, j);
-    const double area = p.A[c];
+    const real area = p.A[c];
     for (int k = 0; k < g.nz; k++) {
         const size_t q = c + (size_t)k * g.plane;
         p.FLXDIV[q] = (p.UFLX[q + 1] - p.UFLX[q] + p.VFLX[q + g.P] - p.VFLX[q]) * p.dsigma[k] / area;
@@ -1052,11 +1059,11 @@ __global__ __launch_bounds__(TI *TJ) void k_derive_pvtf(Geo g, Ptrs p)
     DYC_IJ(0, 0)
     if (i > g.nx + 1 || j > g.ny + 1) return;
     const size_t c = at2(g, i, j);
-    const double colp = p.COLP[c];
-    double p_km12 = interface_pressure(g.pair_top, p.sigma_vb[0], colp), pvb_k = p.PVTFVB[c];
+    const real colp = p.COLP[c];
+    real p_km12 = interface_pressure(g.pair_top, p.sigma_vb[0], colp), pvb_k = p.PVTFVB[c];
     for (int k = 0; k < g.nz; k++) {
         const size_t q = c + (size_t)k * g.plane;
-        const double p_kp12 = interface_pressure(g.pair_top, p.sigma_vb[k + 1], colp), pvb_kp1 = p.PVTFVB[q + g.plane];
+        const real p_kp12 = interface_pressure(g.pair_top, p.sigma_vb[k + 1], colp), pvb_kp1 = p.PVTFVB[q + g.plane];
         p.PVTF[q] = 1.0 / (1.0 + CON_KAPPA) * (pvb_kp1 * p_kp12 - pvb_k * p_km12) / (p_kp12 - p_km12);
         p_km12 = p_kp12; pvb_k = pvb_kp1;
     }
@@ -1089,50 +1096,50 @@ __global__ __launch_bounds__(TI *TJ) void k_derive_phivb(Geo g, Ptrs p)
 // the rows j-1, j+1) serves all of them -- `base + zero-extended VGPR offset` is the native form
 // of global_load/global_store, where 64-bit pointer arithmetic per access was ~50 VALU
 // instructions per level.  (dycore_create refuses fields of 4 GiB and more.)
-__device__ __forceinline__ double ldb(const double *base, unsigned boff) { return *(const double *)((const char *)base + boff); }
-__device__ __forceinline__ void stb(double *base, unsigned boff, double v) { *(double *)((char *)base + boff) = v; }
+__device__ __forceinline__ real ldb(const real *base, unsigned boff) { return *(const real *)((const char *)base + boff); }
+__device__ __forceinline__ void stb(real *base, unsigned boff, real v) { *(real *)((char *)base + boff) = v; }
 
 // WRITE_PVTF = false: PVTF is not stored either -- the production momentum kernel forms it from PVTFVB and COLP, every
 // other reader gets it on demand (k_derive_pvtf, the formula of diag_level_pre on the stored PVTFVB: the same bits).
 template <bool WRITE_PHIVB, bool FROM_WINDS, bool TURB = false, bool WRITE_PVTF = true>
-__global__ __launch_bounds__(TI *TJ) void k_pott_fused(Geo g, Ptrs p, const double *pott_old, double *pott_out, double dt, int lin)
+__global__ __launch_bounds__(TI *TJ) void k_pott_fused(Geo g, Ptrs p, const real *pott_old, real *pott_out, real dt, int lin)
 {
     int i, j;
     if (!owned_cell(g, lin, i, j)) return;
     const int P = g.P, nz = g.nz;
     const size_t c = at2(g, i, j);
-    const unsigned bc = (unsigned)(c * sizeof(double)), bpl = (unsigned)(g.plane * sizeof(double)), bP = (unsigned)(P * sizeof(double));
-    const double colp = p.COLP[c], cnew = p.COLP_NEW[c], cold = p.COLP_OLD[c];
-    const double c_im1 = p.COLP[c - 1], c_ip1 = p.COLP[c + 1], c_jm1 = p.COLP[c - P], c_jp1 = p.COLP[c + P];
-    const double area = p.A[c];
+    const unsigned bc = (unsigned)(c * sizeof(real)), bpl = (unsigned)(g.plane * sizeof(real)), bP = (unsigned)(P * sizeof(real));
+    const real colp = p.COLP[c], cnew = p.COLP_NEW[c], cold = p.COLP_OLD[c];
+    const real c_im1 = p.COLP[c - 1], c_ip1 = p.COLP[c + 1], c_jm1 = p.COLP[c - P], c_jp1 = p.COLP[c + P];
+    const real area = p.A[c];
     // as in k_momentum_dma: divisions by per-column / per-level quantities as multiplications by
     // reciprocals formed once (<= 1 ulp per operation); the diagnostics below keep their divisions
-    const double r_area = 1.0 / area, r_cnew = 1.0 / cnew;
+    const real r_area = 1.0 / area, r_cnew = 1.0 / cnew;
     // surface interface of the new column
-    double p_kp12 = interface_pressure(g.pair_top, p.sigma_vb[nz], cnew);
-    double pvb_kp1 = exner_vb(p_kp12);
-    double phivb_kp1 = p.HSURF[c] * CON_G;
+    real p_kp12 = interface_pressure(g.pair_top, p.sigma_vb[nz], cnew);
+    real pvb_kp1 = exner_vb(p_kp12);
+    real phivb_kp1 = p.HSURF[c] * CON_G;
     stb(p.PVTFVB, bc + (unsigned)nz * bpl, pvb_kp1);
     if (WRITE_PHIVB) stb(p.PHIVB, bc + (unsigned)nz * bpl, phivb_kp1);
-    double w_kp1 = ldb(p.WWIND, bc + (unsigned)nz * bpl);
-    double pvbo_kp1 = ldb(p.POTTVB, bc + (unsigned)nz * bpl);        // old interface values
-    double pottn_kp1 = 0.0, pvtf_kp1 = 0.0, pottvb_first = 0.0;
-    double p_up = interface_pressure(g.pair_top, p.sigma_vb[nz - 1], cnew), pvb_up = exner_vb(p_up);   // upper interface of the bottom level
+    real w_kp1 = ldb(p.WWIND, bc + (unsigned)nz * bpl);
+    real pvbo_kp1 = ldb(p.POTTVB, bc + (unsigned)nz * bpl);        // old interface values
+    real pottn_kp1 = 0.0, pvtf_kp1 = 0.0, pottvb_first = 0.0;
+    real p_up = interface_pressure(g.pair_top, p.sigma_vb[nz - 1], cnew), pvb_up = exner_vb(p_up);   // upper interface of the bottom level
     // software pipeline: the inputs of level k-1 are requested before level k is computed, so the
     // HBM latency overlaps the pow/division chain instead of preceding it.  One level ahead is
     // enough (rings of 2-4 levels cost the third wave per SIMD and ran 5-15 % slower,
     // profiles/r01_notes.md); the two input sets alternate roles in a loop unrolled by two, so
     // no register is copied from "next" to "current".
-    const double m_dy0 = FROM_WINDS ? p.dyis[c] : 0.0, m_dy1 = FROM_WINDS ? p.dyis[c + 1] : 0.0;
-    const double m_dx0 = FROM_WINDS ? p.dxjs[c] : 0.0, m_dx1 = FROM_WINDS ? p.dxjs[c + P] : 0.0;
-    const double *fu = FROM_WINDS ? p.UWIND : p.UFLX, *fv = FROM_WINDS ? p.VWIND : p.VFLX;
-    struct In { double pt, im1, ip1, jm1, jp1, uf, uf1, vf, vf1, w, pvb, po, tb; };
+    const real m_dy0 = FROM_WINDS ? p.dyis[c] : 0.0, m_dy1 = FROM_WINDS ? p.dyis[c + 1] : 0.0;
+    const real m_dx0 = FROM_WINDS ? p.dxjs[c] : 0.0, m_dx1 = FROM_WINDS ? p.dxjs[c + P] : 0.0;
+    const real *fu = FROM_WINDS ? p.UWIND : p.UFLX, *fv = FROM_WINDS ? p.VWIND : p.VFLX;
+    struct In { real pt, im1, ip1, jm1, jp1, uf, uf1, vf, vf1, w, pvb, po, tb; };
     auto load = [&](int k, In &r) {
         const unsigned q = bc + (unsigned)k * bpl;
         r.tb = TURB ? ldb(p.TURB_T, q) : 0.0;
-        r.pt = ldb(p.POTT, q); r.im1 = ldb(p.POTT, q - 8); r.ip1 = ldb(p.POTT, q + 8);
+        r.pt = ldb(p.POTT, q); r.im1 = ldb(p.POTT, q - (unsigned)sizeof(real)); r.ip1 = ldb(p.POTT, q + (unsigned)sizeof(real));
         r.jm1 = ldb(p.POTT, q - bP); r.jp1 = ldb(p.POTT, q + bP);
-        r.uf = ldb(fu, q); r.uf1 = ldb(fu, q + 8); r.vf = ldb(fv, q); r.vf1 = ldb(fv, q + bP);
+        r.uf = ldb(fu, q); r.uf1 = ldb(fu, q + (unsigned)sizeof(real)); r.vf = ldb(fv, q); r.vf1 = ldb(fv, q + bP);
         r.w = ldb(p.WWIND, q); r.pvb = ldb(p.POTTVB, q); r.po = ldb(pott_old, q);
     };
     auto level = [&](int k, In &cur) {
@@ -1143,14 +1150,14 @@ __global__ __launch_bounds__(TI *TJ) void k_pott_fused(Geo g, Ptrs p, const doub
             cur.vf = (c_jm1 + colp) / 2.0 * cur.vf * m_dx0;
             cur.vf1 = (colp + c_jp1) / 2.0 * cur.vf1 * m_dx1;
         }
-        const double pt = cur.pt;
-        const double p_im1 = cur.im1, p_ip1 = cur.ip1, p_jm1 = cur.jm1, p_jp1 = cur.jp1;
-        const double rds = p.rdsigma[k];
-        double t = 0.0;
+        const real pt = cur.pt;
+        const real p_im1 = cur.im1, p_ip1 = cur.ip1, p_jm1 = cur.jm1, p_jp1 = cur.jp1;
+        const real rds = p.rdsigma[k];
+        real t = 0.0;
         t = t + (+cur.uf * (p_im1 + pt) / 2.0 - cur.uf1 * (pt + p_ip1) / 2.0
                  + cur.vf * (p_jm1 + pt) / 2.0 - cur.vf1 * (pt + p_jp1) / 2.0)
                 * r_area;
-        double w_k = 0.0, pvbo_k = 0.0;
+        real w_k = 0.0, pvbo_k = 0.0;
         if (k == 0) {
             t = t + cnew * (-w_kp1 * pvbo_kp1) * rds;
         } else {
@@ -1159,12 +1166,12 @@ __global__ __launch_bounds__(TI *TJ) void k_pott_fused(Geo g, Ptrs p, const doub
             t = t + cnew * (+w_k * pvbo_k - w_kp1 * pvbo_kp1) * rds;
         }
         if (TURB) t = t + cur.tb;                       // k_turb_tendencies (dyn_functions.py:26-67)
-        const double dif = p.POTT_dif_coef[k];
+        const real dif = p.POTT_dif_coef[k];
         if (dif > 0.0)
             t = t + dif * (c_im1 * p_im1 + c_ip1 * p_ip1 + c_jm1 * p_jm1 + c_jp1 * p_jp1 - 4.0 * colp * pt);
         if (g.i_rad) t = t + ldb(p.dPOTTdt_RAD, q) * colp;
         // Euler forward, pressure weighted
-        const double pott = cur.po * cold * r_cnew + dt * t * r_cnew;
+        const real pott = cur.po * cold * r_cnew + dt * t * r_cnew;
         stb(pott_out, q, pott);
         // diagnostics of the new column, level k
         // the interface pressure of this level's upper interface and its Exner value (one pow) were formed during the
@@ -1175,13 +1182,13 @@ __global__ __launch_bounds__(TI *TJ) void k_pott_fused(Geo g, Ptrs p, const doub
             p_up = interface_pressure(g.pair_top, p.sigma_vb[k - 1], cnew);
             pvb_up = exner_vb(p_up);
         }
-        const double p_km12 = dl.p_km12, pvb_k = dl.pvb_k, pvtf = dl.pvtf, phi = dl.phi, phivb = dl.phivb;
+        const real p_km12 = dl.p_km12, pvb_k = dl.pvb_k, pvtf = dl.pvtf, phi = dl.phi, phivb = dl.phivb;
         if (WRITE_PVTF) stb(p.PVTF, q, pvtf);
         stb(p.PVTFVB, q, pvb_k);
         stb(p.PHI, q, phi);
         if (WRITE_PHIVB) stb(p.PHIVB, q, phivb);
         if (k < nz - 1) {
-            const double vb = pottvb_between(pvb_kp1, pvtf, pott, pvtf_kp1, pottn_kp1);
+            const real vb = pottvb_between(pvb_kp1, pvtf, pott, pvtf_kp1, pottn_kp1);
             stb(p.POTTVB, q + bpl, vb);
             if (k == nz - 2 && nz > 2) stb(p.POTTVB, bc + (unsigned)nz * bpl, pottn_kp1 - (vb - pottn_kp1));
             if (k == 0) pottvb_first = vb;

@@ -61,43 +61,43 @@ __device__ __forceinline__ bool owned_cell(const Geo &g, int lin, int &i, int &j
 // continuity: dyn_continuity.py:170-232.  Owned cells i in [1,nx], j in [1,ny]; the lateral
 // halo of UFLX, VFLX, WWIND, COLP_NEW (dyn_org_discretizations.py:107-117) is refreshed by
 // one k_halo_multi launch afterwards.
-__global__ __launch_bounds__(TI *TJ) void k_continuity(Geo g, Ptrs p, double dt)
+__global__ __launch_bounds__(TI *TJ) void k_continuity(Geo g, Ptrs p, real dt)
 {
     DYC_IJ(1, 1)
     if (i > g.nx || j > g.ny) return;
     const size_t c = at2(g, i, j);
-    const double colp = p.COLP[c];
-    const double c_im1 = p.COLP[c - 1], c_ip1 = p.COLP[c + 1];
-    const double c_jm1 = p.COLP[c - g.P], c_jp1 = p.COLP[c + g.P];
-    const double dy_i = p.dyis[c], dy_ip1 = p.dyis[c + 1];
-    const double dx_j = p.dxjs[c], dx_jp1 = p.dxjs[c + g.P];
-    const double area = p.A[c];
-    double sum = 0.0;
+    const real colp = p.COLP[c];
+    const real c_im1 = p.COLP[c - 1], c_ip1 = p.COLP[c + 1];
+    const real c_jm1 = p.COLP[c - g.P], c_jp1 = p.COLP[c + g.P];
+    const real dy_i = p.dyis[c], dy_ip1 = p.dyis[c + 1];
+    const real dx_j = p.dxjs[c], dx_jp1 = p.dxjs[c + g.P];
+    const real area = p.A[c];
+    real sum = 0.0;
 #ifdef DYC_CONT_UNROLL
 #pragma unroll DYC_CONT_UNROLL
 #endif
     for (int k = 0; k < g.nz; k++) {
         const size_t q = c + (size_t)k * g.plane;
-        const double uflx_i = (c_im1 + colp) / 2.0 * p.UWIND[q] * dy_i;
-        const double uflx_ip1 = (colp + c_ip1) / 2.0 * p.UWIND[q + 1] * dy_ip1;
-        const double vflx_j = (c_jm1 + colp) / 2.0 * p.VWIND[q] * dx_j;
-        const double vflx_jp1 = (colp + c_jp1) / 2.0 * p.VWIND[q + g.P] * dx_jp1;
+        const real uflx_i = (c_im1 + colp) / 2.0 * p.UWIND[q] * dy_i;
+        const real uflx_ip1 = (colp + c_ip1) / 2.0 * p.UWIND[q + 1] * dy_ip1;
+        const real vflx_j = (c_jm1 + colp) / 2.0 * p.VWIND[q] * dx_j;
+        const real vflx_jp1 = (colp + c_jp1) / 2.0 * p.VWIND[q + g.P] * dx_jp1;
         p.UFLX[at(g, i, j, k)] = uflx_i;
         p.VFLX[at(g, i, j, k)] = vflx_j;
-        const double div = (uflx_ip1 - uflx_i + vflx_jp1 - vflx_j) * p.dsigma[k] / area;
+        const real div = (uflx_ip1 - uflx_i + vflx_jp1 - vflx_j) * p.dsigma[k] / area;
         p.FLXDIV[q] = div;
         sum += div;
     }
-    const double dcolpdt = -sum;
-    const double colp_new = p.COLP_OLD[c] + dt * dcolpdt;
+    const real dcolpdt = -sum;
+    const real colp_new = p.COLP_OLD[c] + dt * dcolpdt;
     p.dCOLPdt[c] = dcolpdt;
     p.COLP_NEW[at(g, i, j, 0)] = colp_new;
     // sigma-dot vanishes at the model top and at the surface (io_initial_conditions.py:45-46)
     p.WWIND[at(g, i, j, 0)] = 0.0;
     p.WWIND[at(g, i, j, g.nz)] = 0.0;
-    double run = p.FLXDIV[c];
+    real run = p.FLXDIV[c];
     for (int k = 1; k < g.nz; k++) {
-        const double w = -run / colp_new - p.sigma_vb[k] * dcolpdt / colp_new;
+        const real w = -run / colp_new - p.sigma_vb[k] * dcolpdt / colp_new;
         p.WWIND[at(g, i, j, k)] = w;
         run += p.FLXDIV[c + (size_t)k * g.plane];
     }
@@ -119,7 +119,7 @@ __global__ __launch_bounds__(TI *TJ) void k_prepare(Geo g, Ptrs p)
         if (g.pole_s || i > g.nx + 1) return;
         for (int k = 0; k < g.nz; k++) {
             const size_t q = c + (size_t)k * g.plane;
-            const double vs = p.VFLX[q - 1] + p.VFLX[q + P - 1] + p.VFLX[q] + p.VFLX[q + P];
+            const real vs = p.VFLX[q - 1] + p.VFLX[q + P - 1] + p.VFLX[q] + p.VFLX[q + P];
             p.SFLX[q] = 1.0 / 24.0 * (vs + p.UFLX[q - 1] + 2.0 * p.UFLX[q] + p.UFLX[q + 1]);
             p.TFLX[q] = 1.0 / 24.0 * (vs - p.UFLX[q - 1] - 2.0 * p.UFLX[q] - p.UFLX[q + 1]);
             if (i <= g.nx)
@@ -134,7 +134,7 @@ __global__ __launch_bounds__(TI *TJ) void k_prepare(Geo g, Ptrs p)
     const bool lo = (jg == 1), hi = (jg == g.ny_global);
 
     // COLP_NEW*A at the nine points (2-D, reused for every level)
-    double ca[3][3];
+    real ca[3][3];
 #pragma unroll
     for (int b = 0; b < 3; b++)
 #pragma unroll
@@ -152,28 +152,28 @@ __global__ __launch_bounds__(TI *TJ) void k_prepare(Geo g, Ptrs p)
         if (v_ok) { p.KMOM_dVWINDdz[at(g, i, j, 0)] = 0.0; p.KMOM_dVWINDdz[at(g, i, j, g.nz)] = 0.0; }
     }
 
-    double u_km1 = 0.0, v_km1 = 0.0;
+    real u_km1 = 0.0, v_km1 = 0.0;
     for (int k = 0; k < g.nz; k++) {
         const size_t q = c + (size_t)k * g.plane;
         // ---- interface quantities (k = 1..nz-1) ----
-        const double u_k = u_ok ? p.UWIND[q] : 0.0;
-        const double v_k = v_ok ? p.VWIND[q] : 0.0;
+        const real u_k = u_ok ? p.UWIND[q] : 0.0;
+        const real v_k = v_ok ? p.VWIND[q] : 0.0;
         if (k >= 1) {
-            const double ds = p.dsigma[k], ds_km1 = p.dsigma[k - 1];
+            const real ds = p.dsigma[k], ds_km1 = p.dsigma[k - 1];
             // W(a,b) = COLP_NEW*A*WWIND at (i+a-1, j+b-1)
 #define WT(a, b) (ca[b][a] * p.WWIND[q + ((b) - 1) * P + ((a) - 1)])
 #define WT2(a, b) (2.0 * ca[b][a] * p.WWIND[q + ((b) - 1) * P + ((a) - 1)])
             if (u_ok) {   // dyn_functions.py:211-270, d = i, p = j, rigid wall at the poles
-                double s;
+                real s;
                 if (lo) s = 0.25 * (WT(0, 2) + WT(1, 2) + WT(0, 1) + WT(1, 1));
                 else if (hi) s = 0.25 * (WT(0, 1) + WT(1, 1) + WT(0, 0) + WT(1, 0));
                 else s = 0.125 * (WT(0, 2) + WT(1, 2) + WT2(0, 1) + WT2(1, 1) + WT(0, 0) + WT(1, 0));
-                const double u_ks = (ds * u_km1 + ds_km1 * u_k) / (ds + ds_km1);
+                const real u_ks = (ds * u_km1 + ds_km1 * u_k) / (ds + ds_km1);
                 p.WWIND_UWIND[q] = s * u_ks;
             }
             if (v_ok) {   // d = j, p = i, no wall
-                const double s = 0.125 * (WT(2, 0) + WT(2, 1) + WT2(1, 0) + WT2(1, 1) + WT(0, 0) + WT(0, 1));
-                const double v_ks = (ds * v_km1 + ds_km1 * v_k) / (ds + ds_km1);
+                const real s = 0.125 * (WT(2, 0) + WT(2, 1) + WT2(1, 0) + WT2(1, 1) + WT(0, 0) + WT(0, 1));
+                const real v_ks = (ds * v_km1 + ds_km1 * v_k) / (ds + ds_km1);
                 p.WWIND_VWIND[q] = s * v_ks;
             }
 #undef WT
@@ -184,7 +184,7 @@ __global__ __launch_bounds__(TI *TJ) void k_prepare(Geo g, Ptrs p)
 #define PH(a, b) p.PHI[q + ((b) - 1) * P + ((a) - 1)]
 #define PHM(a, b) p.PHI[q - g.plane + ((b) - 1) * P + ((a) - 1)]
                 if (u_ok) {
-                    double k6, alt_km1, alt;
+                    real k6, alt_km1, alt;
                     if (lo) {
                         k6 = 0.25 * (KT(0, 2) + KT(1, 2) + KT(0, 1) + KT(1, 1));
                         alt_km1 = 0.25 * (PHM(0, 2) + PHM(1, 2) + PHM(0, 1) + PHM(1, 1)) / CON_G;
@@ -201,9 +201,9 @@ __global__ __launch_bounds__(TI *TJ) void k_prepare(Geo g, Ptrs p)
                     p.KMOM_dUWINDdz[at(g, i, j, k)] = k6 * ((u_km1 - u_k) / (alt_km1 - alt));
                 }
                 if (v_ok) {
-                    const double k6 = 0.125 * (KT(2, 0) + KT(2, 1) + KT2(1, 0) + KT2(1, 1) + KT(0, 0) + KT(0, 1));
-                    const double alt_km1 = 0.125 * (PHM(2, 0) + PHM(2, 1) + 2.0 * PHM(1, 0) + 2.0 * PHM(1, 1) + PHM(0, 0) + PHM(0, 1)) / CON_G;
-                    const double alt = 0.125 * (PH(2, 0) + PH(2, 1) + 2.0 * PH(1, 0) + 2.0 * PH(1, 1) + PH(0, 0) + PH(0, 1)) / CON_G;
+                    const real k6 = 0.125 * (KT(2, 0) + KT(2, 1) + KT2(1, 0) + KT2(1, 1) + KT(0, 0) + KT(0, 1));
+                    const real alt_km1 = 0.125 * (PHM(2, 0) + PHM(2, 1) + 2.0 * PHM(1, 0) + 2.0 * PHM(1, 1) + PHM(0, 0) + PHM(0, 1)) / CON_G;
+                    const real alt = 0.125 * (PH(2, 0) + PH(2, 1) + 2.0 * PH(1, 0) + 2.0 * PH(1, 1) + PH(0, 0) + PH(0, 1)) / CON_G;
                     p.KMOM_dVWINDdz[at(g, i, j, k)] = k6 * ((v_km1 - v_k) / (alt_km1 - alt));
                 }
 #undef KT
@@ -223,12 +223,12 @@ __global__ __launch_bounds__(TI *TJ) void k_prepare(Geo g, Ptrs p)
             p.QFLX[q] = 1.0 / 12.0 * (UF(0, 0) + UF(0, 1) + 2.0 * (UF(1, 0) + UF(1, 1)) + UF(2, 0) + UF(2, 1));
         }
         if (v_ok) {   // (i,js): D, E
-            const double vs = VF(1, 0) + 2.0 * VF(1, 1) + VF(1, 2);
+            const real vs = VF(1, 0) + 2.0 * VF(1, 1) + VF(1, 2);
             p.DFLX[q] = 1.0 / 24.0 * (vs + UF(1, 0) + UF(1, 1) + UF(2, 0) + UF(2, 1));
             p.EFLX[q] = 1.0 / 24.0 * (vs - UF(1, 0) - UF(1, 1) - UF(2, 0) - UF(2, 1));
         }
         if (u_ok) {   // (is,j): S, T
-            const double vs = VF(0, 1) + VF(0, 2) + VF(1, 1) + VF(1, 2);
+            const real vs = VF(0, 1) + VF(0, 2) + VF(1, 1) + VF(1, 2);
             p.SFLX[q] = 1.0 / 24.0 * (vs + UF(0, 1) + 2.0 * UF(1, 1) + UF(2, 1));
             p.TFLX[q] = 1.0 / 24.0 * (vs - UF(0, 1) - 2.0 * UF(1, 1) - UF(2, 1));
         }
@@ -243,8 +243,8 @@ __global__ __launch_bounds__(TI *TJ) void k_prepare(Geo g, Ptrs p)
 
 // ------------------------------------------------------------------------------------
 // dyn_functions.py:383-424 (divides by g itself)
-__device__ __forceinline__ double var_ds(double v0, double v_dm1, double v_pm1, double v_pp1,
-                                         double v_pm1_dm1, double v_pp1_dm1, bool lo, bool hi)
+__device__ __forceinline__ real var_ds(real v0, real v_dm1, real v_pm1, real v_pp1,
+                                         real v_pm1_dm1, real v_pp1_dm1, bool lo, bool hi)
 {
     if (lo) return 0.25 * (v_pp1_dm1 + v_pp1 + v_dm1 + v0) / CON_G;
     if (hi) return 0.25 * (v_dm1 + v0 + v_pm1_dm1 + v_pm1) / CON_G;
@@ -252,11 +252,11 @@ __device__ __forceinline__ double var_ds(double v0, double v_dm1, double v_pm1, 
 }
 
 // dyn_functions.py:177-207
-__device__ __forceinline__ double pre_grad(double phi, double phi_dm1, double colp, double colp_dm1,
-                                           double pott, double pott_dm1, double pvtf, double pvtf_dm1,
-                                           double pvtfvb, double pvtfvb_dm1, double pvtfvb_dm1_kp1,
-                                           double pvtfvb_kp1, double dsig, double svb, double svb_kp1,
-                                           double dgrid)
+__device__ __forceinline__ real pre_grad(real phi, real phi_dm1, real colp, real colp_dm1,
+                                           real pott, real pott_dm1, real pvtf, real pvtf_dm1,
+                                           real pvtfvb, real pvtfvb_dm1, real pvtfvb_dm1_kp1,
+                                           real pvtfvb_kp1, real dsig, real svb, real svb_kp1,
+                                           real dgrid)
 {
     return -dgrid * ((phi - phi_dm1) * (colp + colp_dm1) / 2.0 +
                      (colp - colp_dm1) * CON_CP / 2.0 *
@@ -277,43 +277,43 @@ __global__ __launch_bounds__(TI *TJ) void k_uflx_tendency(Geo g, Ptrs p)
     const int jg = j + g.joff;
     const bool lo = (jg == 1), hi = (jg == g.ny_global);
     const int dm = (i == 1) ? (g.nx - 1) : -1;        // offset to the i-1 flux column (dyn_UFLX.py:366-374)
-    const double colp = p.COLP[c], colp_im1 = p.COLP[c - 1];
-    const double corf = p.corf_is[c], lat = p.lat_is_rad[c];
-    const double coslat = cos(lat), sinlat = sin(lat);
-    const double dlon = p.dlon_rad[c], dlat = p.dlat_rad[c], dyis = p.dyis[c];
-    double smom_is = 0.0;
+    const real colp = p.COLP[c], colp_im1 = p.COLP[c - 1];
+    const real corf = p.corf_is[c], lat = p.lat_is_rad[c];
+    const real coslat = cos(lat), sinlat = sin(lat);
+    const real dlon = p.dlon_rad[c], dlat = p.dlat_rad[c], dyis = p.dyis[c];
+    real smom_is = 0.0;
     if (TURB)
         smom_is = var_ds(p.SMOMXFLX[c], p.SMOMXFLX[c - 1], p.SMOMXFLX[c - P], p.SMOMXFLX[c + P],
                          p.SMOMXFLX[c - P - 1], p.SMOMXFLX[c + P - 1], lo, hi);
-    double wu_k = p.WWIND_UWIND[c];
-    double pvb_k = p.PVTFVB[c], pvb_im1_k = p.PVTFVB[c - 1];
+    real wu_k = p.WWIND_UWIND[c];
+    real pvb_k = p.PVTFVB[c], pvb_im1_k = p.PVTFVB[c - 1];
     for (int k = 0; k < g.nz; k++) {
         const size_t q = c + (size_t)k * g.plane;
-        double bflx = p.BFLX[q], bflx_im1 = p.BFLX[q + dm];
-        double cflx = p.CFLX[q], cflx_jp1 = p.CFLX[q + P];
-        double dflx_im1 = p.DFLX[q + dm], dflx_jp1 = p.DFLX[q + P];
-        double eflx = p.EFLX[q], eflx_im1_jp1 = p.EFLX[q + P + dm];
+        real bflx = p.BFLX[q], bflx_im1 = p.BFLX[q + dm];
+        real cflx = p.CFLX[q], cflx_jp1 = p.CFLX[q + P];
+        real dflx_im1 = p.DFLX[q + dm], dflx_jp1 = p.DFLX[q + P];
+        real eflx = p.EFLX[q], eflx_im1_jp1 = p.EFLX[q + P + dm];
         if (lo) { dflx_im1 = 0.0; cflx = 0.0; eflx = 0.0; }
         if (hi) { dflx_jp1 = 0.0; cflx_jp1 = 0.0; eflx_im1_jp1 = 0.0; }
 #define U(a, b) p.UWIND[q + (b) * P + (a)]
 #define V(a, b) p.VWIND[q + (b) * P + (a)]
-        const double u = U(0, 0), u_im1 = U(-1, 0), u_ip1 = U(1, 0);
-        double t = 0.0;
+        const real u = U(0, 0), u_im1 = U(-1, 0), u_ip1 = U(1, 0);
+        real t = 0.0;
         t = t + (+bflx_im1 * (u_im1 + u) / 2.0 - bflx * (u + u_ip1) / 2.0
                  + cflx * (U(0, -1) + u) / 2.0 - cflx_jp1 * (u + U(0, 1)) / 2.0
                  + dflx_im1 * (U(-1, -1) + u) / 2.0 - dflx_jp1 * (u + U(1, 1)) / 2.0
                  + 1.0 * (+eflx * (U(1, -1) + u) / 2.0 - eflx_im1_jp1 * (u + U(-1, 1)) / 2.0));
-        const double wu_kp1 = p.WWIND_UWIND[q + g.plane];
+        const real wu_kp1 = p.WWIND_UWIND[q + g.plane];
         t = t + (wu_k - wu_kp1) / p.dsigma[k];
         wu_k = wu_kp1;
         if (TURB) {
 #define PV(a, b, kk) p.PHIVB[q + (size_t)(kk) * g.plane + (b) * P + (a)]
 #define RH(a, b) p.RHO[q + (b) * P + (a)]
-            const double altvb = var_ds(PV(0, 0, 0), PV(-1, 0, 0), PV(0, -1, 0), PV(0, 1, 0), PV(-1, -1, 0), PV(-1, 1, 0), lo, hi) / CON_G;
-            const double altvb_kp1 = var_ds(PV(0, 0, 1), PV(-1, 0, 1), PV(0, -1, 1), PV(0, 1, 1), PV(-1, -1, 1), PV(-1, 1, 1), lo, hi) / CON_G;
-            const double rho_is = var_ds(RH(0, 0), RH(-1, 0), RH(0, -1), RH(0, 1), RH(-1, -1), RH(-1, 1), lo, hi);
-            const double kd = p.KMOM_dUWINDdz[q], kd_kp1 = p.KMOM_dUWINDdz[q + g.plane];
-            double turb;
+            const real altvb = var_ds(PV(0, 0, 0), PV(-1, 0, 0), PV(0, -1, 0), PV(0, 1, 0), PV(-1, -1, 0), PV(-1, 1, 0), lo, hi) / CON_G;
+            const real altvb_kp1 = var_ds(PV(0, 0, 1), PV(-1, 0, 1), PV(0, -1, 1), PV(0, 1, 1), PV(-1, -1, 1), PV(-1, 1, 1), lo, hi) / CON_G;
+            const real rho_is = var_ds(RH(0, 0), RH(-1, 0), RH(0, -1), RH(0, 1), RH(-1, -1), RH(-1, 1), lo, hi);
+            const real kd = p.KMOM_dUWINDdz[q], kd_kp1 = p.KMOM_dUWINDdz[q + g.plane];
+            real turb;
             if (k == 0) turb = (0.0 - kd_kp1) / ((altvb - altvb_kp1) * rho_is);
             else if (k == g.nz - 1) turb = (kd + smom_is) / ((altvb - altvb_kp1) * rho_is);
             else turb = (kd - kd_kp1) / ((altvb - altvb_kp1) * rho_is);
@@ -326,13 +326,13 @@ __global__ __launch_bounds__(TI *TJ) void k_uflx_tendency(Geo g, Ptrs p)
         t = t + CON_RE * dlon * dlat / 2.0 *
                     (colp_im1 * (V(-1, 0) + V(-1, 1)) / 2.0 * (corf * CON_RE * coslat + (u_im1 + u) / 2.0 * sinlat) +
                      colp * (V(0, 0) + V(0, 1)) / 2.0 * (corf * CON_RE * coslat + (u + u_ip1) / 2.0 * sinlat));
-        const double pvb_kp1 = p.PVTFVB[q + g.plane], pvb_im1_kp1 = p.PVTFVB[q + g.plane - 1];
+        const real pvb_kp1 = p.PVTFVB[q + g.plane], pvb_im1_kp1 = p.PVTFVB[q + g.plane - 1];
         t = t + pre_grad(p.PHI[q], p.PHI[q - 1], colp, colp_im1, p.POTT[q], p.POTT[q - 1],
                          p.PVTF[q], p.PVTF[q - 1], pvb_k, pvb_im1_k, pvb_im1_kp1, pvb_kp1,
                          p.dsigma[k], p.sigma_vb[k], p.sigma_vb[k + 1], dyis);
         pvb_k = pvb_kp1;
         pvb_im1_k = pvb_im1_kp1;
-        const double dif = p.UVFLX_dif_coef[k];
+        const real dif = p.UVFLX_dif_coef[k];
         if (dif > 0.0)
             t = t + dif * (p.UFLX[q - 1] + p.UFLX[q + 1] + p.UFLX[q - P] + p.UFLX[q + P] - 4.0 * p.UFLX[q]);
         p.dUFLXdt[q] = t;
@@ -352,42 +352,42 @@ __global__ __launch_bounds__(TI *TJ) void k_vflx_tendency(Geo g, Ptrs p, int jlo
     const int P = g.P;
     const size_t c = at2(g, i, jj);
     const int dp = (i == g.nx) ? -(g.nx - 1) : 1;       // offset to the i+1 flux column (dyn_VFLX.py:349-356)
-    const double colp = p.COLP[c], colp_jm1 = p.COLP[c - P];
-    const double corf = p.corf[c], corf_jm1 = p.corf[c - P];
-    const double lat = p.lat_rad[c], lat_jm1 = p.lat_rad[c - P];
-    const double coslat = cos(lat), sinlat = sin(lat), coslat_jm1 = cos(lat_jm1), sinlat_jm1 = sin(lat_jm1);
-    const double dlon = p.dlon_rad[c], dlat = p.dlat_rad[c], dxjs = p.dxjs[c];
-    double smom_js = 0.0;
+    const real colp = p.COLP[c], colp_jm1 = p.COLP[c - P];
+    const real corf = p.corf[c], corf_jm1 = p.corf[c - P];
+    const real lat = p.lat_rad[c], lat_jm1 = p.lat_rad[c - P];
+    const real coslat = cos(lat), sinlat = sin(lat), coslat_jm1 = cos(lat_jm1), sinlat_jm1 = sin(lat_jm1);
+    const real dlon = p.dlon_rad[c], dlat = p.dlat_rad[c], dxjs = p.dxjs[c];
+    real smom_js = 0.0;
     if (TURB)
         smom_js = var_ds(p.SMOMYFLX[c], p.SMOMYFLX[c - P], p.SMOMYFLX[c - 1], p.SMOMYFLX[c + 1],
                          p.SMOMYFLX[c - P - 1], p.SMOMYFLX[c - P + 1], false, false);
-    double wv_k = p.WWIND_VWIND[c];
-    double pvb_k = p.PVTFVB[c], pvb_jm1_k = p.PVTFVB[c - P];
+    real wv_k = p.WWIND_VWIND[c];
+    real pvb_k = p.PVTFVB[c], pvb_jm1_k = p.PVTFVB[c - P];
     for (int k = 0; k < g.nz; k++) {
         const size_t q = c + (size_t)k * g.plane;
-        const double rflx = p.RFLX[q], rflx_jm1 = p.RFLX[q - P];
-        const double qflx = p.QFLX[q], qflx_ip1 = p.QFLX[q + dp];
-        const double sflx_jm1 = p.SFLX[q - P], sflx_ip1 = p.SFLX[q + dp];
-        const double tflx = p.TFLX[q], tflx_ip1_jm1 = p.TFLX[q - P + dp];
+        const real rflx = p.RFLX[q], rflx_jm1 = p.RFLX[q - P];
+        const real qflx = p.QFLX[q], qflx_ip1 = p.QFLX[q + dp];
+        const real sflx_jm1 = p.SFLX[q - P], sflx_ip1 = p.SFLX[q + dp];
+        const real tflx = p.TFLX[q], tflx_ip1_jm1 = p.TFLX[q - P + dp];
 #define U(a, b) p.UWIND[q + (b) * P + (a)]
 #define V(a, b) p.VWIND[q + (b) * P + (a)]
-        const double v = V(0, 0);
-        double t = 0.0;
+        const real v = V(0, 0);
+        real t = 0.0;
         t = t + (+rflx_jm1 * (V(0, -1) + v) / 2.0 - rflx * (v + V(0, 1)) / 2.0
                  + qflx * (V(-1, 0) + v) / 2.0 - qflx_ip1 * (v + V(1, 0)) / 2.0
                  + sflx_jm1 * (V(-1, -1) + v) / 2.0 - sflx_ip1 * (v + V(1, 1)) / 2.0
                  + -1.0 * (+tflx * (V(-1, 1) + v) / 2.0 - tflx_ip1_jm1 * (v + V(1, -1)) / 2.0));
-        const double wv_kp1 = p.WWIND_VWIND[q + g.plane];
+        const real wv_kp1 = p.WWIND_VWIND[q + g.plane];
         t = t + (wv_k - wv_kp1) / p.dsigma[k];
         wv_k = wv_kp1;
         if (TURB) {
 #define PV(a, b, kk) p.PHIVB[q + (size_t)(kk) * g.plane + (b) * P + (a)]
 #define RH(a, b) p.RHO[q + (b) * P + (a)]
-            const double altvb = var_ds(PV(0, 0, 0), PV(0, -1, 0), PV(-1, 0, 0), PV(1, 0, 0), PV(-1, -1, 0), PV(1, -1, 0), false, false) / CON_G;
-            const double altvb_kp1 = var_ds(PV(0, 0, 1), PV(0, -1, 1), PV(-1, 0, 1), PV(1, 0, 1), PV(-1, -1, 1), PV(1, -1, 1), false, false) / CON_G;
-            const double rho_js = var_ds(RH(0, 0), RH(0, -1), RH(-1, 0), RH(1, 0), RH(-1, -1), RH(1, -1), false, false);
-            const double kd = p.KMOM_dVWINDdz[q], kd_kp1 = p.KMOM_dVWINDdz[q + g.plane];
-            double turb;
+            const real altvb = var_ds(PV(0, 0, 0), PV(0, -1, 0), PV(-1, 0, 0), PV(1, 0, 0), PV(-1, -1, 0), PV(1, -1, 0), false, false) / CON_G;
+            const real altvb_kp1 = var_ds(PV(0, 0, 1), PV(0, -1, 1), PV(-1, 0, 1), PV(1, 0, 1), PV(-1, -1, 1), PV(1, -1, 1), false, false) / CON_G;
+            const real rho_js = var_ds(RH(0, 0), RH(0, -1), RH(-1, 0), RH(1, 0), RH(-1, -1), RH(1, -1), false, false);
+            const real kd = p.KMOM_dVWINDdz[q], kd_kp1 = p.KMOM_dVWINDdz[q + g.plane];
+            real turb;
             if (k == 0) turb = (0.0 - kd_kp1) / ((altvb - altvb_kp1) * rho_js);
             else if (k == g.nz - 1) turb = (kd + smom_js) / ((altvb - altvb_kp1) * rho_js);
             else turb = (kd - kd_kp1) / ((altvb - altvb_kp1) * rho_js);
@@ -397,17 +397,17 @@ __global__ __launch_bounds__(TI *TJ) void k_vflx_tendency(Geo g, Ptrs p, int jlo
 #undef RH
         }
         // Coriolis + metric: dyn_VFLX.py:39-64
-        const double ub_jm1 = (U(0, -1) + U(1, -1)) / 2.0, ub = (U(0, 0) + U(1, 0)) / 2.0;
+        const real ub_jm1 = (U(0, -1) + U(1, -1)) / 2.0, ub = (U(0, 0) + U(1, 0)) / 2.0;
         t = t + -CON_RE * dlon * dlat / 2.0 *
                     (colp_jm1 * ub_jm1 * (corf_jm1 * CON_RE * coslat_jm1 + ub_jm1 * sinlat_jm1) +
                      colp * ub * (corf * CON_RE * coslat + ub * sinlat));
-        const double pvb_kp1 = p.PVTFVB[q + g.plane], pvb_jm1_kp1 = p.PVTFVB[q + g.plane - P];
+        const real pvb_kp1 = p.PVTFVB[q + g.plane], pvb_jm1_kp1 = p.PVTFVB[q + g.plane - P];
         t = t + pre_grad(p.PHI[q], p.PHI[q - P], colp, colp_jm1, p.POTT[q], p.POTT[q - P],
                          p.PVTF[q], p.PVTF[q - P], pvb_k, pvb_jm1_k, pvb_jm1_kp1, pvb_kp1,
                          p.dsigma[k], p.sigma_vb[k], p.sigma_vb[k + 1], dxjs);
         pvb_k = pvb_kp1;
         pvb_jm1_k = pvb_jm1_kp1;
-        const double dif = p.UVFLX_dif_coef[k];
+        const real dif = p.UVFLX_dif_coef[k];
         if (dif > 0.0)
             t = t + dif * (p.VFLX[q - 1] + p.VFLX[q + 1] + p.VFLX[q - P] + p.VFLX[q + P] - 4.0 * p.VFLX[q]);
         p.dVFLXdt[q] = t;
@@ -425,41 +425,41 @@ __global__ __launch_bounds__(TI *TJ) void k_pott_tendency(Geo g, Ptrs p)
     if (i > g.nx || j > g.ny) return;
     const int P = g.P;
     const size_t c = at2(g, i, j);
-    const double colp = p.COLP[c], colp_new = p.COLP_NEW[c];
-    const double c_im1 = p.COLP[c - 1], c_ip1 = p.COLP[c + 1], c_jm1 = p.COLP[c - P], c_jp1 = p.COLP[c + P];
-    const double area = p.A[c];
-    double surf = 0.0;
+    const real colp = p.COLP[c], colp_new = p.COLP_NEW[c];
+    const real c_im1 = p.COLP[c - 1], c_ip1 = p.COLP[c + 1], c_jm1 = p.COLP[c - P], c_jp1 = p.COLP[c + P];
+    const real area = p.A[c];
+    real surf = 0.0;
     if (TURB) surf = p.SSHFLX[c] / CON_CP;
-    double w_k = 0.0, pvb_k = 0.0;     // k = 0: first term omitted (dyn_functions.py:124-127)
-    double pott_km1 = 0.0, phi_km1 = 0.0;
+    real w_k = 0.0, pvb_k = 0.0;     // k = 0: first term omitted (dyn_functions.py:124-127)
+    real pott_km1 = 0.0, phi_km1 = 0.0;
     for (int k = 0; k < g.nz; k++) {
         const size_t q = c + (size_t)k * g.plane;
-        const double pt = p.POTT[q];
-        const double p_im1 = p.POTT[q - 1], p_ip1 = p.POTT[q + 1], p_jm1 = p.POTT[q - P], p_jp1 = p.POTT[q + P];
-        double t = 0.0;
+        const real pt = p.POTT[q];
+        const real p_im1 = p.POTT[q - 1], p_ip1 = p.POTT[q + 1], p_jm1 = p.POTT[q - P], p_jp1 = p.POTT[q + P];
+        real t = 0.0;
         t = t + (+p.UFLX[q] * (p_im1 + pt) / 2.0 - p.UFLX[q + 1] * (pt + p_ip1) / 2.0
                  + p.VFLX[q] * (p_jm1 + pt) / 2.0 - p.VFLX[q + P] * (pt + p_jp1) / 2.0) / area;
-        const double w_kp1 = p.WWIND[q + g.plane], pvb_kp1 = p.POTTVB[q + g.plane];
+        const real w_kp1 = p.WWIND[q + g.plane], pvb_kp1 = p.POTTVB[q + g.plane];
         if (k == 0) t = t + colp_new * (-w_kp1 * pvb_kp1) / p.dsigma[k];
         else t = t + colp_new * (+w_k * pvb_k - w_kp1 * pvb_kp1) / p.dsigma[k];
         w_k = w_kp1;
         pvb_k = pvb_kp1;
         if (TURB) {   // dyn_functions.py:26-67
-            const double phi = p.PHI[q];
-            const double alt = phi / CON_G;
-            const double altvb = p.PHIVB[q] / CON_G, altvb_kp1 = p.PHIVB[q + g.plane] / CON_G;
-            const double rho = p.RHO[q];
-            double turb;
+            const real phi = p.PHI[q];
+            const real alt = phi / CON_G;
+            const real altvb = p.PHIVB[q] / CON_G, altvb_kp1 = p.PHIVB[q + g.plane] / CON_G;
+            const real rho = p.RHO[q];
+            real turb;
             if (k == 0) {
-                const double alt_kp1 = p.PHI[q + g.plane] / CON_G;
+                const real alt_kp1 = p.PHI[q + g.plane] / CON_G;
                 turb = colp * ((0.0 - ((pt - p.POTT[q + g.plane]) / (alt - alt_kp1) * p.RHOVB[q + g.plane] * p.KHEAT[q + g.plane])) /
                                ((altvb - altvb_kp1) * rho));
             } else if (k == g.nz - 1) {
-                const double alt_km1 = phi_km1 / CON_G;
+                const real alt_km1 = phi_km1 / CON_G;
                 turb = colp * ((((pott_km1 - pt) / (alt_km1 - alt) * p.RHOVB[q] * p.KHEAT[q]) + surf) /
                                ((altvb - altvb_kp1) * rho));
             } else {
-                const double alt_kp1 = p.PHI[q + g.plane] / CON_G, alt_km1 = phi_km1 / CON_G;
+                const real alt_kp1 = p.PHI[q + g.plane] / CON_G, alt_km1 = phi_km1 / CON_G;
                 turb = colp * ((((pott_km1 - pt) / (alt_km1 - alt) * p.RHOVB[q] * p.KHEAT[q])
                                 - ((pt - p.POTT[q + g.plane]) / (alt - alt_kp1) * p.RHOVB[q + g.plane] * p.KHEAT[q + g.plane])) /
                                ((altvb - altvb_kp1) * rho));
@@ -469,7 +469,7 @@ __global__ __launch_bounds__(TI *TJ) void k_pott_tendency(Geo g, Ptrs p)
             phi_km1 = phi;
         }
         pott_km1 = pt;
-        const double dif = p.POTT_dif_coef[k];
+        const real dif = p.POTT_dif_coef[k];
         if (dif > 0.0)
             t = t + dif * (c_im1 * p_im1 + c_ip1 * p_ip1 + c_jm1 * p_jm1 + c_jp1 * p_jp1 - 4.0 * colp * pt);
         if (g.i_rad) t = t + p.dPOTTdt_RAD[q] * colp;
@@ -480,9 +480,9 @@ __global__ __launch_bounds__(TI *TJ) void k_pott_tendency(Geo g, Ptrs p)
 // ------------------------------------------------------------------------------------
 // dyn_functions.py:70-95: interface value by logarithmic interpolation (Python's max(VAR,
 // min_val): the first argument unless the second is greater)
-__device__ __forceinline__ double varvb_log(double var, double var_km1)
+__device__ __forceinline__ real varvb_log(real var, real var_km1)
 {
-    const double min_val = 0.0000001;
+    const real min_val = 0.0000001;
     if (min_val > var) var = min_val;
     if (min_val > var_km1) var_km1 = min_val;
     if (var_km1 == var) return var;
@@ -493,10 +493,10 @@ __device__ __forceinline__ double varvb_log(double var, double var_km1)
 // lower argument of one interface and the upper argument of the next (k_moist carries the cache down the column),
 // and neither is formed where the two clamped values are equal (cloud water is 1e-7 = the clamp in most of the
 // atmosphere).  Same operations on the same operands as varvb_log: bit-identical.
-struct LogCache { double c, l, r; bool have; };
-__device__ __forceinline__ LogCache log_cache(double var)
+struct LogCache { real c, l, r; bool have; };
+__device__ __forceinline__ LogCache log_cache(real var)
 {
-    const double min_val = 0.0000001;
+    const real min_val = 0.0000001;
     LogCache x;
     x.c = (min_val > var) ? min_val : var;
     x.l = 0.0; x.r = 0.0; x.have = false;
@@ -506,7 +506,7 @@ __device__ __forceinline__ void log_need(LogCache &x)
 {
     if (!x.have) { x.l = log(x.c); x.r = 1.0 / x.c; x.have = true; }
 }
-__device__ __forceinline__ double varvb_log_cached(LogCache &var, LogCache &var_km1)
+__device__ __forceinline__ real varvb_log_cached(LogCache &var, LogCache &var_km1)
 {
     if (var_km1.c == var.c) return var.c;
     log_need(var);
@@ -515,13 +515,13 @@ __device__ __forceinline__ double varvb_log_cached(LogCache &var, LogCache &var_
 }
 
 // dyn_functions.py:26-67
-__device__ __forceinline__ double turb_flux(double phi, double phi_kp1, double phi_km1, double phivb,
-                                            double phivb_kp1, double var, double var_kp1, double var_km1,
-                                            double kvar, double kvar_kp1, double rho, double rhovb,
-                                            double rhovb_kp1, double colp, double surf, int k, int nz)
+__device__ __forceinline__ real turb_flux(real phi, real phi_kp1, real phi_km1, real phivb,
+                                            real phivb_kp1, real var, real var_kp1, real var_km1,
+                                            real kvar, real kvar_kp1, real rho, real rhovb,
+                                            real rhovb_kp1, real colp, real surf, int k, int nz)
 {
-    const double alt = phi / CON_G, alt_kp1 = phi_kp1 / CON_G, alt_km1 = phi_km1 / CON_G;
-    const double altvb = phivb / CON_G, altvb_kp1 = phivb_kp1 / CON_G;
+    const real alt = phi / CON_G, alt_kp1 = phi_kp1 / CON_G, alt_km1 = phi_km1 / CON_G;
+    const real altvb = phivb / CON_G, altvb_kp1 = phivb_kp1 / CON_G;
     if (k == 0)
         return colp * ((0.0 - ((var - var_kp1) / (alt - alt_kp1) * rhovb_kp1 * kvar_kp1)) / ((altvb - altvb_kp1) * rho));
     if (k == nz - 1)
@@ -540,32 +540,32 @@ __device__ __forceinline__ double turb_flux(double phi, double phi_kp1, double p
 // TURB_PRE: the turbulent tendencies come from k_turb_tendencies (fused turbulence-coupled step: by the
 // time this kernel runs, PHI already belongs to the new state).
 template <bool TURB, bool EULER, bool FROM_WINDS = false, bool TURB_PRE = false>
-__global__ __launch_bounds__(TI *TJ) void k_moist(Geo g, Ptrs p, const double *qv_old, const double *qc_old,
-                                                  double *qv_out, double *qc_out, double dt, int lin)
+__global__ __launch_bounds__(TI *TJ) void k_moist(Geo g, Ptrs p, const real *qv_old, const real *qc_old,
+                                                  real *qv_out, real *qc_out, real dt, int lin)
 {
     int i, j;
     if (!owned_cell(g, lin, i, j)) return;
     const int P = g.P, nz = g.nz;
     const size_t c = at2(g, i, j);
-    const double colp = p.COLP[c], colp_new = p.COLP_NEW[c], colp_old = p.COLP_OLD[c];
-    const double c_im1 = p.COLP[c - 1], c_ip1 = p.COLP[c + 1], c_jm1 = p.COLP[c - P], c_jp1 = p.COLP[c + P];
-    const double area = p.A[c];
-    double surf = 0.0;
+    const real colp = p.COLP[c], colp_new = p.COLP_NEW[c], colp_old = p.COLP_OLD[c];
+    const real c_im1 = p.COLP[c - 1], c_ip1 = p.COLP[c + 1], c_jm1 = p.COLP[c - P], c_jp1 = p.COLP[c + P];
+    const real area = p.A[c];
+    real surf = 0.0;
     if (TURB) surf = p.SLHFLX[c] / CON_LH;
-    const double r_area = 1.0 / area, r_cn = 1.0 / colp_new;
-    double qv_km1 = 0.0, qc_km1 = 0.0, phi_km1 = 0.0;
-    double fv_k = 0.0, fc_k = 0.0;                 // W * interface value at interface k (0 at the top)
-    double qv_k = p.QV[c], qc_k = p.QC[c];
+    const real r_area = 1.0 / area, r_cn = 1.0 / colp_new;
+    real qv_km1 = 0.0, qc_km1 = 0.0, phi_km1 = 0.0;
+    real fv_k = 0.0, fc_k = 0.0;                 // W * interface value at interface k (0 at the top)
+    real qv_k = p.QV[c], qc_k = p.QC[c];
     LogCache lv_k = log_cache(qv_k), lc_k = log_cache(qc_k);
     // software pipeline as in k_pott_fused: the inputs of level k+1 are requested before level k is
     // computed, so the HBM latency overlaps the two logarithms per interface
-    __shared__ double s_met[FROM_WINDS ? 4 : 1][TI * TJ];
+    __shared__ real s_met[FROM_WINDS ? 4 : 1][TI * TJ];
     const int st = threadIdx.y * TI + threadIdx.x;
     if (FROM_WINDS) {
         s_met[0][st] = p.dyis[c]; s_met[1][st] = p.dyis[c + 1]; s_met[2][st] = p.dxjs[c]; s_met[3][st] = p.dxjs[c + P];
     }
-    const double *fu = FROM_WINDS ? p.UWIND : p.UFLX, *fv = FROM_WINDS ? p.VWIND : p.VFLX;
-    struct In { double uf, uf1, vf, vf1, w1, qv1, qc1, v_im1, v_ip1, v_jm1, v_jp1, c_im1, c_ip1, c_jm1, c_jp1, vo, co; };
+    const real *fu = FROM_WINDS ? p.UWIND : p.UFLX, *fv = FROM_WINDS ? p.VWIND : p.VFLX;
+    struct In { real uf, uf1, vf, vf1, w1, qv1, qc1, v_im1, v_ip1, v_jm1, v_jp1, c_im1, c_ip1, c_jm1, c_jp1, vo, co; };
     auto load = [&](int k) {
         In r;
         const size_t q = c + (size_t)k * g.plane;
@@ -586,9 +586,9 @@ __global__ __launch_bounds__(TI *TJ) void k_moist(Geo g, Ptrs p, const double *q
         const size_t q = c + (size_t)k * g.plane;
         const In cur = nxt;
         if (k + 1 < nz) nxt = load(k + 1);
-        const double ds = p.dsigma[k], dif = p.moist_dif_coef[k];
-        const double rds = EULER ? p.rdsigma[k] : 0.0;
-        double uflx = cur.uf, uflx_ip1 = cur.uf1, vflx = cur.vf, vflx_jp1 = cur.vf1;
+        const real ds = p.dsigma[k], dif = p.moist_dif_coef[k];
+        const real rds = EULER ? p.rdsigma[k] : 0.0;
+        real uflx = cur.uf, uflx_ip1 = cur.uf1, vflx = cur.vf, vflx_jp1 = cur.vf1;
         if (FROM_WINDS) {           // dyn_continuity.py:40-45, operand order of k_continuity_reg
             uflx = (c_im1 + colp) / 2.0 * uflx * s_met[0][st];
             uflx_ip1 = (colp + c_ip1) / 2.0 * uflx_ip1 * s_met[1][st];
@@ -596,31 +596,31 @@ __global__ __launch_bounds__(TI *TJ) void k_moist(Geo g, Ptrs p, const double *q
             vflx_jp1 = (colp + c_jp1) / 2.0 * vflx_jp1 * s_met[3][st];
         }
         const bool last = (k == nz - 1);
-        const double qv_kp1 = cur.qv1, qc_kp1 = cur.qc1;
-        double fv_kp1 = 0.0, fc_kp1 = 0.0;
+        const real qv_kp1 = cur.qv1, qc_kp1 = cur.qc1;
+        real fv_kp1 = 0.0, fc_kp1 = 0.0;
         if (!last) {
-            const double w_kp1 = cur.w1;
+            const real w_kp1 = cur.w1;
             LogCache lv_kp1 = log_cache(qv_kp1), lc_kp1 = log_cache(qc_kp1);
             fv_kp1 = w_kp1 * varvb_log_cached(lv_kp1, lv_k);
             fc_kp1 = w_kp1 * varvb_log_cached(lc_kp1, lc_k);
             lv_k = lv_kp1; lc_k = lc_kp1;
         }
-        double tq[2];
+        real tq[2];
 #pragma unroll
         for (int s = 0; s < 2; s++) {
-            const double x = s == 0 ? qv_k : qc_k;
-            const double x_im1 = s == 0 ? cur.v_im1 : cur.c_im1, x_ip1 = s == 0 ? cur.v_ip1 : cur.c_ip1;
-            const double x_jm1 = s == 0 ? cur.v_jm1 : cur.c_jm1, x_jp1 = s == 0 ? cur.v_jp1 : cur.c_jp1;
-            const double f_k = s == 0 ? fv_k : fc_k, f_kp1 = s == 0 ? fv_kp1 : fc_kp1;
-            double d = 0.0;
-            const double adv = (+uflx * (x_im1 + x) / 2.0 - uflx_ip1 * (x + x_ip1) / 2.0
+            const real x = s == 0 ? qv_k : qc_k;
+            const real x_im1 = s == 0 ? cur.v_im1 : cur.c_im1, x_ip1 = s == 0 ? cur.v_ip1 : cur.c_ip1;
+            const real x_jm1 = s == 0 ? cur.v_jm1 : cur.c_jm1, x_jp1 = s == 0 ? cur.v_jp1 : cur.c_jp1;
+            const real f_k = s == 0 ? fv_k : fc_k, f_kp1 = s == 0 ? fv_kp1 : fc_kp1;
+            real d = 0.0;
+            const real adv = (+uflx * (x_im1 + x) / 2.0 - uflx_ip1 * (x + x_ip1) / 2.0
                                 + vflx * (x_jm1 + x) / 2.0 - vflx_jp1 * (x + x_jp1) / 2.0);
             // fused step (EULER): per-column / per-level divisors as reciprocals, as in k_pott_fused
             d = d + (EULER ? adv * r_area : adv / area);
             if (k == 0) d = d + (EULER ? colp_new * (-f_kp1) * rds : colp_new * (-f_kp1) / ds);
             else d = d + (EULER ? colp_new * (+f_k - f_kp1) * rds : colp_new * (+f_k - f_kp1) / ds);
             if (TURB) {
-                const double tb = turb_flux(p.PHI[q], last ? 0.0 : p.PHI[q + g.plane], phi_km1, p.PHIVB[q], p.PHIVB[q + g.plane],
+                const real tb = turb_flux(p.PHI[q], last ? 0.0 : p.PHI[q + g.plane], phi_km1, p.PHIVB[q], p.PHIVB[q + g.plane],
                                             x, s == 0 ? qv_kp1 : qc_kp1, s == 0 ? qv_km1 : qc_km1,
                                             p.KHEAT[q], p.KHEAT[q + g.plane], p.RHO[q], p.RHOVB[q], p.RHOVB[q + g.plane],
                                             colp, s == 0 ? surf : 0.0, k, nz);
@@ -633,8 +633,8 @@ __global__ __launch_bounds__(TI *TJ) void k_moist(Geo g, Ptrs p, const double *q
             tq[s] = d;
         }
         if (EULER) {
-            double nv = cur.vo * colp_old * r_cn + dt * tq[0] * r_cn;
-            double nc = cur.co * colp_old * r_cn + dt * tq[1] * r_cn;
+            real nv = cur.vo * colp_old * r_cn + dt * tq[0] * r_cn;
+            real nc = cur.co * colp_old * r_cn + dt * tq[1] * r_cn;
             if (g.i_moist_clip) {       // dyn_timestep.py:145-154: `if QV < 0: QV = 0` (a NaN stays a NaN)
                 if (nv < 0.0) nv = 0.0;
                 if (nc < 0.0) nc = 0.0;
@@ -659,7 +659,7 @@ __global__ __launch_bounds__(TI *TJ) void k_moist(Geo g, Ptrs p, const double *q
 // j in [1,ny+1]; U and POTT own rows 1..ny, V owns js rows not on a pole.
 // `cur` pointers are the fields being written (UWIND, VWIND, POTT); *_OLD and the
 // tendencies are read at the same cell only, so writing in place is race-free.
-__global__ __launch_bounds__(TI *TJ) void k_euler_forward(Geo g, Ptrs p, double dt)
+__global__ __launch_bounds__(TI *TJ) void k_euler_forward(Geo g, Ptrs p, real dt)
 {
     DYC_IJ(1, 1)
     if (i > g.nx || j > g.ny + 1) return;
@@ -673,7 +673,7 @@ __global__ __launch_bounds__(TI *TJ) void k_euler_forward(Geo g, Ptrs p, double 
     const bool row_c = (j <= g.ny);
     const bool v_pole = (jg == 1) || (jg == g.ny_global + 1);
     const bool v_own = row_c || g.pole_n;   // js = ny+1 belongs to the northern neighbour band
-    double ca_is = 1.0, cao_is = 1.0, ca_js = 1.0, cao_js = 1.0, cn = 1.0, co = 1.0;
+    real ca_is = 1.0, cao_is = 1.0, ca_js = 1.0, cao_js = 1.0, cn = 1.0, co = 1.0;
     if (row_c) {
         if (jg == 1) {
             ca_is = 1.0 / 4.0 * (CN(-1, 1) + CN(0, 1) + CN(-1, 0) + CN(0, 0));
@@ -702,8 +702,8 @@ __global__ __launch_bounds__(TI *TJ) void k_euler_forward(Geo g, Ptrs p, double 
             p.UWIND[at(g, i, j, k)] = p.UWIND_OLD[q] * cao_is / ca_is + dt * p.dUFLXdt[q] / ca_is;
             p.POTT[at(g, i, j, k)] = p.POTT_OLD[q] * co / cn + dt * p.dPOTTdt[q] / cn;
             if (g.i_moist) {   // the reference's CPU kernel does not clip (dyn_timestep.py:291-296), its accelerator kernel does (:145-154)
-                double nv = p.QV_OLD[q] * co / cn + dt * p.dQVdt[q] / cn;
-                double nc = p.QC_OLD[q] * co / cn + dt * p.dQCdt[q] / cn;
+                real nv = p.QV_OLD[q] * co / cn + dt * p.dQVdt[q] / cn;
+                real nc = p.QC_OLD[q] * co / cn + dt * p.dQCdt[q] / cn;
                 if (g.i_moist_clip) {
                     if (nv < 0.0) nv = 0.0;
                     if (nc < 0.0) nc = 0.0;
@@ -726,7 +726,7 @@ __global__ __launch_bounds__(TI *TJ) void k_euler_forward(Geo g, Ptrs p, double 
 #ifndef DYC_POW_VARIANT
 #define DYC_POW_VARIANT 0
 #endif
-__device__ __forceinline__ double exner_vb(double p)
+__device__ __forceinline__ real exner_vb(real p)
 {
 #if DYC_POW_VARIANT == 1
     return exp(CON_KAPPA * (log(p) - 11.512925464970229));   // log(100000)
@@ -740,15 +740,15 @@ __device__ __forceinline__ double exner_vb(double p)
 // switched off inside: the compiler fuses a*b+c differently in different surroundings, and a band
 // recomputes the diagnostics of rows it received from its neighbour -- they must come out bit
 // for bit as the owner computed them.
-__device__ __forceinline__ double interface_pressure(double pair_top, double svb, double colp)
+__device__ __forceinline__ real interface_pressure(real pair_top, real svb, real colp)
 {
 #pragma clang fp contract(off)
     return pair_top + svb * colp;
 }
-struct DiagLevel { double p_km12, pvb_k, pvtf, phi, phivb; };
+struct DiagLevel { real p_km12, pvb_k, pvtf, phi, phivb; };
 // ... with the interface pressure and its Exner value already at hand
-__device__ __forceinline__ DiagLevel diag_level_pre(double p_km12, double pvb_k, double pott,
-                                                    double p_kp12, double pvb_kp1, double phivb_kp1)
+__device__ __forceinline__ DiagLevel diag_level_pre(real p_km12, real pvb_k, real pott,
+                                                    real p_kp12, real pvb_kp1, real phivb_kp1)
 {
 #pragma clang fp contract(off)
     DiagLevel d;
@@ -759,14 +759,14 @@ __device__ __forceinline__ DiagLevel diag_level_pre(double p_km12, double pvb_k,
     d.phivb = d.phi - CON_CP * (pott * (d.pvb_k - d.pvtf));
     return d;
 }
-__device__ __forceinline__ DiagLevel diag_level(double pair_top, double svb_k, double colp, double pott,
-                                                double p_kp12, double pvb_kp1, double phivb_kp1)
+__device__ __forceinline__ DiagLevel diag_level(real pair_top, real svb_k, real colp, real pott,
+                                                real p_kp12, real pvb_kp1, real phivb_kp1)
 {
-    const double p_km12 = interface_pressure(pair_top, svb_k, colp);
+    const real p_km12 = interface_pressure(pair_top, svb_k, colp);
     return diag_level_pre(p_km12, exner_vb(p_km12), pott, p_kp12, pvb_kp1, phivb_kp1);
 }
 // interface value between levels k and k+1, dyn_diagnostics.py:183-186
-__device__ __forceinline__ double pottvb_between(double pvb_kp1, double pvtf, double pott, double pvtf_kp1, double pott_kp1)
+__device__ __forceinline__ real pottvb_between(real pvb_kp1, real pvtf, real pott, real pvtf_kp1, real pott_kp1)
 {
 #pragma clang fp contract(off)
     return ((pvb_kp1 - pvtf) * pott + (pvtf_kp1 - pvb_kp1) * pott_kp1) / (pvtf_kp1 - pvtf);
@@ -776,29 +776,29 @@ __device__ __forceinline__ double pottvb_between(double pvb_kp1, double pvtf, do
 // bottom-up sweep over the whole array incl. halos (i in [0,nx+1], j in [0,ny+1]).
 // One pow() per interface instead of the reference's two per cell: PVTFVB[k+1] is carried.
 // `pvb` (optional): the Exner values of the column's interfaces, pvb[k * stride], computed beforehand.
-__device__ __forceinline__ void diag_column(const Geo &g, const Ptrs &p, int i, int j, const double *pvb = nullptr, int stride = 0)
+__device__ __forceinline__ void diag_column(const Geo &g, const Ptrs &p, int i, int j, const real *pvb = nullptr, int stride = 0)
 {
     const size_t c = at2(g, i, j);
     const int nz = g.nz;
-    const double colp = p.COLP[c];
-    double p_kp12 = interface_pressure(g.pair_top, p.sigma_vb[nz], colp);
-    double pvb_kp1 = pvb ? pvb[nz * stride] : exner_vb(p_kp12);
-    double phivb_kp1 = p.HSURF[c] * CON_G;
+    const real colp = p.COLP[c];
+    real p_kp12 = interface_pressure(g.pair_top, p.sigma_vb[nz], colp);
+    real pvb_kp1 = pvb ? pvb[nz * stride] : exner_vb(p_kp12);
+    real phivb_kp1 = p.HSURF[c] * CON_G;
     p.PVTFVB[c + (size_t)nz * g.plane] = pvb_kp1;
     p.PHIVB[c + (size_t)nz * g.plane] = phivb_kp1;
-    double pott_kp1 = 0.0, pvtf_kp1 = 0.0, pottvb_first = 0.0;
+    real pott_kp1 = 0.0, pvtf_kp1 = 0.0, pottvb_first = 0.0;
     for (int k = nz - 1; k >= 0; k--) {
         const size_t q = c + (size_t)k * g.plane;
-        const double pott = p.POTT[q];
+        const real pott = p.POTT[q];
         const DiagLevel dl = pvb ? diag_level_pre(interface_pressure(g.pair_top, p.sigma_vb[k], colp), pvb[k * stride], pott, p_kp12, pvb_kp1, phivb_kp1)
                                  : diag_level(g.pair_top, p.sigma_vb[k], colp, pott, p_kp12, pvb_kp1, phivb_kp1);
-        const double p_km12 = dl.p_km12, pvb_k = dl.pvb_k, pvtf = dl.pvtf, phi = dl.phi, phivb = dl.phivb;
+        const real p_km12 = dl.p_km12, pvb_k = dl.pvb_k, pvtf = dl.pvtf, phi = dl.phi, phivb = dl.phivb;
         p.PVTF[q] = pvtf;
         p.PVTFVB[q] = pvb_k;
         p.PHI[q] = phi;
         p.PHIVB[q] = phivb;
         if (k < nz - 1) {   // interface k+1 between levels k and k+1
-            const double vb = pottvb_between(pvb_kp1, pvtf, pott, pvtf_kp1, pott_kp1);
+            const real vb = pottvb_between(pvb_kp1, pvtf, pott, pvtf_kp1, pott_kp1);
             p.POTTVB[q + g.plane] = vb;
             if (k == nz - 2 && nz > 2)   // surface extrapolation (elif branch, dyn_diagnostics.py:191-194)
                 p.POTTVB[c + (size_t)nz * g.plane] = pott_kp1 - (vb - pott_kp1);
@@ -827,7 +827,7 @@ __global__ __launch_bounds__(TI *TJ) void k_primary_diag(Geo g, Ptrs p)
 // the columns with those values taken from LDS.  Same helper functions, same bits as diag_column.
 __global__ __launch_bounds__(256) void k_primary_diag_rows(Geo g, Ptrs p, int row_a, int row_b)
 {
-    extern __shared__ double s_pvb[];                   // [nz + 1][64]
+    extern __shared__ real s_pvb[];                   // [nz + 1][64]
     const int i0 = blockIdx.x * 64;
     const int j = blockIdx.y == 0 ? row_a : row_b;
     if (j < 0) return;
@@ -851,10 +851,10 @@ __global__ __launch_bounds__(TI *TJ) void k_diag_rho(Geo g, Ptrs p)
     const size_t c = at2(g, i, j);
     for (int k = 0; k <= g.nz; k++) {
         const size_t q = c + (size_t)k * g.plane;
-        const double pvb = p.PVTFVB[q];
+        const real pvb = p.PVTFVB[q];
         p.RHOVB[q] = 100000.0 * pow(pvb, 1.0 / CON_KAPPA) / (CON_RD * (p.POTTVB[q] * pvb));
         if (k < g.nz) {
-            const double pv = p.PVTF[q];
+            const real pv = p.PVTF[q];
             p.RHO[q] = 100000.0 * pow(pv, 1.0 / CON_KAPPA) / (CON_RD * (p.POTT[q] * pv));
         }
     }
@@ -868,18 +868,18 @@ __global__ __launch_bounds__(TI *TJ) void k_diag_secondary(Geo g, Ptrs p)
     const size_t c = at2(g, i, j);
     for (int k = 0; k <= g.nz; k++) {
         const size_t q = c + (size_t)k * g.plane;
-        const double pvb = p.PVTFVB[q];
-        const double pairvb = 100000.0 * pow(pvb, 1.0 / CON_KAPPA), tairvb = p.POTTVB[q] * pvb;
+        const real pvb = p.PVTFVB[q];
+        const real pairvb = 100000.0 * pow(pvb, 1.0 / CON_KAPPA), tairvb = p.POTTVB[q] * pvb;
         p.PAIRVB[q] = pairvb;
         p.TAIRVB[q] = tairvb;
         p.RHOVB[q] = pairvb / (CON_RD * tairvb);
         if (k < g.nz) {
-            const double pv = p.PVTF[q];
-            const double tair = p.POTT[q] * pv, pair = 100000.0 * pow(pv, 1.0 / CON_KAPPA);
+            const real pv = p.PVTF[q];
+            const real tair = p.POTT[q] * pv, pair = 100000.0 * pow(pv, 1.0 / CON_KAPPA);
             p.TAIR[q] = tair;
             p.PAIR[q] = pair;
             p.RHO[q] = pair / (CON_RD * tair);
-            const double wx = (p.UWIND[q] + p.UWIND[q + 1]) / 2.0, wy = (p.VWIND[q] + p.VWIND[q + g.P]) / 2.0;
+            const real wx = (p.UWIND[q] + p.UWIND[q + 1]) / 2.0, wy = (p.VWIND[q] + p.VWIND[q + g.P]) / 2.0;
             p.WINDX[q] = wx;
             p.WINDY[q] = wy;
             p.WIND[q] = sqrt(wx * wx + wy * wy);
@@ -893,26 +893,26 @@ __global__ __launch_bounds__(TI *TJ) void k_turbulence(Geo g, Ptrs p)
 {
     DYC_IJ(0, 0)
     if (i > g.nx + 1 || j > g.ny + 1) return;
-    const double Ri_c = 1.0, free_mix_len = 200.0, con_k = 0.35, con_Pr = 0.72;
-    const double min_wind_diff = 0.0001, min_KMOM = 0.000001, max_KMOM = 0.01;
+    const real Ri_c = 1.0, free_mix_len = 200.0, con_k = 0.35, con_Pr = 0.72;
+    const real min_wind_diff = 0.0001, min_KMOM = 0.000001, max_KMOM = 0.01;
     const size_t c = at2(g, i, j);
-    const double hsurf = p.HSURF[c];
-    double wx_km = p.WINDX[c], wy_km = p.WINDY[c], phi_km = p.PHI[c], qv_km = p.QV[c], pott_km = p.POTT[c];
+    const real hsurf = p.HSURF[c];
+    real wx_km = p.WINDX[c], wy_km = p.WINDY[c], phi_km = p.PHI[c], qv_km = p.QV[c], pott_km = p.POTT[c];
     for (int k = 1; k < g.nz; k++) {
         const size_t q = c + (size_t)k * g.plane;
-        const double wx_kp = p.WINDX[q], wy_kp = p.WINDY[q], phi_kp = p.PHI[q], qv_kp = p.QV[q], pott_kp = p.POTT[q];
-        double ax = wx_km, ay = wy_km;
+        const real wx_kp = p.WINDX[q], wy_kp = p.WINDY[q], phi_kp = p.PHI[q], qv_kp = p.QV[q], pott_kp = p.POTT[q];
+        real ax = wx_km, ay = wy_km;
         if (ax == wx_kp) ax += min_wind_diff;
         if (ay == wy_kp) ay += min_wind_diff;
-        const double alt_k = p.PHIVB[q] / CON_G, alt_km = phi_km / CON_G, alt_kp = phi_kp / CON_G;
-        const double hgt = alt_k - hsurf;
-        const double mix_len = con_k * hgt / (1.0 + con_k * hgt / free_mix_len);
-        const double qv_k = varvb_log(qv_kp, qv_km);
-        const double pott_v = p.POTTVB[q] * (1.0 + qv_k / 0.622) / (1.0 + qv_k);
-        const double dwx = ax - wx_kp, dwy = ay - wy_kp, dz = alt_km - alt_kp;
-        const double ri_b = (CON_G / pott_v * (pott_km - pott_kp) * dz) / (dwx * dwx + dwy * dwy);
-        const double shear = sqrt((dwx / dz) * (dwx / dz) + (dwy / dz) * (dwy / dz));
-        double kmom = mix_len * mix_len * shear * (Ri_c - ri_b) / Ri_c;
+        const real alt_k = p.PHIVB[q] / CON_G, alt_km = phi_km / CON_G, alt_kp = phi_kp / CON_G;
+        const real hgt = alt_k - hsurf;
+        const real mix_len = con_k * hgt / (1.0 + con_k * hgt / free_mix_len);
+        const real qv_k = varvb_log(qv_kp, qv_km);
+        const real pott_v = p.POTTVB[q] * (1.0 + qv_k / 0.622) / (1.0 + qv_k);
+        const real dwx = ax - wx_kp, dwy = ay - wy_kp, dz = alt_km - alt_kp;
+        const real ri_b = (CON_G / pott_v * (pott_km - pott_kp) * dz) / (dwx * dwx + dwy * dwy);
+        const real shear = sqrt((dwx / dz) * (dwx / dz) + (dwy / dz) * (dwy / dz));
+        real kmom = mix_len * mix_len * shear * (Ri_c - ri_b) / Ri_c;
         if (kmom < min_KMOM) kmom = min_KMOM;
         if (kmom > max_KMOM) kmom = max_KMOM;
         p.KMOM[q] = kmom;
@@ -924,7 +924,7 @@ __global__ __launch_bounds__(TI *TJ) void k_turbulence(Geo g, Ptrs p)
 // ------------------------------------------------------------------------------------
 // lateral boundary conditions of one field: misc_boundaries.py:47-82.  Every halo cell
 // pulls from the interior cell it mirrors, so one pass suffices (corners included).
-__global__ void k_exchange_bc(Geo g, double *F, int stgx, int stgy, int nk)
+__global__ void k_exchange_bc(Geo g, real *F, int stgx, int stgy, int nk)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int j = blockIdx.y;
@@ -935,7 +935,7 @@ __global__ void k_exchange_bc(Geo g, double *F, int stgx, int stgy, int nk)
     if (i == 0) si = g.nx;
     else if (i == g.nx + 1) si = 1;
     else if (stgx && i == g.nx + 2) si = 2;
-    double *pl = F + (size_t)k * g.plane;
+    real *pl = F + (size_t)k * g.plane;
     if (stgy) {
         const bool zero = (g.pole_s && j <= 1) || (g.pole_n && j >= g.ny + 1);
         if (zero) pl[(size_t)j * g.P + i] = 0.0;
@@ -955,12 +955,12 @@ __global__ void k_exchange_bc(Geo g, double *F, int stgx, int stgy, int nk)
 // latitude band are left alone: they arrive by message, periodic columns included.
 struct HaloList {
     int n;
-    double *base[12];
+    real *base[12];
     int stgx[12], stgy[12], nk[12];
     // optional rider: a plain copy of one 2-D plane (COLP <- COLP_NEW of dyn_matsuno.py:64-67) on the
     // z-slice after the last field, so that the step does not pay a launch for it
-    const double *copy_src;
-    double *copy_dst;
+    const real *copy_src;
+    real *copy_dst;
     long long copy_n;
 };
 __global__ void k_halo_multi(Geo g, HaloList l)
@@ -978,7 +978,7 @@ __global__ void k_halo_multi(Geo g, HaloList l)
     int t = blockIdx.x * blockDim.x + threadIdx.x;
     const int stgx = l.stgx[e], stgy = l.stgy[e];
     const int fnx = g.nx + 2 + stgx;
-    double *pl = l.base[e] + (size_t)k * g.plane;
+    real *pl = l.base[e] + (size_t)k * g.plane;
     // ---- part A: wall rows ----
     const int rows_s = g.pole_s ? (stgy ? 2 : 1) : 0, rows_n = g.pole_n ? (stgy ? 2 : 1) : 0;
     const int nA = (rows_s + rows_n) * fnx;
@@ -1008,10 +1008,10 @@ __global__ void k_halo_multi(Geo g, HaloList l)
 // ---- layout adaptor: host [i][j][k] (k contiguous) <-> device [k][j][i] ---------------
 // One workgroup transposes a 32(i) x 32(k) tile of row j through LDS, so both the read
 // and the write side are contiguous.
-__global__ void k_to_device(Geo g, const double *__restrict__ src, double *__restrict__ dst,
+__global__ void k_to_device(Geo g, const real *__restrict__ src, real *__restrict__ dst,
                             int n0, int n1, int n2)
 {
-    __shared__ double tile[32][33];
+    __shared__ real tile[32][33];
     const int j = blockIdx.z;
     const int i0 = blockIdx.x * 32, k0 = blockIdx.y * 32;
     for (int r = threadIdx.y; r < 32; r += blockDim.y) {
@@ -1024,10 +1024,10 @@ __global__ void k_to_device(Geo g, const double *__restrict__ src, double *__res
         if (i < n0 && k < n2) dst[(size_t)k * g.plane + (size_t)j * g.P + i] = tile[threadIdx.x][r];
     }
 }
-__global__ void k_to_host(Geo g, const double *__restrict__ src, double *__restrict__ dst,
+__global__ void k_to_host(Geo g, const real *__restrict__ src, real *__restrict__ dst,
                           int n0, int n1, int n2)
 {
-    __shared__ double tile[32][33];
+    __shared__ real tile[32][33];
     const int j = blockIdx.z;
     const int i0 = blockIdx.x * 32, k0 = blockIdx.y * 32;
     for (int r = threadIdx.y; r < 32; r += blockDim.y) {
@@ -1046,17 +1046,17 @@ __global__ void k_to_host(Geo g, const double *__restrict__ src, double *__restr
 constexpr int ROWLIST_MAX = 12;
 struct RowList {
     int n;
-    double *base[ROWLIST_MAX];
+    real *base[ROWLIST_MAX];
     int row[ROWLIST_MAX], nk[ROWLIST_MAX];
     long long off[ROWLIST_MAX];
 };
-__global__ void k_rows(Geo g, RowList rl, double *buf, int unpack)
+__global__ void k_rows(Geo g, RowList rl, real *buf, int unpack)
 {
     const int e = blockIdx.z, k = blockIdx.y;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= rl.n || k >= rl.nk[e] || i > g.nx + 2) return;
-    double *f = rl.base[e] + (size_t)k * g.plane + (size_t)rl.row[e] * g.P;
-    double *b = buf + rl.off[e] + (size_t)k * (g.nx + 3) + i;
+    real *f = rl.base[e] + (size_t)k * g.plane + (size_t)rl.row[e] * g.P;
+    real *b = buf + rl.off[e] + (size_t)k * (g.nx + 3) + i;
     if (unpack) { f[i] = *b; return; }
     // a packed row carries the periodic images of its interior columns (misc_boundaries.py:22-31), so a
     // sender need not refresh the lateral halo of a field before its rows leave
@@ -1064,7 +1064,7 @@ __global__ void k_rows(Geo g, RowList rl, double *buf, int unpack)
     *b = f[si];
 }
 
-__global__ void k_fill(double *dst, size_t n, double v)
+__global__ void k_fill(real *dst, size_t n, real v)
 {
     for (size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x; t < n; t += (size_t)gridDim.x * blockDim.x)
         dst[t] = v;

@@ -183,7 +183,9 @@ class ModelFields:
     PROGNOSTIC_FIELDS = 'prognostic_fields'
     PRINT_DIAG_FIELDS = 'print_diag_fields'
 
-    def __init__(self, GR, core=None, dtype=np.float64):
+    def __init__(self, GR, core=None, dtype=None):
+        if dtype is None:       # the working precision of the handle (namelist.py:225-226), float64 without one
+            dtype = getattr(core, 'dtype', None) or getattr(getattr(GR, 'nl', None), 'wp', None) or np.float64
         self.host = allocate_fields(GR.nx, GR.ny, GR.nz, dtype=dtype)
         self.device = {}
         self.core = core

@@ -10,6 +10,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'csrc', 'libdycore_hip.so')
+LIB_PATH_F32 = os.path.join(_HERE, 'csrc', 'libdycore_hip_f32.so')     # working_precision = 'float32' (namelist.py:225-226)
 ABI_VERSION = 1
 
 
@@ -27,7 +28,7 @@ class DycoreConfig(C.Structure):
 
 # every symbol include/dycore.h declares (tests check the library exports all of them)
 ABI_SYMBOLS = [
-    'dycore_create', 'dycore_destroy', 'dycore_last_error', 'dycore_abi_version', 'dycore_sync',
+    'dycore_create', 'dycore_destroy', 'dycore_last_error', 'dycore_abi_version', 'dycore_real_bytes', 'dycore_sync',
     'dycore_set_grid', 'dycore_has_field', 'dycore_field_shape', 'dycore_upload', 'dycore_download', 'dycore_field_ptr',
     'dycore_copy_field', 'dycore_exchange_bc',
     'dycore_continuity', 'dycore_momentum', 'dycore_momentum_prepare', 'dycore_uflx_tendency',
@@ -43,6 +44,7 @@ ABI_SYMBOLS = [
 ]
 
 _lib = None
+_lib_f32 = None
 _runtime_preloaded = None
 
 
@@ -75,19 +77,26 @@ def _one_hip_runtime():
         pass
 
 
-def load_library(path=None):
-    """Load libdycore_hip.so and declare its prototypes.  Raises if it is absent."""
-    global _lib
-    if _lib is not None and path is None:
-        return _lib
-    path = path or os.environ.get('DYCORE_LIB') or LIB_PATH   # DYCORE_LIB: A/B builds of the same ABI
+def load_library(path=None, dtype=np.float64):
+    """Load libdycore_hip.so (or, for dtype float32, libdycore_hip_f32.so) and declare its prototypes.
+    Raises if it is absent."""
+    global _lib, _lib_f32
+    f32 = np.dtype(dtype) == np.float32
+    if path is None:
+        if f32 and _lib_f32 is not None:
+            return _lib_f32
+        if not f32 and _lib is not None:
+            return _lib
+    cached = path is None
+    path = path or ((os.environ.get('DYCORE_LIB_F32') or LIB_PATH_F32) if f32 else
+                    (os.environ.get('DYCORE_LIB') or LIB_PATH))   # DYCORE_LIB: A/B builds of the same ABI
     if not os.path.exists(path):
         raise DycoreError('HIP extension not built: %s is missing (run __graft_entry__.build() '
                           'or `make -C climate_model_amd/csrc`); there is no CPU fallback' % path)
     _one_hip_runtime()
     lib = C.CDLL(path)
     hp = C.c_void_p
-    dp = C.POINTER(C.c_double)
+    dp = C.POINTER(C.c_float if f32 else C.c_double)        # dycore_real_t of that build
     lib.dycore_last_error.restype = C.c_char_p
     lib.dycore_create.argtypes = [C.POINTER(DycoreConfig), C.POINTER(hp)]
     lib.dycore_destroy.argtypes = [hp]
@@ -136,7 +145,14 @@ def load_library(path=None):
                                         C.POINTER(C.c_double)]
     if lib.dycore_abi_version() != ABI_VERSION:
         raise DycoreError('libdycore_hip.so ABI %d != binding ABI %d' % (lib.dycore_abi_version(), ABI_VERSION))
-    _lib = lib
+    if hasattr(lib, 'dycore_real_bytes') and lib.dycore_real_bytes() != (4 if f32 else 8):
+        raise DycoreError('%s holds %d-byte fields, asked for %s' % (path, lib.dycore_real_bytes(), np.dtype(dtype).name))
+    lib._real = C.c_float if f32 else C.c_double
+    if cached:
+        if f32:
+            _lib_f32 = lib
+        else:
+            _lib = lib
     return lib
 
 
@@ -148,8 +164,12 @@ class HipDycore:
     """One dycore handle = one GPU (or one latitude band of a decomposed grid)."""
 
     def __init__(self, nx, ny, nz, pair_top=10000., i_turb=0, i_radiation=0, device=0,
-                 ny_global=None, j_offset=0, stream=None, i_moist=0, i_moist_clip=0):
-        self.lib = load_library()
+                 ny_global=None, j_offset=0, stream=None, i_moist=0, i_moist_clip=0, dtype=np.float64):
+        self.dtype = np.dtype(dtype)
+        if self.dtype not in (np.dtype(np.float64), np.dtype(np.float32)):
+            raise ValueError("working precision is 'float64' or 'float32' (io_read_namelist.py:47-53)")
+        self.lib = load_library(dtype=self.dtype)
+        self._rp = C.POINTER(self.lib._real)
         self.nx, self.ny, self.nz = int(nx), int(ny), int(nz)
         cfg = DycoreConfig()
         cfg.abi_version = ABI_VERSION
@@ -192,9 +212,9 @@ class HipDycore:
     def set_grid(self, GRF):
         names = GRID_ARRAYS + (['moist_dif_coef'] if self.i_moist else [])
         for name in names:
-            a = np.ascontiguousarray(np.asarray(GRF[name], dtype=np.float64))
+            a = np.ascontiguousarray(np.asarray(GRF[name], dtype=self.dtype))
             shp = a.shape if a.ndim == 3 else (a.size, 1, 1)
-            self._check(self.lib.dycore_set_grid(self._h, name.encode(), a.ctypes.data_as(C.POINTER(C.c_double)),
+            self._check(self.lib.dycore_set_grid(self._h, name.encode(), a.ctypes.data_as(self._rp),
                                                  shp[0], shp[1], shp[2]))
 
     def has_field(self, name):
@@ -207,18 +227,18 @@ class HipDycore:
         return tuple(s)
 
     def upload(self, name, host):
-        a = np.ascontiguousarray(np.asarray(host, dtype=np.float64))
+        a = np.ascontiguousarray(np.asarray(host, dtype=self.dtype))
         if a.shape != self.field_shape(name):
             raise DycoreError('upload(%s): host shape %s != %s' % (name, a.shape, self.field_shape(name)))
-        self._check(self.lib.dycore_upload(self._h, name.encode(), a.ctypes.data_as(C.POINTER(C.c_double))))
+        self._check(self.lib.dycore_upload(self._h, name.encode(), a.ctypes.data_as(self._rp)))
 
     def download(self, name, out=None):
         shp = self.field_shape(name)
         if out is None:
-            out = np.empty(shp, dtype=np.float64)
-        if out.shape != shp or out.dtype != np.float64 or not out.flags.c_contiguous:
-            raise DycoreError('download(%s): need a C-contiguous float64 array of shape %s' % (name, shp))
-        self._check(self.lib.dycore_download(self._h, name.encode(), out.ctypes.data_as(C.POINTER(C.c_double))))
+            out = np.empty(shp, dtype=self.dtype)
+        if out.shape != shp or out.dtype != self.dtype or not out.flags.c_contiguous:
+            raise DycoreError('download(%s): need a C-contiguous %s array of shape %s' % (name, self.dtype.name, shp))
+        self._check(self.lib.dycore_download(self._h, name.encode(), out.ctypes.data_as(self._rp)))
         return out
 
     def field_ptr(self, name):

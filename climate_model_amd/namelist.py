@@ -68,8 +68,8 @@ class Namelist:
             raise NotImplementedError('nb > 1 not implemented (io_read_namelist.py:30-31)')
         if self.lon0_deg != 0 or self.lon1_deg != 360:
             raise NotImplementedError('only periodic longitude 0..360 (io_read_namelist.py:32-34)')
-        if self.working_precision != 'float64':
-            raise NotImplementedError('the HIP dycore computes in float64')
+        if self.working_precision not in ('float64', 'float32'):
+            raise ValueError("working_precision is 'float64' or 'float32' (io_read_namelist.py:47-53)")
         if bool(self.i_UVFLX_vert_turb) != bool(self.i_POTT_vert_turb):
             raise NotImplementedError('i_UVFLX_vert_turb and i_POTT_vert_turb must agree')
         if self.i_radiation:
@@ -78,6 +78,13 @@ class Namelist:
             self.moist_dif_coef = self.POTT_dif_coef
         if self.UVFLX_dif_coef is None:
             self.UVFLX_dif_coef = uvflx_dif_coef_for(self.dlat_deg)
+
+    @property
+    def wp(self):
+        """numpy dtype of the fields (io_read_namelist.py:47-53).  The grid constants are formed in float64 and cast
+        when they are handed to a float32 handle."""
+        import numpy as np
+        return np.dtype(self.working_precision)
 
     @property
     def i_turb(self):

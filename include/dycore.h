@@ -46,6 +46,17 @@ enum {
 
 typedef struct dycore dycore_t;
 
+/* Working precision of the fields (namelist.py:225-226 working_precision): one build of the library per precision --
+ * libdycore_hip.so (double, the reference's default and the parity mode) and libdycore_hip_f32.so (built with
+ * -DDYCORE_FLOAT32).  Host arrays cross the boundary in that type; scalar arguments are double in both.
+ * dycore_real_bytes() tells a binding which one it has loaded. */
+#ifdef DYCORE_FLOAT32
+typedef float dycore_real_t;
+#else
+typedef double dycore_real_t;
+#endif
+int dycore_real_bytes(void);
+
 /* Replaces the module-level globals the reference freezes into its kernels:
  * main_grid.py:42-51 (extents), namelist.py:62-88 (switches), pair_top. */
 typedef struct DycoreConfig {
@@ -79,7 +90,7 @@ int dycore_sync(dycore_t *h);
 /* name in {A,dxjs,dyis,corf,corf_is,lat_rad,lat_is_rad,dlon_rad,dlat_rad} with host
  * shape (n0,n1,1), or {sigma_vb,dsigma,UVFLX_dif_coef,POTT_dif_coef,moist_dif_coef} with
  * n0*n1*n2 = nz+1 / nz elements (moist_dif_coef is required only with i_moist). */
-int dycore_set_grid(dycore_t *h, const char *name, const double *host,
+int dycore_set_grid(dycore_t *h, const char *name, const dycore_real_t *host,
                     int32_t n0, int32_t n1, int32_t n2);
 
 /* ---- fields: main_fields.py:184-215 (copy_host_to_device / copy_device_to_host) ---- */
@@ -88,8 +99,8 @@ int dycore_set_grid(dycore_t *h, const char *name, const double *host,
  * group (main_fields.py:150-182) from what can actually be transferred */
 int dycore_has_field(dycore_t *h, const char *name);
 int dycore_field_shape(dycore_t *h, const char *name, int32_t shape[3]);
-int dycore_upload(dycore_t *h, const char *name, const double *host);
-int dycore_download(dycore_t *h, const char *name, double *host);   /* synchronises */
+int dycore_upload(dycore_t *h, const char *name, const dycore_real_t *host);
+int dycore_download(dycore_t *h, const char *name, dycore_real_t *host);   /* synchronises */
 /* raw device view for callers that keep data resident (torch, other kernels):
  * element (i,j,k) is dev[(k*rows + j)*pitch + i] */
 int dycore_field_ptr(dycore_t *h, const char *name, void **dev,

@@ -52,23 +52,23 @@ static int nthreads_of(const oracle_cfg *c) { (void)c; return 1; }
 
 /* ------------------------------------------------------------------------- */
 /* misc_boundaries.py:22-42 */
-void oracle_exchange_bc(const oracle_cfg *c, double *F, int stgx, int stgy, int nk)
+void oracle_exchange_bc(const oracle_cfg *c, real *F, int stgx, int stgy, int nk)
 {
     const int nx = c->nx, ny = c->ny;
     const int nxs = nx + 1, nys = ny + 1;
     const int fny = ny + 2 + stgy;
     const size_t col = (size_t)fny * nk;
     if (stgx) {
-        memcpy(F, F + (size_t)(nxs - 1) * col, col * sizeof(double));
-        memcpy(F + (size_t)nxs * col, F + 1 * col, col * sizeof(double));
-        memcpy(F + (size_t)(nxs + 1) * col, F + 2 * col, col * sizeof(double));
+        memcpy(F, F + (size_t)(nxs - 1) * col, col * sizeof(real));
+        memcpy(F + (size_t)nxs * col, F + 1 * col, col * sizeof(real));
+        memcpy(F + (size_t)(nxs + 1) * col, F + 2 * col, col * sizeof(real));
     } else {
-        memcpy(F, F + (size_t)nx * col, col * sizeof(double));
-        memcpy(F + (size_t)(nx + 1) * col, F + 1 * col, col * sizeof(double));
+        memcpy(F, F + (size_t)nx * col, col * sizeof(real));
+        memcpy(F + (size_t)(nx + 1) * col, F + 1 * col, col * sizeof(real));
     }
     const int fnx = nx + 2 + stgx;
     for (int i = 0; i < fnx; i++) {
-        double *Fi = F + (size_t)i * col;
+        real *Fi = F + (size_t)i * col;
         if (stgy) {
             const int rows[4] = {0, 1, nys, nys + 1};
             for (int r = 0; r < 4; r++)
@@ -92,29 +92,29 @@ void oracle_continuity(const oracle_cfg *c, const oracle_grid *g, oracle_fields 
     PAR_FOR
     for (int i = 1; i < nx + 1; i++) {
         for (int j = 1; j < ny + 1; j++) {
-            const double colp = A2(f->COLP, i, j);
-            const double c_im1 = A2(f->COLP, i - 1, j), c_ip1 = A2(f->COLP, i + 1, j);
-            const double c_jm1 = A2(f->COLP, i, j - 1), c_jp1 = A2(f->COLP, i, j + 1);
-            const double dy_i = AT(g->dyis, i, j, 0, 0, 1), dy_ip1 = AT(g->dyis, i + 1, j, 0, 0, 1);
-            const double dx_j = A2S(g->dxjs, i, j), dx_jp1 = A2S(g->dxjs, i, j + 1);
-            const double area = A2(g->A, i, j);
-            double sum = 0.0;
+            const real colp = A2(f->COLP, i, j);
+            const real c_im1 = A2(f->COLP, i - 1, j), c_ip1 = A2(f->COLP, i + 1, j);
+            const real c_jm1 = A2(f->COLP, i, j - 1), c_jp1 = A2(f->COLP, i, j + 1);
+            const real dy_i = AT(g->dyis, i, j, 0, 0, 1), dy_ip1 = AT(g->dyis, i + 1, j, 0, 0, 1);
+            const real dx_j = A2S(g->dxjs, i, j), dx_jp1 = A2S(g->dxjs, i, j + 1);
+            const real area = A2(g->A, i, j);
+            real sum = 0.0;
             for (int k = 0; k < nz; k++) {
-                const double uflx_i = (c_im1 + colp) / 2.0 * AT(f->UWIND, i, j, k, 0, nz) * dy_i;
-                const double uflx_ip1 = (colp + c_ip1) / 2.0 * AT(f->UWIND, i + 1, j, k, 0, nz) * dy_ip1;
-                const double vflx_j = (c_jm1 + colp) / 2.0 * AT(f->VWIND, i, j, k, 1, nz) * dx_j;
-                const double vflx_jp1 = (colp + c_jp1) / 2.0 * AT(f->VWIND, i, j + 1, k, 1, nz) * dx_jp1;
+                const real uflx_i = (c_im1 + colp) / 2.0 * AT(f->UWIND, i, j, k, 0, nz) * dy_i;
+                const real uflx_ip1 = (colp + c_ip1) / 2.0 * AT(f->UWIND, i + 1, j, k, 0, nz) * dy_ip1;
+                const real vflx_j = (c_jm1 + colp) / 2.0 * AT(f->VWIND, i, j, k, 1, nz) * dx_j;
+                const real vflx_jp1 = (colp + c_jp1) / 2.0 * AT(f->VWIND, i, j + 1, k, 1, nz) * dx_jp1;
                 AT(f->UFLX, i, j, k, 0, nz) = uflx_i;
                 AT(f->VFLX, i, j, k, 1, nz) = vflx_j;
-                const double div = (uflx_ip1 - uflx_i + vflx_jp1 - vflx_j) * g->dsigma[k] / area;
+                const real div = (uflx_ip1 - uflx_i + vflx_jp1 - vflx_j) * g->dsigma[k] / area;
                 AT(f->FLXDIV, i, j, k, 0, nz) = div;
                 sum += div;
             }
-            const double dcolpdt = -sum;                               /* :212 */
-            const double colp_new = A2(f->COLP_OLD, i, j) + dt * dcolpdt; /* :218 */
+            const real dcolpdt = -sum;                               /* :212 */
+            const real colp_new = A2(f->COLP_OLD, i, j) + dt * dcolpdt; /* :218 */
             A2(f->dCOLPdt, i, j) = dcolpdt;
             A2(f->COLP_NEW, i, j) = colp_new;
-            double run = AT(f->FLXDIV, i, j, 0, 0, nz);                /* :222-229 */
+            real run = AT(f->FLXDIV, i, j, 0, 0, nz);                /* :222-229 */
             for (int k = 1; k < nz; k++) {
                 AT(f->WWIND, i, j, k, 0, nzs) =
                     -run / colp_new - g->sigma_vb[k] * dcolpdt / colp_new;
@@ -140,22 +140,22 @@ void oracle_uvflx_prepare(const oracle_cfg *c, const oracle_grid *g, oracle_fiel
             const int lo = (j == 1), hi = (j == ny);
             for (int k = 1; k < nz; k++) {
                 /* products are formed as COLP_NEW*A*WWIND, doubled terms as 2*COLP_NEW*A*WWIND */
-                const double p_pp1_dm1 = A2(f->COLP_NEW, i - 1, j + 1) * A2(g->A, i - 1, j + 1) * AT(f->WWIND, i - 1, j + 1, k, 0, nzs);
-                const double p_pp1 = A2(f->COLP_NEW, i, j + 1) * A2(g->A, i, j + 1) * AT(f->WWIND, i, j + 1, k, 0, nzs);
-                const double p_pm1_dm1 = A2(f->COLP_NEW, i - 1, j - 1) * A2(g->A, i - 1, j - 1) * AT(f->WWIND, i - 1, j - 1, k, 0, nzs);
-                const double p_pm1 = A2(f->COLP_NEW, i, j - 1) * A2(g->A, i, j - 1) * AT(f->WWIND, i, j - 1, k, 0, nzs);
-                double s;
+                const real p_pp1_dm1 = A2(f->COLP_NEW, i - 1, j + 1) * A2(g->A, i - 1, j + 1) * AT(f->WWIND, i - 1, j + 1, k, 0, nzs);
+                const real p_pp1 = A2(f->COLP_NEW, i, j + 1) * A2(g->A, i, j + 1) * AT(f->WWIND, i, j + 1, k, 0, nzs);
+                const real p_pm1_dm1 = A2(f->COLP_NEW, i - 1, j - 1) * A2(g->A, i - 1, j - 1) * AT(f->WWIND, i - 1, j - 1, k, 0, nzs);
+                const real p_pm1 = A2(f->COLP_NEW, i, j - 1) * A2(g->A, i, j - 1) * AT(f->WWIND, i, j - 1, k, 0, nzs);
+                real s;
                 if (lo || hi) {
-                    const double p_dm1 = A2(f->COLP_NEW, i - 1, j) * A2(g->A, i - 1, j) * AT(f->WWIND, i - 1, j, k, 0, nzs);
-                    const double p_0 = A2(f->COLP_NEW, i, j) * A2(g->A, i, j) * AT(f->WWIND, i, j, k, 0, nzs);
+                    const real p_dm1 = A2(f->COLP_NEW, i - 1, j) * A2(g->A, i - 1, j) * AT(f->WWIND, i - 1, j, k, 0, nzs);
+                    const real p_0 = A2(f->COLP_NEW, i, j) * A2(g->A, i, j) * AT(f->WWIND, i, j, k, 0, nzs);
                     s = lo ? 0.25 * (p_pp1_dm1 + p_pp1 + p_dm1 + p_0)
                            : 0.25 * (p_dm1 + p_0 + p_pm1_dm1 + p_pm1);
                 } else {
-                    const double d_dm1 = 2.0 * A2(f->COLP_NEW, i - 1, j) * A2(g->A, i - 1, j) * AT(f->WWIND, i - 1, j, k, 0, nzs);
-                    const double d_0 = 2.0 * A2(f->COLP_NEW, i, j) * A2(g->A, i, j) * AT(f->WWIND, i, j, k, 0, nzs);
+                    const real d_dm1 = 2.0 * A2(f->COLP_NEW, i - 1, j) * A2(g->A, i - 1, j) * AT(f->WWIND, i - 1, j, k, 0, nzs);
+                    const real d_0 = 2.0 * A2(f->COLP_NEW, i, j) * A2(g->A, i, j) * AT(f->WWIND, i, j, k, 0, nzs);
                     s = 0.125 * (p_pp1_dm1 + p_pp1 + d_dm1 + d_0 + p_pm1_dm1 + p_pm1);
                 }
-                const double u_ks = (g->dsigma[k] * AT(f->UWIND, i, j, k - 1, 0, nz) +
+                const real u_ks = (g->dsigma[k] * AT(f->UWIND, i, j, k - 1, 0, nz) +
                                      g->dsigma[k - 1] * AT(f->UWIND, i, j, k, 0, nz)) /
                                     (g->dsigma[k] + g->dsigma[k - 1]);
                 AT(f->WWIND_UWIND, i, j, k, 0, nzs) = s * u_ks;
@@ -168,14 +168,14 @@ void oracle_uvflx_prepare(const oracle_cfg *c, const oracle_grid *g, oracle_fiel
             AT(f->WWIND_VWIND, i, j, 0, 1, nzs) = 0.0;
             AT(f->WWIND_VWIND, i, j, nz, 1, nzs) = 0.0;
             for (int k = 1; k < nz; k++) {
-                const double p_pp1_dm1 = A2(f->COLP_NEW, i + 1, j - 1) * A2(g->A, i + 1, j - 1) * AT(f->WWIND, i + 1, j - 1, k, 0, nzs);
-                const double p_pp1 = A2(f->COLP_NEW, i + 1, j) * A2(g->A, i + 1, j) * AT(f->WWIND, i + 1, j, k, 0, nzs);
-                const double d_dm1 = 2.0 * A2(f->COLP_NEW, i, j - 1) * A2(g->A, i, j - 1) * AT(f->WWIND, i, j - 1, k, 0, nzs);
-                const double d_0 = 2.0 * A2(f->COLP_NEW, i, j) * A2(g->A, i, j) * AT(f->WWIND, i, j, k, 0, nzs);
-                const double p_pm1_dm1 = A2(f->COLP_NEW, i - 1, j - 1) * A2(g->A, i - 1, j - 1) * AT(f->WWIND, i - 1, j - 1, k, 0, nzs);
-                const double p_pm1 = A2(f->COLP_NEW, i - 1, j) * A2(g->A, i - 1, j) * AT(f->WWIND, i - 1, j, k, 0, nzs);
-                const double s = 0.125 * (p_pp1_dm1 + p_pp1 + d_dm1 + d_0 + p_pm1_dm1 + p_pm1);
-                const double v_ks = (g->dsigma[k] * AT(f->VWIND, i, j, k - 1, 1, nz) +
+                const real p_pp1_dm1 = A2(f->COLP_NEW, i + 1, j - 1) * A2(g->A, i + 1, j - 1) * AT(f->WWIND, i + 1, j - 1, k, 0, nzs);
+                const real p_pp1 = A2(f->COLP_NEW, i + 1, j) * A2(g->A, i + 1, j) * AT(f->WWIND, i + 1, j, k, 0, nzs);
+                const real d_dm1 = 2.0 * A2(f->COLP_NEW, i, j - 1) * A2(g->A, i, j - 1) * AT(f->WWIND, i, j - 1, k, 0, nzs);
+                const real d_0 = 2.0 * A2(f->COLP_NEW, i, j) * A2(g->A, i, j) * AT(f->WWIND, i, j, k, 0, nzs);
+                const real p_pm1_dm1 = A2(f->COLP_NEW, i - 1, j - 1) * A2(g->A, i - 1, j - 1) * AT(f->WWIND, i - 1, j - 1, k, 0, nzs);
+                const real p_pm1 = A2(f->COLP_NEW, i - 1, j) * A2(g->A, i - 1, j) * AT(f->WWIND, i - 1, j, k, 0, nzs);
+                const real s = 0.125 * (p_pp1_dm1 + p_pp1 + d_dm1 + d_0 + p_pm1_dm1 + p_pm1);
+                const real v_ks = (g->dsigma[k] * AT(f->VWIND, i, j, k - 1, 1, nz) +
                                      g->dsigma[k - 1] * AT(f->VWIND, i, j, k, 1, nz)) /
                                     (g->dsigma[k] + g->dsigma[k - 1]);
                 AT(f->WWIND_VWIND, i, j, k, 1, nzs) = s * v_ks;
@@ -195,7 +195,7 @@ void oracle_uvflx_prepare(const oracle_cfg *c, const oracle_grid *g, oracle_fiel
                 AT(f->KMOM_dUWINDdz, i, j, nz, 0, nzs) = 0.0;
                 const int lo = (j == 1), hi = (j == ny);
                 for (int k = 1; k < nz; k++) {
-                    double cak, alt_km1, alt;
+                    real cak, alt_km1, alt;
                     if (lo) {
                         cak = 0.25 * (RK(i - 1, j + 1) + RK(i, j + 1) + RK(i - 1, j) + RK(i, j));
                         alt_km1 = 0.25 * (PH(i - 1, j + 1, k - 1) + PH(i, j + 1, k - 1) + PH(i - 1, j, k - 1) + PH(i, j, k - 1)) / CON_G;
@@ -209,7 +209,7 @@ void oracle_uvflx_prepare(const oracle_cfg *c, const oracle_grid *g, oracle_fiel
                         alt_km1 = 0.125 * (PH(i - 1, j + 1, k - 1) + PH(i, j + 1, k - 1) + 2.0 * PH(i - 1, j, k - 1) + 2.0 * PH(i, j, k - 1) + PH(i - 1, j - 1, k - 1) + PH(i, j - 1, k - 1)) / CON_G;
                         alt = 0.125 * (PH(i - 1, j + 1, k) + PH(i, j + 1, k) + 2.0 * PH(i - 1, j, k) + 2.0 * PH(i, j, k) + PH(i - 1, j - 1, k) + PH(i, j - 1, k)) / CON_G;
                     }
-                    const double dudz = (AT(f->UWIND, i, j, k - 1, 0, nz) - AT(f->UWIND, i, j, k, 0, nz)) / (alt_km1 - alt);
+                    const real dudz = (AT(f->UWIND, i, j, k - 1, 0, nz) - AT(f->UWIND, i, j, k, 0, nz)) / (alt_km1 - alt);
                     AT(f->KMOM_dUWINDdz, i, j, k, 0, nzs) = cak * dudz;
                 }
             }
@@ -219,10 +219,10 @@ void oracle_uvflx_prepare(const oracle_cfg *c, const oracle_grid *g, oracle_fiel
                 AT(f->KMOM_dVWINDdz, i, j, 0, 1, nzs) = 0.0;
                 AT(f->KMOM_dVWINDdz, i, j, nz, 1, nzs) = 0.0;
                 for (int k = 1; k < nz; k++) {
-                    const double cak = 0.125 * (RK(i + 1, j - 1) + RK(i + 1, j) + RK2(i, j - 1) + RK2(i, j) + RK(i - 1, j - 1) + RK(i - 1, j));
-                    const double alt_km1 = 0.125 * (PH(i + 1, j - 1, k - 1) + PH(i + 1, j, k - 1) + 2.0 * PH(i, j - 1, k - 1) + 2.0 * PH(i, j, k - 1) + PH(i - 1, j - 1, k - 1) + PH(i - 1, j, k - 1)) / CON_G;
-                    const double alt = 0.125 * (PH(i + 1, j - 1, k) + PH(i + 1, j, k) + 2.0 * PH(i, j - 1, k) + 2.0 * PH(i, j, k) + PH(i - 1, j - 1, k) + PH(i - 1, j, k)) / CON_G;
-                    const double dvdz = (AT(f->VWIND, i, j, k - 1, 1, nz) - AT(f->VWIND, i, j, k, 1, nz)) / (alt_km1 - alt);
+                    const real cak = 0.125 * (RK(i + 1, j - 1) + RK(i + 1, j) + RK2(i, j - 1) + RK2(i, j) + RK(i - 1, j - 1) + RK(i - 1, j));
+                    const real alt_km1 = 0.125 * (PH(i + 1, j - 1, k - 1) + PH(i + 1, j, k - 1) + 2.0 * PH(i, j - 1, k - 1) + 2.0 * PH(i, j, k - 1) + PH(i - 1, j - 1, k - 1) + PH(i - 1, j, k - 1)) / CON_G;
+                    const real alt = 0.125 * (PH(i + 1, j - 1, k) + PH(i + 1, j, k) + 2.0 * PH(i, j - 1, k) + 2.0 * PH(i, j, k) + PH(i - 1, j - 1, k) + PH(i - 1, j, k)) / CON_G;
+                    const real dvdz = (AT(f->VWIND, i, j, k - 1, 1, nz) - AT(f->VWIND, i, j, k, 1, nz)) / (alt_km1 - alt);
                     AT(f->KMOM_dVWINDdz, i, j, k, 1, nzs) = cak * dvdz;
                 }
             }
@@ -267,8 +267,8 @@ void oracle_uvflx_prepare(const oracle_cfg *c, const oracle_grid *g, oracle_fiel
 
 /* ------------------------------------------------------------------------- */
 /* dyn_functions.py:383-424 (note: divides by g itself) */
-static inline double var_ds(double v0, double v_dm1, double v_pm1, double v_pp1,
-                            double v_pm1_dm1, double v_pp1_dm1, int wall_lo, int wall_hi)
+static inline real var_ds(real v0, real v_dm1, real v_pm1, real v_pp1,
+                            real v_pm1_dm1, real v_pp1_dm1, int wall_lo, int wall_hi)
 {
     if (wall_lo) return 0.25 * (v_pp1_dm1 + v_pp1 + v_dm1 + v0) / CON_G;
     if (wall_hi) return 0.25 * (v_dm1 + v0 + v_pm1_dm1 + v_pm1) / CON_G;
@@ -276,11 +276,11 @@ static inline double var_ds(double v0, double v_dm1, double v_pm1, double v_pp1,
 }
 
 /* dyn_functions.py:177-207 */
-static inline double pre_grad(double phi, double phi_dm1, double colp, double colp_dm1,
-                              double pott, double pott_dm1, double pvtf, double pvtf_dm1,
-                              double pvtfvb, double pvtfvb_dm1, double pvtfvb_dm1_kp1,
-                              double pvtfvb_kp1, double dsig, double svb, double svb_kp1,
-                              double dgrid)
+static inline real pre_grad(real phi, real phi_dm1, real colp, real colp_dm1,
+                              real pott, real pott_dm1, real pvtf, real pvtf_dm1,
+                              real pvtfvb, real pvtfvb_dm1, real pvtfvb_dm1_kp1,
+                              real pvtfvb_kp1, real dsig, real svb, real svb_kp1,
+                              real dgrid)
 {
     return -dgrid * ((phi - phi_dm1) * (colp + colp_dm1) / 2.0 +
                      (colp - colp_dm1) * CON_CP / 2.0 *
@@ -300,24 +300,24 @@ void oracle_uflx_tendency(const oracle_cfg *c, const oracle_grid *g, oracle_fiel
     for (int i = 1; i < nx + 1; i++) {
         const int im1 = (i == 1) ? nx : i - 1;          /* :366-374 */
         for (int j = 1; j < ny + 1; j++) {
-            const double colp = A2(f->COLP, i, j), colp_im1 = A2(f->COLP, i - 1, j);
-            const double corf = AT(g->corf_is, i, j, 0, 0, 1), lat = AT(g->lat_is_rad, i, j, 0, 0, 1);
-            const double dlon = A2S(g->dlon_rad, i, j), dlat = AT(g->dlat_rad, i, j, 0, 0, 1);
-            const double dyis = AT(g->dyis, i, j, 0, 0, 1);
+            const real colp = A2(f->COLP, i, j), colp_im1 = A2(f->COLP, i - 1, j);
+            const real corf = AT(g->corf_is, i, j, 0, 0, 1), lat = AT(g->lat_is_rad, i, j, 0, 0, 1);
+            const real dlon = A2S(g->dlon_rad, i, j), dlat = AT(g->dlat_rad, i, j, 0, 0, 1);
+            const real dyis = AT(g->dyis, i, j, 0, 0, 1);
             const int lo = (j == 1), hi = (j == ny);
-            double smom_is = 0.0;
+            real smom_is = 0.0;
             if (c->i_turb)
                 smom_is = var_ds(A2(f->SMOMXFLX, i, j), A2(f->SMOMXFLX, i - 1, j), A2(f->SMOMXFLX, i, j - 1),
                                  A2(f->SMOMXFLX, i, j + 1), A2(f->SMOMXFLX, i - 1, j - 1), A2(f->SMOMXFLX, i - 1, j + 1), lo, hi);
             for (int k = 0; k < nz; k++) {
-                double bflx = AT(f->BFLX, i, j, k, 0, nz), bflx_im1 = AT(f->BFLX, im1, j, k, 0, nz);
-                double cflx = AT(f->CFLX, i, j, k, 1, nz), cflx_jp1 = AT(f->CFLX, i, j + 1, k, 1, nz);
-                double dflx_im1 = AT(f->DFLX, im1, j, k, 1, nz), dflx_jp1 = AT(f->DFLX, i, j + 1, k, 1, nz);
-                double eflx = AT(f->EFLX, i, j, k, 1, nz), eflx_im1_jp1 = AT(f->EFLX, im1, j + 1, k, 1, nz);
+                real bflx = AT(f->BFLX, i, j, k, 0, nz), bflx_im1 = AT(f->BFLX, im1, j, k, 0, nz);
+                real cflx = AT(f->CFLX, i, j, k, 1, nz), cflx_jp1 = AT(f->CFLX, i, j + 1, k, 1, nz);
+                real dflx_im1 = AT(f->DFLX, im1, j, k, 1, nz), dflx_jp1 = AT(f->DFLX, i, j + 1, k, 1, nz);
+                real eflx = AT(f->EFLX, i, j, k, 1, nz), eflx_im1_jp1 = AT(f->EFLX, im1, j + 1, k, 1, nz);
                 if (lo) { dflx_im1 = 0.0; cflx = 0.0; eflx = 0.0; }               /* :377-380 */
                 if (hi) { dflx_jp1 = 0.0; cflx_jp1 = 0.0; eflx_im1_jp1 = 0.0; }   /* :381-384 */
-                const double u = U(i, j);
-                double t = 0.0;
+                const real u = U(i, j);
+                real t = 0.0;
                 /* horizontal advection, dyn_functions.py:541-572, sign +1 */
                 t = t + (+bflx_im1 * (U(i - 1, j) + u) / 2.0 - bflx * (u + U(i + 1, j)) / 2.0
                          + cflx * (U(i, j - 1) + u) / 2.0 - cflx_jp1 * (u + U(i, j + 1)) / 2.0
@@ -330,11 +330,11 @@ void oracle_uflx_tendency(const oracle_cfg *c, const oracle_grid *g, oracle_fiel
                 if (c->i_turb) {
 #define PV(ii, jj, kk) AT(f->PHIVB, ii, jj, kk, 0, nzs)
 #define RH(ii, jj) AT(f->RHO, ii, jj, k, 0, nz)
-                    const double altvb = var_ds(PV(i, j, k), PV(i - 1, j, k), PV(i, j - 1, k), PV(i, j + 1, k), PV(i - 1, j - 1, k), PV(i - 1, j + 1, k), lo, hi) / CON_G;
-                    const double altvb_kp1 = var_ds(PV(i, j, k + 1), PV(i - 1, j, k + 1), PV(i, j - 1, k + 1), PV(i, j + 1, k + 1), PV(i - 1, j - 1, k + 1), PV(i - 1, j + 1, k + 1), lo, hi) / CON_G;
-                    const double rho_is = var_ds(RH(i, j), RH(i - 1, j), RH(i, j - 1), RH(i, j + 1), RH(i - 1, j - 1), RH(i - 1, j + 1), lo, hi);
-                    const double kd = AT(f->KMOM_dUWINDdz, i, j, k, 0, nzs), kd_kp1 = AT(f->KMOM_dUWINDdz, i, j, k + 1, 0, nzs);
-                    double turb;
+                    const real altvb = var_ds(PV(i, j, k), PV(i - 1, j, k), PV(i, j - 1, k), PV(i, j + 1, k), PV(i - 1, j - 1, k), PV(i - 1, j + 1, k), lo, hi) / CON_G;
+                    const real altvb_kp1 = var_ds(PV(i, j, k + 1), PV(i - 1, j, k + 1), PV(i, j - 1, k + 1), PV(i, j + 1, k + 1), PV(i - 1, j - 1, k + 1), PV(i - 1, j + 1, k + 1), lo, hi) / CON_G;
+                    const real rho_is = var_ds(RH(i, j), RH(i - 1, j), RH(i, j - 1), RH(i, j + 1), RH(i - 1, j - 1), RH(i - 1, j + 1), lo, hi);
+                    const real kd = AT(f->KMOM_dUWINDdz, i, j, k, 0, nzs), kd_kp1 = AT(f->KMOM_dUWINDdz, i, j, k + 1, 0, nzs);
+                    real turb;
                     if (k == 0) turb = (0.0 - kd_kp1) / ((altvb - altvb_kp1) * rho_is);
                     else if (k == nz - 1) turb = (kd + smom_is) / ((altvb - altvb_kp1) * rho_is);
                     else turb = (kd - kd_kp1) / ((altvb - altvb_kp1) * rho_is);
@@ -384,22 +384,22 @@ void oracle_vflx_tendency(const oracle_cfg *c, const oracle_grid *g, oracle_fiel
     for (int i = 1; i < nx + 1; i++) {
         const int ip1 = (i == nx) ? 1 : i + 1;          /* :349-356 */
         for (int j = 2; j < ny + 1; j++) {
-            const double colp = A2(f->COLP, i, j), colp_jm1 = A2(f->COLP, i, j - 1);
-            const double corf = A2(g->corf, i, j), corf_jm1 = A2(g->corf, i, j - 1);
-            const double lat = A2(g->lat_rad, i, j), lat_jm1 = A2(g->lat_rad, i, j - 1);
-            const double dlon = A2S(g->dlon_rad, i, j), dlat = AT(g->dlat_rad, i, j, 0, 0, 1);
-            const double dxjs = A2S(g->dxjs, i, j);
-            double smom_js = 0.0;
+            const real colp = A2(f->COLP, i, j), colp_jm1 = A2(f->COLP, i, j - 1);
+            const real corf = A2(g->corf, i, j), corf_jm1 = A2(g->corf, i, j - 1);
+            const real lat = A2(g->lat_rad, i, j), lat_jm1 = A2(g->lat_rad, i, j - 1);
+            const real dlon = A2S(g->dlon_rad, i, j), dlat = AT(g->dlat_rad, i, j, 0, 0, 1);
+            const real dxjs = A2S(g->dxjs, i, j);
+            real smom_js = 0.0;
             if (c->i_turb)
                 smom_js = var_ds(A2(f->SMOMYFLX, i, j), A2(f->SMOMYFLX, i, j - 1), A2(f->SMOMYFLX, i - 1, j),
                                  A2(f->SMOMYFLX, i + 1, j), A2(f->SMOMYFLX, i - 1, j - 1), A2(f->SMOMYFLX, i + 1, j - 1), 0, 0);
             for (int k = 0; k < nz; k++) {
-                const double rflx = AT(f->RFLX, i, j, k, 0, nz), rflx_jm1 = AT(f->RFLX, i, j - 1, k, 0, nz);
-                const double qflx = AT(f->QFLX, i, j, k, 1, nz), qflx_ip1 = AT(f->QFLX, ip1, j, k, 1, nz);
-                const double sflx_jm1 = AT(f->SFLX, i, j - 1, k, 0, nz), sflx_ip1 = AT(f->SFLX, ip1, j, k, 0, nz);
-                const double tflx = AT(f->TFLX, i, j, k, 0, nz), tflx_ip1_jm1 = AT(f->TFLX, ip1, j - 1, k, 0, nz);
-                const double v = V(i, j);
-                double t = 0.0;
+                const real rflx = AT(f->RFLX, i, j, k, 0, nz), rflx_jm1 = AT(f->RFLX, i, j - 1, k, 0, nz);
+                const real qflx = AT(f->QFLX, i, j, k, 1, nz), qflx_ip1 = AT(f->QFLX, ip1, j, k, 1, nz);
+                const real sflx_jm1 = AT(f->SFLX, i, j - 1, k, 0, nz), sflx_ip1 = AT(f->SFLX, ip1, j, k, 0, nz);
+                const real tflx = AT(f->TFLX, i, j, k, 0, nz), tflx_ip1_jm1 = AT(f->TFLX, ip1, j - 1, k, 0, nz);
+                const real v = V(i, j);
+                real t = 0.0;
                 /* horizontal advection, sign -1 on the T term */
                 t = t + (+rflx_jm1 * (V(i, j - 1) + v) / 2.0 - rflx * (v + V(i, j + 1)) / 2.0
                          + qflx * (V(i - 1, j) + v) / 2.0 - qflx_ip1 * (v + V(i + 1, j)) / 2.0
@@ -409,11 +409,11 @@ void oracle_vflx_tendency(const oracle_cfg *c, const oracle_grid *g, oracle_fiel
                 if (c->i_turb) {
 #define PV(ii, jj, kk) AT(f->PHIVB, ii, jj, kk, 0, nzs)
 #define RH(ii, jj) AT(f->RHO, ii, jj, k, 0, nz)
-                    const double altvb = var_ds(PV(i, j, k), PV(i, j - 1, k), PV(i - 1, j, k), PV(i + 1, j, k), PV(i - 1, j - 1, k), PV(i + 1, j - 1, k), 0, 0) / CON_G;
-                    const double altvb_kp1 = var_ds(PV(i, j, k + 1), PV(i, j - 1, k + 1), PV(i - 1, j, k + 1), PV(i + 1, j, k + 1), PV(i - 1, j - 1, k + 1), PV(i + 1, j - 1, k + 1), 0, 0) / CON_G;
-                    const double rho_js = var_ds(RH(i, j), RH(i, j - 1), RH(i - 1, j), RH(i + 1, j), RH(i - 1, j - 1), RH(i + 1, j - 1), 0, 0);
-                    const double kd = AT(f->KMOM_dVWINDdz, i, j, k, 1, nzs), kd_kp1 = AT(f->KMOM_dVWINDdz, i, j, k + 1, 1, nzs);
-                    double turb;
+                    const real altvb = var_ds(PV(i, j, k), PV(i, j - 1, k), PV(i - 1, j, k), PV(i + 1, j, k), PV(i - 1, j - 1, k), PV(i + 1, j - 1, k), 0, 0) / CON_G;
+                    const real altvb_kp1 = var_ds(PV(i, j, k + 1), PV(i, j - 1, k + 1), PV(i - 1, j, k + 1), PV(i + 1, j, k + 1), PV(i - 1, j - 1, k + 1), PV(i + 1, j - 1, k + 1), 0, 0) / CON_G;
+                    const real rho_js = var_ds(RH(i, j), RH(i, j - 1), RH(i - 1, j), RH(i + 1, j), RH(i - 1, j - 1), RH(i + 1, j - 1), 0, 0);
+                    const real kd = AT(f->KMOM_dVWINDdz, i, j, k, 1, nzs), kd_kp1 = AT(f->KMOM_dVWINDdz, i, j, k + 1, 1, nzs);
+                    real turb;
                     if (k == 0) turb = (0.0 - kd_kp1) / ((altvb - altvb_kp1) * rho_js);
                     else if (k == nz - 1) turb = (kd + smom_js) / ((altvb - altvb_kp1) * rho_js);
                     else turb = (kd - kd_kp1) / ((altvb - altvb_kp1) * rho_js);
@@ -458,13 +458,13 @@ void oracle_pott_tendency(const oracle_cfg *c, const oracle_grid *g, oracle_fiel
     PAR_FOR
     for (int i = 1; i < nx + 1; i++)
         for (int j = 1; j < ny + 1; j++) {
-            const double colp = A2(f->COLP, i, j), colp_new = A2(f->COLP_NEW, i, j);
-            const double c_im1 = A2(f->COLP, i - 1, j), c_ip1 = A2(f->COLP, i + 1, j);
-            const double c_jm1 = A2(f->COLP, i, j - 1), c_jp1 = A2(f->COLP, i, j + 1);
-            const double area = A2(g->A, i, j);
+            const real colp = A2(f->COLP, i, j), colp_new = A2(f->COLP_NEW, i, j);
+            const real c_im1 = A2(f->COLP, i - 1, j), c_ip1 = A2(f->COLP, i + 1, j);
+            const real c_jm1 = A2(f->COLP, i, j - 1), c_jp1 = A2(f->COLP, i, j + 1);
+            const real area = A2(g->A, i, j);
             for (int k = 0; k < nz; k++) {
-                const double p = P(i, j, k);
-                double t = 0.0;
+                const real p = P(i, j, k);
+                real t = 0.0;
                 /* hor_adv_py, dyn_functions.py:105-114 */
                 t = t + (+AT(f->UFLX, i, j, k, 0, nz) * (P(i - 1, j, k) + p) / 2.0
                          - AT(f->UFLX, i + 1, j, k, 0, nz) * (p + P(i + 1, j, k)) / 2.0
@@ -472,7 +472,7 @@ void oracle_pott_tendency(const oracle_cfg *c, const oracle_grid *g, oracle_fiel
                          - AT(f->VFLX, i, j + 1, k, 1, nz) * (p + P(i, j + 1, k)) / 2.0) / area;
                 /* vert_adv_py, dyn_functions.py:118-138 */
                 {
-                    const double w_kp1 = AT(f->WWIND, i, j, k + 1, 0, nzs), pvb_kp1 = AT(f->POTTVB, i, j, k + 1, 0, nzs);
+                    const real w_kp1 = AT(f->WWIND, i, j, k + 1, 0, nzs), pvb_kp1 = AT(f->POTTVB, i, j, k + 1, 0, nzs);
                     if (k == 0)
                         t = t + colp_new * (-w_kp1 * pvb_kp1) / g->dsigma[k];
                     else
@@ -480,22 +480,22 @@ void oracle_pott_tendency(const oracle_cfg *c, const oracle_grid *g, oracle_fiel
                 }
                 /* turb_flux_tendency_py, dyn_functions.py:26-67 */
                 if (c->i_turb) {
-                    const double alt = AT(f->PHI, i, j, k, 0, nz) / CON_G;
-                    const double altvb = AT(f->PHIVB, i, j, k, 0, nzs) / CON_G, altvb_kp1 = AT(f->PHIVB, i, j, k + 1, 0, nzs) / CON_G;
-                    const double rho = AT(f->RHO, i, j, k, 0, nz);
-                    const double surf = A2(f->SSHFLX, i, j) / CON_CP;
-                    double turb;
+                    const real alt = AT(f->PHI, i, j, k, 0, nz) / CON_G;
+                    const real altvb = AT(f->PHIVB, i, j, k, 0, nzs) / CON_G, altvb_kp1 = AT(f->PHIVB, i, j, k + 1, 0, nzs) / CON_G;
+                    const real rho = AT(f->RHO, i, j, k, 0, nz);
+                    const real surf = A2(f->SSHFLX, i, j) / CON_CP;
+                    real turb;
                     if (k == 0) {
-                        const double alt_kp1 = AT(f->PHI, i, j, k + 1, 0, nz) / CON_G;
+                        const real alt_kp1 = AT(f->PHI, i, j, k + 1, 0, nz) / CON_G;
                         turb = colp * ((+0.0 - ((p - P(i, j, k + 1)) / (alt - alt_kp1) * AT(f->RHOVB, i, j, k + 1, 0, nzs) * AT(f->KHEAT, i, j, k + 1, 0, nzs))) /
                                        ((altvb - altvb_kp1) * rho));
                     } else if (k == nz - 1) {
-                        const double alt_km1 = AT(f->PHI, i, j, k - 1, 0, nz) / CON_G;
+                        const real alt_km1 = AT(f->PHI, i, j, k - 1, 0, nz) / CON_G;
                         turb = colp * ((+((P(i, j, k - 1) - p) / (alt_km1 - alt) * AT(f->RHOVB, i, j, k, 0, nzs) * AT(f->KHEAT, i, j, k, 0, nzs)) + surf) /
                                        ((altvb - altvb_kp1) * rho));
                     } else {
-                        const double alt_kp1 = AT(f->PHI, i, j, k + 1, 0, nz) / CON_G;
-                        const double alt_km1 = AT(f->PHI, i, j, k - 1, 0, nz) / CON_G;
+                        const real alt_kp1 = AT(f->PHI, i, j, k + 1, 0, nz) / CON_G;
+                        const real alt_km1 = AT(f->PHI, i, j, k - 1, 0, nz) / CON_G;
                         turb = colp * ((+((P(i, j, k - 1) - p) / (alt_km1 - alt) * AT(f->RHOVB, i, j, k, 0, nzs) * AT(f->KHEAT, i, j, k, 0, nzs))
                                         - ((p - P(i, j, k + 1)) / (alt - alt_kp1) * AT(f->RHOVB, i, j, k + 1, 0, nzs) * AT(f->KHEAT, i, j, k + 1, 0, nzs))) /
                                        ((altvb - altvb_kp1) * rho));
@@ -518,9 +518,9 @@ void oracle_pott_tendency(const oracle_cfg *c, const oracle_grid *g, oracle_fiel
 /* ------------------------------------------------------------------------- */
 /* dyn_functions.py:70-95: interface value by logarithmic interpolation.  max(VAR, min_val)
  * is Python's: the first argument unless the second is greater. */
-static inline double varvb_log(double var, double var_km1)
+static inline real varvb_log(real var, real var_km1)
 {
-    const double min_val = 0.0000001;
+    const real min_val = 0.0000001;
     if (min_val > var) var = min_val;
     if (min_val > var_km1) var_km1 = min_val;
     if (var_km1 == var) return var;
@@ -528,13 +528,13 @@ static inline double varvb_log(double var, double var_km1)
 }
 
 /* dyn_functions.py:26-67 */
-static inline double turb_flux_tendency(double phi, double phi_kp1, double phi_km1, double phivb,
-                                        double phivb_kp1, double var, double var_kp1, double var_km1,
-                                        double kvar, double kvar_kp1, double rho, double rhovb,
-                                        double rhovb_kp1, double colp, double surf_flux, int k, int nz)
+static inline real turb_flux_tendency(real phi, real phi_kp1, real phi_km1, real phivb,
+                                        real phivb_kp1, real var, real var_kp1, real var_km1,
+                                        real kvar, real kvar_kp1, real rho, real rhovb,
+                                        real rhovb_kp1, real colp, real surf_flux, int k, int nz)
 {
-    const double alt = phi / CON_G, alt_kp1 = phi_kp1 / CON_G, alt_km1 = phi_km1 / CON_G;
-    const double altvb = phivb / CON_G, altvb_kp1 = phivb_kp1 / CON_G;
+    const real alt = phi / CON_G, alt_kp1 = phi_kp1 / CON_G, alt_km1 = phi_km1 / CON_G;
+    const real altvb = phivb / CON_G, altvb_kp1 = phivb_kp1 / CON_G;
     if (k == 0)
         return colp * ((+0.0 - ((var - var_kp1) / (alt - alt_kp1) * rhovb_kp1 * kvar_kp1)) / ((altvb - altvb_kp1) * rho));
     if (k == nz - 1)
@@ -557,29 +557,29 @@ void oracle_moist_tendency(const oracle_cfg *c, const oracle_grid *g, oracle_fie
     PAR_FOR
     for (int i = 1; i < nx + 1; i++)
         for (int j = 1; j < ny + 1; j++) {
-            const double colp = A2(f->COLP, i, j), colp_new = A2(f->COLP_NEW, i, j);
-            const double c_im1 = A2(f->COLP, i - 1, j), c_ip1 = A2(f->COLP, i + 1, j);
-            const double c_jm1 = A2(f->COLP, i, j - 1), c_jp1 = A2(f->COLP, i, j + 1);
-            const double area = A2(g->A, i, j);
+            const real colp = A2(f->COLP, i, j), colp_new = A2(f->COLP_NEW, i, j);
+            const real c_im1 = A2(f->COLP, i - 1, j), c_ip1 = A2(f->COLP, i + 1, j);
+            const real c_jm1 = A2(f->COLP, i, j - 1), c_jp1 = A2(f->COLP, i, j + 1);
+            const real area = A2(g->A, i, j);
             for (int k = 0; k < nz; k++) {
-                const double uflx = AT(f->UFLX, i, j, k, 0, nz), uflx_ip1 = AT(f->UFLX, i + 1, j, k, 0, nz);
-                const double vflx = AT(f->VFLX, i, j, k, 1, nz), vflx_jp1 = AT(f->VFLX, i, j + 1, k, 1, nz);
-                const double w = AT(f->WWIND, i, j, k, 0, nzs), w_kp1 = AT(f->WWIND, i, j, k + 1, 0, nzs);
-                const double ds = g->dsigma[k], dif = g->moist_dif_coef[k];
-                double t[2];
-                double turb_qv = 0.0;
+                const real uflx = AT(f->UFLX, i, j, k, 0, nz), uflx_ip1 = AT(f->UFLX, i + 1, j, k, 0, nz);
+                const real vflx = AT(f->VFLX, i, j, k, 1, nz), vflx_jp1 = AT(f->VFLX, i, j + 1, k, 1, nz);
+                const real w = AT(f->WWIND, i, j, k, 0, nzs), w_kp1 = AT(f->WWIND, i, j, k + 1, 0, nzs);
+                const real ds = g->dsigma[k], dif = g->moist_dif_coef[k];
+                real t[2];
+                real turb_qv = 0.0;
                 for (int s = 0; s < 2; s++) {
-                    double *Q = s == 0 ? f->QV : f->QC;
+                    real *Q = s == 0 ? f->QV : f->QC;
 #define QA(ii, jj, kk) AT(Q, ii, jj, kk, 0, nz)
-                    const double q = QA(i, j, k);
-                    const double q_im1 = QA(i - 1, j, k), q_ip1 = QA(i + 1, j, k), q_jm1 = QA(i, j - 1, k), q_jp1 = QA(i, j + 1, k);
-                    double d = 0.0;
+                    const real q = QA(i, j, k);
+                    const real q_im1 = QA(i - 1, j, k), q_ip1 = QA(i + 1, j, k), q_jm1 = QA(i, j - 1, k), q_jp1 = QA(i, j + 1, k);
+                    real d = 0.0;
                     /* hor_adv_py */
                     d = d + (+uflx * (q_im1 + q) / 2.0 - uflx_ip1 * (q + q_ip1) / 2.0
                              + vflx * (q_jm1 + q) / 2.0 - vflx_jp1 * (q + q_jp1) / 2.0) / area;
                     /* vertical advection with log-interpolated interface values */
                     {
-                        double flux_kp1 = 0.0;                           /* W[nz] * (unchecked read) = 0 */
+                        real flux_kp1 = 0.0;                           /* W[nz] * (unchecked read) = 0 */
                         if (k < nz - 1) flux_kp1 = w_kp1 * varvb_log(QA(i, j, k + 1), q);
                         if (k == 0)
                             d = d + colp_new * (-flux_kp1) / ds;
@@ -587,8 +587,8 @@ void oracle_moist_tendency(const oracle_cfg *c, const oracle_grid *g, oracle_fie
                             d = d + colp_new * (+w * varvb_log(q, QA(i, j, k - 1)) - flux_kp1) / ds;
                     }
                     if (c->i_turb) {
-                        const double surf = s == 0 ? A2(f->SLHFLX, i, j) / CON_LH : 0.0;
-                        const double tb = turb_flux_tendency(
+                        const real surf = s == 0 ? A2(f->SLHFLX, i, j) / CON_LH : 0.0;
+                        const real tb = turb_flux_tendency(
                             AT(f->PHI, i, j, k, 0, nz), k < nz - 1 ? AT(f->PHI, i, j, k + 1, 0, nz) : 0.0,
                             k > 0 ? AT(f->PHI, i, j, k - 1, 0, nz) : 0.0,
                             AT(f->PHIVB, i, j, k, 0, nzs), AT(f->PHIVB, i, j, k + 1, 0, nzs),
@@ -625,7 +625,7 @@ void oracle_make_timestep(const oracle_cfg *c, const oracle_grid *g, oracle_fiel
         for (int j = 1; j < ny + 2; j++) {
             if (i < nx + 1 && j < ny + 1) {   /* UWIND: is in [1,nx], j in [1,ny]; column nx+1 is the
                                                  periodic duplicate refreshed by exchange_BC */
-                double ca, ca_old;
+                real ca, ca_old;
                 if (j == 1) {
                     ca = 1.0 / 4.0 * (CN(i - 1, j + 1) * AR(i - 1, j + 1) + CN(i, j + 1) * AR(i, j + 1) + CN(i - 1, j) * AR(i - 1, j) + CN(i, j) * AR(i, j));
                     ca_old = 1.0 / 4.0 * (CO(i - 1, j + 1) * AR(i - 1, j + 1) + CO(i, j + 1) * AR(i, j + 1) + CO(i - 1, j) * AR(i - 1, j) + CO(i, j) * AR(i, j));
@@ -640,13 +640,13 @@ void oracle_make_timestep(const oracle_cfg *c, const oracle_grid *g, oracle_fiel
                     AT(f->UWIND, i, j, k, 0, nz) = AT(f->UWIND_OLD, i, j, k, 0, nz) * ca_old / ca + dt * AT(f->dUFLXdt, i, j, k, 0, nz) / ca;
             }
             if (i < nx + 1 && j > 1 && j < ny + 1) {   /* VWIND: js in [2,ny] (poles are zeroed by exchange_BC) */
-                const double ca = 1.0 / 8.0 * (CN(i + 1, j - 1) * AR(i + 1, j - 1) + CN(i + 1, j) * AR(i + 1, j) + 2.0 * CN(i, j - 1) * AR(i, j - 1) + 2.0 * CN(i, j) * AR(i, j) + CN(i - 1, j - 1) * AR(i - 1, j - 1) + CN(i - 1, j) * AR(i - 1, j));
-                const double ca_old = 1.0 / 8.0 * (CO(i + 1, j - 1) * AR(i + 1, j - 1) + CO(i + 1, j) * AR(i + 1, j) + 2.0 * CO(i, j - 1) * AR(i, j - 1) + 2.0 * CO(i, j) * AR(i, j) + CO(i - 1, j - 1) * AR(i - 1, j - 1) + CO(i - 1, j) * AR(i - 1, j));
+                const real ca = 1.0 / 8.0 * (CN(i + 1, j - 1) * AR(i + 1, j - 1) + CN(i + 1, j) * AR(i + 1, j) + 2.0 * CN(i, j - 1) * AR(i, j - 1) + 2.0 * CN(i, j) * AR(i, j) + CN(i - 1, j - 1) * AR(i - 1, j - 1) + CN(i - 1, j) * AR(i - 1, j));
+                const real ca_old = 1.0 / 8.0 * (CO(i + 1, j - 1) * AR(i + 1, j - 1) + CO(i + 1, j) * AR(i + 1, j) + 2.0 * CO(i, j - 1) * AR(i, j - 1) + 2.0 * CO(i, j) * AR(i, j) + CO(i - 1, j - 1) * AR(i - 1, j - 1) + CO(i - 1, j) * AR(i - 1, j));
                 for (int k = 0; k < nz; k++)
                     AT(f->VWIND, i, j, k, 1, nz) = AT(f->VWIND_OLD, i, j, k, 1, nz) * ca_old / ca + dt * AT(f->dVFLXdt, i, j, k, 1, nz) / ca;
             }
             if (i < nx + 1 && j < ny + 1) {
-                const double cn = CN(i, j), co = CO(i, j);
+                const real cn = CN(i, j), co = CO(i, j);
                 for (int k = 0; k < nz; k++)
                     AT(f->POTT, i, j, k, 0, nz) = AT(f->POTT_OLD, i, j, k, 0, nz) * co / cn + dt * AT(f->dPOTTdt, i, j, k, 0, nz) / cn;
                 if (c->i_moist)   /* no clipping of QV/QC on the CPU path (dyn_timestep.py:291-296) */
@@ -675,10 +675,10 @@ void oracle_diag_pvtf(const oracle_cfg *c, const oracle_grid *g, oracle_fields *
     PAR_FOR
     for (int i = 0; i < nx + 2; i++)
         for (int j = 0; j < ny + 2; j++) {
-            const double colp = A2(f->COLP, i, j);
+            const real colp = A2(f->COLP, i, j);
             for (int k = 0; k < nz; k++) {
-                const double p_km12 = c->pair_top + g->sigma_vb[k] * colp;
-                const double p_kp12 = c->pair_top + g->sigma_vb[k + 1] * colp;
+                const real p_km12 = c->pair_top + g->sigma_vb[k] * colp;
+                const real p_kp12 = c->pair_top + g->sigma_vb[k + 1] * colp;
                 AT(f->PVTF, i, j, k, 0, nz) = 1.0 / (1.0 + CON_KAPPA) *
                     (pow(p_kp12 / 100000.0, CON_KAPPA) * p_kp12 - pow(p_km12 / 100000.0, CON_KAPPA) * p_km12) / (p_kp12 - p_km12);
                 AT(f->PVTFVB, i, j, k, 0, nzs) = pow(p_km12 / 100000.0, CON_KAPPA);
@@ -698,8 +698,8 @@ void oracle_diag_phi(const oracle_cfg *c, oracle_fields *f)
         for (int j = 0; j < ny + 2; j++) {
             AT(f->PHIVB, i, j, nz, 0, nzs) = A2(f->HSURF, i, j) * CON_G;
             for (int k = nz - 1; k >= 0; k--) {
-                const double pott = AT(f->POTT, i, j, k, 0, nz), pvtf = AT(f->PVTF, i, j, k, 0, nz);
-                const double phi = AT(f->PHIVB, i, j, k + 1, 0, nzs) - CON_CP * (pott * (pvtf - AT(f->PVTFVB, i, j, k + 1, 0, nzs)));
+                const real pott = AT(f->POTT, i, j, k, 0, nz), pvtf = AT(f->PVTF, i, j, k, 0, nz);
+                const real phi = AT(f->PHIVB, i, j, k + 1, 0, nzs) - CON_CP * (pott * (pvtf - AT(f->PVTFVB, i, j, k + 1, 0, nzs)));
                 AT(f->PHI, i, j, k, 0, nz) = phi;
                 AT(f->PHIVB, i, j, k, 0, nzs) = phi - CON_CP * (pott * (AT(f->PVTFVB, i, j, k, 0, nzs) - pvtf));
             }
@@ -716,7 +716,7 @@ void oracle_diag_pottvb(const oracle_cfg *c, oracle_fields *f)
     for (int i = 0; i < nx + 2; i++)
         for (int j = 0; j < ny + 2; j++)
             for (int k = 1; k < nzs - 1; k++) {
-                const double v = (+(AT(f->PVTFVB, i, j, k, 0, nzs) - AT(f->PVTF, i, j, k - 1, 0, nz)) * AT(f->POTT, i, j, k - 1, 0, nz)
+                const real v = (+(AT(f->PVTFVB, i, j, k, 0, nzs) - AT(f->PVTF, i, j, k - 1, 0, nz)) * AT(f->POTT, i, j, k - 1, 0, nz)
                                   + (AT(f->PVTF, i, j, k, 0, nz) - AT(f->PVTFVB, i, j, k, 0, nzs)) * AT(f->POTT, i, j, k, 0, nz)) /
                                  (AT(f->PVTF, i, j, k, 0, nz) - AT(f->PVTF, i, j, k - 1, 0, nz));
                 AT(f->POTTVB, i, j, k, 0, nzs) = v;
@@ -737,13 +737,13 @@ void oracle_diag_rho(const oracle_cfg *c, oracle_fields *f)
     for (int i = 0; i < nx + 2; i++)
         for (int j = 0; j < ny + 2; j++) {
             for (int k = 0; k < nzs; k++) {
-                const double pairvb = 100000.0 * pow(AT(f->PVTFVB, i, j, k, 0, nzs), 1.0 / CON_KAPPA);
-                const double tairvb = AT(f->POTTVB, i, j, k, 0, nzs) * AT(f->PVTFVB, i, j, k, 0, nzs);
+                const real pairvb = 100000.0 * pow(AT(f->PVTFVB, i, j, k, 0, nzs), 1.0 / CON_KAPPA);
+                const real tairvb = AT(f->POTTVB, i, j, k, 0, nzs) * AT(f->PVTFVB, i, j, k, 0, nzs);
                 AT(f->RHOVB, i, j, k, 0, nzs) = pairvb / (CON_RD * tairvb);
             }
             for (int k = 0; k < nz; k++) {
-                const double tair = AT(f->POTT, i, j, k, 0, nz) * AT(f->PVTF, i, j, k, 0, nz);
-                const double pair = 100000.0 * pow(AT(f->PVTF, i, j, k, 0, nz), 1.0 / CON_KAPPA);
+                const real tair = AT(f->POTT, i, j, k, 0, nz) * AT(f->PVTF, i, j, k, 0, nz);
+                const real pair = 100000.0 * pow(AT(f->PVTF, i, j, k, 0, nz), 1.0 / CON_KAPPA);
                 AT(f->RHO, i, j, k, 0, nz) = pair / (CON_RD * tair);
             }
         }
@@ -760,20 +760,20 @@ void oracle_diag_secondary(const oracle_cfg *c, oracle_fields *f)
     for (int i = 0; i < nx + 2; i++)
         for (int j = 0; j < ny + 2; j++) {
             for (int k = 0; k < nzs; k++) {
-                const double pairvb = 100000.0 * pow(AT(f->PVTFVB, i, j, k, 0, nzs), 1.0 / CON_KAPPA);
-                const double tairvb = AT(f->POTTVB, i, j, k, 0, nzs) * AT(f->PVTFVB, i, j, k, 0, nzs);
+                const real pairvb = 100000.0 * pow(AT(f->PVTFVB, i, j, k, 0, nzs), 1.0 / CON_KAPPA);
+                const real tairvb = AT(f->POTTVB, i, j, k, 0, nzs) * AT(f->PVTFVB, i, j, k, 0, nzs);
                 AT(f->PAIRVB, i, j, k, 0, nzs) = pairvb;
                 AT(f->TAIRVB, i, j, k, 0, nzs) = tairvb;
                 AT(f->RHOVB, i, j, k, 0, nzs) = pairvb / (CON_RD * tairvb);
             }
             for (int k = 0; k < nz; k++) {
-                const double tair = AT(f->POTT, i, j, k, 0, nz) * AT(f->PVTF, i, j, k, 0, nz);
-                const double pair = 100000.0 * pow(AT(f->PVTF, i, j, k, 0, nz), 1.0 / CON_KAPPA);
+                const real tair = AT(f->POTT, i, j, k, 0, nz) * AT(f->PVTF, i, j, k, 0, nz);
+                const real pair = 100000.0 * pow(AT(f->PVTF, i, j, k, 0, nz), 1.0 / CON_KAPPA);
                 AT(f->TAIR, i, j, k, 0, nz) = tair;
                 AT(f->PAIR, i, j, k, 0, nz) = pair;
                 AT(f->RHO, i, j, k, 0, nz) = pair / (CON_RD * tair);
-                const double wx = (AT(f->UWIND, i, j, k, 0, nz) + AT(f->UWIND, i + 1, j, k, 0, nz)) / 2.0;
-                const double wy = (AT(f->VWIND, i, j, k, 1, nz) + AT(f->VWIND, i, j + 1, k, 1, nz)) / 2.0;
+                const real wx = (AT(f->UWIND, i, j, k, 0, nz) + AT(f->UWIND, i + 1, j, k, 0, nz)) / 2.0;
+                const real wy = (AT(f->VWIND, i, j, k, 1, nz) + AT(f->VWIND, i, j + 1, k, 1, nz)) / 2.0;
                 AT(f->WINDX, i, j, k, 0, nz) = wx;
                 AT(f->WINDY, i, j, k, 0, nz) = wy;
                 AT(f->WIND, i, j, k, 0, nz) = sqrt(wx * wx + wy * wy);
@@ -787,28 +787,28 @@ void oracle_compute_turbulence(const oracle_cfg *c, oracle_fields *f)
     const int nx = c->nx, ny = c->ny, nz = c->nz, nzs = nz + 1;
     const int nthr = nthreads_of(c);
     (void)nthr;
-    const double Ri_c = 1.0, free_mix_len = 200.0, con_k = 0.35, con_Pr = 0.72;
-    const double min_wind_diff = 0.0001, min_KMOM = 0.000001, max_KMOM = 0.01;
+    const real Ri_c = 1.0, free_mix_len = 200.0, con_k = 0.35, con_Pr = 0.72;
+    const real min_wind_diff = 0.0001, min_KMOM = 0.000001, max_KMOM = 0.01;
     PAR_FOR
     for (int i = 0; i < nx + 2; i++)
         for (int j = 0; j < ny + 2; j++)
             for (int k = 1; k < nzs - 1; k++) {
-                double wx_km = AT(f->WINDX, i, j, k - 1, 0, nz), wx_kp = AT(f->WINDX, i, j, k, 0, nz);
-                double wy_km = AT(f->WINDY, i, j, k - 1, 0, nz), wy_kp = AT(f->WINDY, i, j, k, 0, nz);
+                real wx_km = AT(f->WINDX, i, j, k - 1, 0, nz), wx_kp = AT(f->WINDX, i, j, k, 0, nz);
+                real wy_km = AT(f->WINDY, i, j, k - 1, 0, nz), wy_kp = AT(f->WINDY, i, j, k, 0, nz);
                 if (wx_km == wx_kp) wx_km += min_wind_diff;
                 if (wy_km == wy_kp) wy_km += min_wind_diff;
-                const double alt_k = AT(f->PHIVB, i, j, k, 0, nzs) / CON_G;
-                const double alt_km = AT(f->PHI, i, j, k - 1, 0, nz) / CON_G, alt_kp = AT(f->PHI, i, j, k, 0, nz) / CON_G;
-                const double hgt = alt_k - A2(f->HSURF, i, j);
-                const double mix_len = con_k * hgt / (1.0 + con_k * hgt / free_mix_len);
-                const double qv_k = varvb_log(AT(f->QV, i, j, k, 0, nz), AT(f->QV, i, j, k - 1, 0, nz));
-                const double pott_k = AT(f->POTTVB, i, j, k, 0, nzs);
-                const double pott_v = pott_k * (1.0 + qv_k / 0.622) / (1.0 + qv_k);   /* misc_meteo_utilities.py:38-52 */
-                const double dwx = wx_km - wx_kp, dwy = wy_km - wy_kp, dz = alt_km - alt_kp;
-                const double ri_b = (CON_G / pott_v * (AT(f->POTT, i, j, k - 1, 0, nz) - AT(f->POTT, i, j, k, 0, nz)) * dz) /
+                const real alt_k = AT(f->PHIVB, i, j, k, 0, nzs) / CON_G;
+                const real alt_km = AT(f->PHI, i, j, k - 1, 0, nz) / CON_G, alt_kp = AT(f->PHI, i, j, k, 0, nz) / CON_G;
+                const real hgt = alt_k - A2(f->HSURF, i, j);
+                const real mix_len = con_k * hgt / (1.0 + con_k * hgt / free_mix_len);
+                const real qv_k = varvb_log(AT(f->QV, i, j, k, 0, nz), AT(f->QV, i, j, k - 1, 0, nz));
+                const real pott_k = AT(f->POTTVB, i, j, k, 0, nzs);
+                const real pott_v = pott_k * (1.0 + qv_k / 0.622) / (1.0 + qv_k);   /* misc_meteo_utilities.py:38-52 */
+                const real dwx = wx_km - wx_kp, dwy = wy_km - wy_kp, dz = alt_km - alt_kp;
+                const real ri_b = (CON_G / pott_v * (AT(f->POTT, i, j, k - 1, 0, nz) - AT(f->POTT, i, j, k, 0, nz)) * dz) /
                                     (dwx * dwx + dwy * dwy);
-                const double shear = sqrt((dwx / dz) * (dwx / dz) + (dwy / dz) * (dwy / dz));
-                double kmom = mix_len * mix_len * shear * (Ri_c - ri_b) / Ri_c;
+                const real shear = sqrt((dwx / dz) * (dwx / dz) + (dwy / dz) * (dwy / dz));
+                real kmom = mix_len * mix_len * shear * (Ri_c - ri_b) / Ri_c;
                 if (kmom < min_KMOM) kmom = min_KMOM;
                 if (kmom > max_KMOM) kmom = max_KMOM;
                 AT(f->KMOM, i, j, k, 0, nzs) = kmom;
@@ -885,20 +885,20 @@ void oracle_step_matsuno(const oracle_cfg *c, const oracle_grid *g, oracle_field
     const size_t n2 = (size_t)(nx + 2) * (ny + 2);
     for (int s = 0; s < nsteps; s++) {
         if (with_rho) oracle_diag_rho(c, f);                        /* solver.py:99-101 */
-        memcpy(f->COLP_OLD, f->COLP, n2 * sizeof(double));          /* :34-41 */
-        memcpy(f->UWIND_OLD, f->UWIND, (size_t)(nx + 3) * (ny + 2) * nz * sizeof(double));
-        memcpy(f->VWIND_OLD, f->VWIND, (size_t)(nx + 2) * (ny + 3) * nz * sizeof(double));
-        memcpy(f->POTT_OLD, f->POTT, n2 * nz * sizeof(double));
+        memcpy(f->COLP_OLD, f->COLP, n2 * sizeof(real));          /* :34-41 */
+        memcpy(f->UWIND_OLD, f->UWIND, (size_t)(nx + 3) * (ny + 2) * nz * sizeof(real));
+        memcpy(f->VWIND_OLD, f->VWIND, (size_t)(nx + 2) * (ny + 3) * nz * sizeof(real));
+        memcpy(f->POTT_OLD, f->POTT, n2 * nz * sizeof(real));
         if (c->i_moist) {
-            memcpy(f->QV_OLD, f->QV, n2 * nz * sizeof(double));
-            memcpy(f->QC_OLD, f->QC, n2 * nz * sizeof(double));
+            memcpy(f->QV_OLD, f->QV, n2 * nz * sizeof(real));
+            memcpy(f->QC_OLD, f->QC, n2 * nz * sizeof(real));
         }
         for (int sub = 0; sub < 2; sub++) {
             oracle_stage_continuity(c, g, f, dt);                   /* dyn_tendencies.py:25-70 */
             oracle_stage_momentum(c, g, f);
             oracle_stage_temperature(c, g, f);
             oracle_stage_moisture(c, g, f);
-            memcpy(f->COLP, f->COLP_NEW, n2 * sizeof(double));      /* :64-67 */
+            memcpy(f->COLP, f->COLP_NEW, n2 * sizeof(real));      /* :64-67 */
             oracle_stage_euler_forward(c, g, f, dt);                /* :75-77 */
             oracle_stage_primary_diag(c, g, f);                     /* :86-88 */
         }

@@ -25,6 +25,14 @@
 extern "C" {
 #endif
 
+/* Working precision (namelist.py:225-226): libdycore_oracle.so is built with real = double (the parity mode),
+ * libdycore_oracle_f32.so with -DORACLE_FLOAT32 (real = float: fields and grid constants; scalars stay double). */
+#ifdef ORACLE_FLOAT32
+typedef float real;
+#else
+typedef double real;
+#endif
+
 typedef struct {
     int nx, ny, nz;
     int i_turb;        /* i_UVFLX_vert_turb / i_POTT_vert_turb (namelist.py:66,77) */
@@ -38,33 +46,33 @@ typedef struct {
 
 /* grid constants: main_grid.py:299-314 (GRF dict) */
 typedef struct {
-    const double *A, *dxjs, *dyis, *corf, *corf_is, *lat_rad, *lat_is_rad,
+    const real *A, *dxjs, *dyis, *corf, *corf_is, *lat_rad, *lat_is_rad,
                  *dlon_rad, *dlat_rad;                 /* 2-D (.., .., 1) */
-    const double *sigma_vb, *dsigma, *UVFLX_dif_coef, *POTT_dif_coef; /* 1-D */
-    const double *moist_dif_coef;                                     /* 1-D */
+    const real *sigma_vb, *dsigma, *UVFLX_dif_coef, *POTT_dif_coef; /* 1-D */
+    const real *moist_dif_coef;                                     /* 1-D */
 } oracle_grid;
 
 /* model fields touched by the hot path: main_fields.py:234-475 */
 typedef struct {
-    double *COLP, *COLP_OLD, *COLP_NEW, *dCOLPdt, *HSURF;
-    double *UWIND, *UWIND_OLD, *VWIND, *VWIND_OLD, *WWIND;
-    double *POTT, *POTT_OLD, *POTTVB;
-    double *UFLX, *VFLX, *FLXDIV;
-    double *BFLX, *CFLX, *DFLX, *EFLX, *RFLX, *QFLX, *SFLX, *TFLX;
-    double *WWIND_UWIND, *WWIND_VWIND, *KMOM_dUWINDdz, *KMOM_dVWINDdz;
-    double *dUFLXdt, *dVFLXdt, *dPOTTdt;
-    double *dUFLXdt_TURB, *dVFLXdt_TURB, *dPOTTdt_TURB;
-    double *PVTF, *PVTFVB, *PHI, *PHIVB;
-    double *RHO, *RHOVB, *KMOM, *KHEAT;
-    double *SSHFLX, *SMOMXFLX, *SMOMYFLX, *dPOTTdt_RAD;
+    real *COLP, *COLP_OLD, *COLP_NEW, *dCOLPdt, *HSURF;
+    real *UWIND, *UWIND_OLD, *VWIND, *VWIND_OLD, *WWIND;
+    real *POTT, *POTT_OLD, *POTTVB;
+    real *UFLX, *VFLX, *FLXDIV;
+    real *BFLX, *CFLX, *DFLX, *EFLX, *RFLX, *QFLX, *SFLX, *TFLX;
+    real *WWIND_UWIND, *WWIND_VWIND, *KMOM_dUWINDdz, *KMOM_dVWINDdz;
+    real *dUFLXdt, *dVFLXdt, *dPOTTdt;
+    real *dUFLXdt_TURB, *dVFLXdt_TURB, *dPOTTdt_TURB;
+    real *PVTF, *PVTFVB, *PHI, *PHIVB;
+    real *RHO, *RHOVB, *KMOM, *KHEAT;
+    real *SSHFLX, *SMOMXFLX, *SMOMYFLX, *dPOTTdt_RAD;
     /* moisture (dyn_moist.py) */
-    double *QV, *QV_OLD, *QC, *QC_OLD, *dQVdt, *dQCdt, *dQVdt_TURB, *SLHFLX;
+    real *QV, *QV_OLD, *QC, *QC_OLD, *dQVdt, *dQCdt, *dQVdt_TURB, *SLHFLX;
     /* full secondary diagnostics (dyn_diagnostics.py:199-222) */
-    double *TAIR, *TAIRVB, *PAIR, *PAIRVB, *WINDX, *WINDY, *WIND;
+    real *TAIR, *TAIRVB, *PAIR, *PAIRVB, *WINDX, *WINDY, *WIND;
 } oracle_fields;
 
 /* misc_boundaries.py:22-42 ; stgx/stgy = 1 if staggered in that direction */
-void oracle_exchange_bc(const oracle_cfg *c, double *F, int stgx, int stgy, int nk);
+void oracle_exchange_bc(const oracle_cfg *c, real *F, int stgx, int stgy, int nk);
 
 /* dyn_continuity.py:170-232 (kernel only, no exchange) */
 void oracle_continuity(const oracle_cfg *c, const oracle_grid *g, oracle_fields *f, double dt);

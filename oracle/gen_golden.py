@@ -56,6 +56,8 @@ CASES = {
     'g10x4_dry':  dict(d=10, nz=4, steps=10, snaps=(1, 2, 10), stages=True,  turb=False),
     'g10x4_turb': dict(d=10, nz=4, steps=1,  snaps=(1,),       stages=True,  turb=True),
     'g4x8_dry':   dict(d=4,  nz=8, steps=10, snaps=(1, 10),    stages=False, turb=False),
+    # working_precision = 'float32' (namelist.py:225-226): the reference's arrays and wp() constants in float32
+    'g10x4_dry_f32': dict(d=10, nz=4, steps=10, snaps=(1, 2, 10), stages=True, turb=False, wp='float32'),
     # turbulence scheme of the reference switched on (turb_main.Turbulence): KMOM/KHEAT are
     # produced by compute_turbulence from the full secondary diagnostics every step
     'g10x4_phys': dict(d=10, nz=4, steps=5,  snaps=(1, 5),     stages=True,  turb=False, turbulence=True),
@@ -312,7 +314,7 @@ def run_case(name):
         return run_preset_case(name)
     sys.dont_write_bytecode = True
     tmp = tempfile.mkdtemp(prefix='golden_shims_')
-    _install_shims(tmp, cfg['d'], cfg['nz'], 'float64', cfg.get('turbulence', False))
+    _install_shims(tmp, cfg['d'], cfg['nz'], cfg.get('wp', 'float64'), cfg.get('turbulence', False))
     sys.path.insert(0, REF)
     sys.path.insert(0, tmp)
     os.chdir(REF)            # the reference opens data/... relative to cwd

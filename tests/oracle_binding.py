@@ -14,8 +14,10 @@ from climate_model_amd.fields import FIELD_TABLE, field_shape
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ORACLE_DIR = os.path.join(ROOT, 'oracle')
 LIB_PATH = os.path.join(ORACLE_DIR, 'libdycore_oracle.so')
+LIB_PATH_F32 = os.path.join(ORACLE_DIR, 'libdycore_oracle_f32.so')     # working_precision = 'float32'
 
 _dp = C.POINTER(C.c_double)
+_fp = C.POINTER(C.c_float)
 
 
 class OracleCfg(C.Structure):
@@ -29,7 +31,7 @@ GRID_1D = ['sigma_vb', 'dsigma', 'UVFLX_dif_coef', 'POTT_dif_coef', 'moist_dif_c
 
 
 class OracleGrid(C.Structure):
-    _fields_ = [(n, _dp) for n in GRID_2D + GRID_1D]
+    _fields_ = [(n, C.c_void_p) for n in GRID_2D + GRID_1D]
 
 
 ORACLE_FIELDS = ['COLP', 'COLP_OLD', 'COLP_NEW', 'dCOLPdt', 'HSURF',
@@ -48,28 +50,30 @@ ORACLE_FIELDS = ['COLP', 'COLP_OLD', 'COLP_NEW', 'dCOLPdt', 'HSURF',
 
 
 class OracleFields(C.Structure):
-    _fields_ = [(n, _dp) for n in ORACLE_FIELDS]
+    _fields_ = [(n, C.c_void_p) for n in ORACLE_FIELDS]
 
 
 _lib = None
+_lib_f32 = None
 
 
 def build_oracle(force=False):
     src = [os.path.join(ORACLE_DIR, f) for f in ('dycore_oracle.c', 'dycore_oracle.h', 'Makefile')]
-    stale = (not os.path.exists(LIB_PATH) or
-             any(os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in src))
+    stale = any(not os.path.exists(L) or any(os.path.getmtime(s) > os.path.getmtime(L) for s in src)
+                for L in (LIB_PATH, LIB_PATH_F32))
     if force or stale:
         subprocess.run(['make', '-C', ORACLE_DIR, '-s'], check=True)
     return LIB_PATH
 
 
-def load_oracle():
-    global _lib
-    if _lib is None:
+def load_oracle(dtype=np.float64):
+    global _lib, _lib_f32
+    f32 = np.dtype(dtype) == np.float32
+    if (_lib_f32 if f32 else _lib) is None:
         build_oracle()
-        lib = C.CDLL(LIB_PATH)
+        lib = C.CDLL(LIB_PATH_F32 if f32 else LIB_PATH)
         cp, gp, fp = C.POINTER(OracleCfg), C.POINTER(OracleGrid), C.POINTER(OracleFields)
-        lib.oracle_exchange_bc.argtypes = [cp, _dp, C.c_int, C.c_int, C.c_int]
+        lib.oracle_exchange_bc.argtypes = [cp, C.c_void_p, C.c_int, C.c_int, C.c_int]
         for n in ('oracle_continuity', 'oracle_make_timestep', 'oracle_stage_continuity',
                   'oracle_stage_euler_forward'):
             getattr(lib, n).argtypes = [cp, gp, fp, C.c_double]
@@ -82,16 +86,20 @@ def load_oracle():
                   'oracle_compute_turbulence'):
             getattr(lib, n).argtypes = [cp, fp]
         lib.oracle_step_matsuno.argtypes = [cp, gp, fp, C.c_double, C.c_int, C.c_int]
-        _lib = lib
-    return _lib
+        if f32:
+            _lib_f32 = lib
+        else:
+            _lib = lib
+    return _lib_f32 if f32 else _lib
 
 
 class Oracle:
     """The CPU restatement bound to one set of numpy arrays (reference layout)."""
 
     def __init__(self, nx, ny, nz, grid, fields=None, pair_top=10000., i_turb=1,
-                 i_radiation=0, nthreads=0, fill_nan=True, i_moist=0, i_moist_clip=0):
-        self.lib = load_oracle()
+                 i_radiation=0, nthreads=0, fill_nan=True, i_moist=0, i_moist_clip=0, dtype=np.float64):
+        self.dtype = np.dtype(dtype)
+        self.lib = load_oracle(self.dtype)
         self.nx, self.ny, self.nz = int(nx), int(ny), int(nz)
         if not nthreads:        # a GPU box shows every core of its host; its share is 16
             nthreads = min(16, len(os.sched_getaffinity(0)))
@@ -102,22 +110,22 @@ class Oracle:
         for n in GRID_2D + GRID_1D:
             if n == 'moist_dif_coef' and n not in grid:      # dry callers: same vertical profile as POTT
                 grid = dict(grid, moist_dif_coef=grid['POTT_dif_coef'])
-            a = np.ascontiguousarray(np.asarray(grid[n], dtype=np.float64))
+            a = np.ascontiguousarray(np.asarray(grid[n], dtype=self.dtype))
             self.G[n] = a
-            setattr(self.grid, n, a.ctypes.data_as(_dp))
+            setattr(self.grid, n, a.ctypes.data)
         self.F = {}
         self.fields = OracleFields()
         for n in ORACLE_FIELDS:
             shp = field_shape(n, self.nx, self.ny, self.nz)
             if fields is not None and n in fields:
-                a = np.array(fields[n], dtype=np.float64, order='C')
+                a = np.array(fields[n], dtype=self.dtype, order='C')
                 assert a.shape == shp, (n, a.shape, shp)
             elif fill_nan:
-                a = np.full(shp, np.nan)
+                a = np.full(shp, np.nan, dtype=self.dtype)
             else:               # benchmark use: untouched pages cost nothing
-                a = np.empty(shp)
+                a = np.empty(shp, dtype=self.dtype)
             self.F[n] = a
-            setattr(self.fields, n, a.ctypes.data_as(_dp))
+            setattr(self.fields, n, a.ctypes.data)
 
     def set(self, name, value):
         self.F[name][...] = value
@@ -128,7 +136,7 @@ class Oracle:
     def exchange_bc(self, name):
         stgx, stgy, _ = FIELD_TABLE[name]
         a = self.F[name]
-        self.lib.oracle_exchange_bc(C.byref(self.cfg), a.ctypes.data_as(_dp), stgx, stgy, a.shape[2])
+        self.lib.oracle_exchange_bc(C.byref(self.cfg), a.ctypes.data, stgx, stgy, a.shape[2])
 
     def continuity(self, dt):
         c, g, f = self._c(); self.lib.oracle_stage_continuity(c, g, f, float(dt))
@@ -162,7 +170,7 @@ class Oracle:
         self.lib.oracle_step_matsuno(c, g, f, float(dt), int(nsteps), int(bool(with_rho)))
 
 
-def oracle_from_golden(z, tag=None, i_turb=1, i_moist=0):
+def oracle_from_golden(z, tag=None, i_turb=1, i_moist=0, dtype=np.float64):
     """Build an Oracle from a golden .npz: grid constants + either the initial
     conditions (tag None) or the full captured state `tag` (e.g. 'st00_pre')."""
     nx, ny, nz = int(z['meta/nx']), int(z['meta/ny']), int(z['meta/nz'])
@@ -172,7 +180,7 @@ def oracle_from_golden(z, tag=None, i_turb=1, i_moist=0):
     for n in ORACLE_FIELDS:
         if prefix + n in z:
             fields[n] = z[prefix + n]
-    o = Oracle(nx, ny, nz, grid, fields, pair_top=float(z['meta/pair_top']), i_turb=i_turb, i_moist=i_moist)
+    o = Oracle(nx, ny, nz, grid, fields, pair_top=float(z['meta/pair_top']), i_turb=i_turb, i_moist=i_moist, dtype=dtype)
     return o
 
 

@@ -729,14 +729,31 @@ __global__ __launch_bounds__(FTI *TJ) void k_momentum_dma(Geo g, Ptrs p, int gbx
             for (int b = 0; b < 4; b++)
 #pragma unroll
                 for (int a = 0; a < 3; a++) vf[b][a] = SM(S_VF, a - 1, b - 1);
-#pragma unroll
-            for (int b = 0; b < 3; b++)
-#pragma unroll
-                for (int a = 0; a < 3; a++) { uw[b][a] = SM(S_UW, a - 1, b - 1); vw[b][a] = SM(S_VW, a - 1, b - 1); }
 #define UF(a, b) uf[(b) + 1][(a) + 1]
 #define VF(a, b) vf[(b) + 1][(a) + 1]
 #define U(a, b) uw[(b) + 1][(a) + 1]
 #define V(a, b) vw[(b) + 1][(a) + 1]
+            // ---- the sixteen Arakawa-C flux means B,C,D,E / R,Q,S,T (dyn_UVFLX_prepare.py:249-439) from shared pair
+            // sums of the UFLX (3 x 4) and VFLX (4 x 3) neighbourhoods.  They carry HALF their weight (1/24, 1/48):
+            // the "/ 2" of the wind mean in every advective term is applied here, where it is free -- a power of
+            // two passes through every rounding unchanged.  The sums are associated pairwise instead of left to
+            // right (<= 1 ulp per sum from the reference's order); 80 instead of ~125 fp64 instructions.
+            // Everything the flux neighbourhoods feed is formed first, so that their 24 registers are free again
+            // before the wind neighbourhoods are read.
+            const real hx_m_m = UF(-1, -1) + UF(0, -1), hx_0_m = UF(0, -1) + UF(1, -1), hx_p_m = UF(1, -1) + UF(2, -1);
+            const real hx_m_0 = UF(-1, 0) + UF(0, 0), hx_0_0 = UF(0, 0) + UF(1, 0), hx_p_0 = UF(1, 0) + UF(2, 0);
+            const real hx_m_p = UF(-1, 1) + UF(0, 1), hx_0_p = UF(0, 1) + UF(1, 1);
+            const real gy_m_m = VF(-1, -1) + VF(-1, 0), gy_0_m = VF(0, -1) + VF(0, 0), gy_p_m = VF(1, -1) + VF(1, 0);
+            const real gy_m_0 = VF(-1, 0) + VF(-1, 1), gy_0_0 = VF(0, 0) + VF(0, 1), gy_p_0 = VF(1, 0) + VF(1, 1);
+            const real gy_m_p = VF(-1, 1) + VF(-1, 2), gy_0_p = VF(0, 1) + VF(0, 2);
+            const real gx_m = VF(-1, -1) + VF(0, -1), gx_0 = VF(-1, 0) + VF(0, 0), gx_p = VF(-1, 1) + VF(0, 1), gx_pp = VF(-1, 2) + VF(0, 2);
+            const real hy_m = UF(-1, -1) + UF(-1, 0), hy_0 = UF(0, -1) + UF(0, 0), hy_p = UF(1, -1) + UF(1, 0), hy_pp = UF(2, -1) + UF(2, 0);
+            const real lap_u = UF(-1, 0) + UF(1, 0) + UF(0, -1) + UF(0, 1) - 4.0 * UF(0, 0);     // five-point diffusion stencils
+            const real lap_v = VF(-1, 0) + VF(1, 0) + VF(0, -1) + VF(0, 1) - 4.0 * VF(0, 0);
+#pragma unroll
+            for (int b = 0; b < 3; b++)
+#pragma unroll
+                for (int a = 0; a < 3; a++) { uw[b][a] = SM(S_UW, a - 1, b - 1); vw[b][a] = SM(S_VW, a - 1, b - 1); }
             // ---- six-point sums at interface k+1 (dyn_functions.py:211-270) ----
             if (k + 1 < nz) {
                 const real w_c = SM(S_W, 0, 0), w_w = SM(S_W, -1, 0), w_s = SM(S_W, 0, -1), w_sw = SM(S_W, -1, -1);
@@ -760,23 +777,11 @@ __global__ __launch_bounds__(FTI *TJ) void k_momentum_dma(Geo g, Ptrs p, int gbx
             } else {
                 pvtf = SM(S_PVTF, 0, 0); pvtf_im1 = SM(S_PVTF, -1, 0); pvtf_jm1 = SM(S_PVTF, 0, -1);
             }
-            // ---- the sixteen Arakawa-C flux means B,C,D,E / R,Q,S,T (dyn_UVFLX_prepare.py:249-439) from shared pair
-            // sums of the UFLX (3 x 4) and VFLX (4 x 3) neighbourhoods.  They carry HALF their weight (1/24, 1/48):
-            // the "/ 2" of the wind mean in every advective term is applied here, where it is free -- a power of
-            // two passes through every rounding unchanged.  The sums are associated pairwise instead of left to
-            // right (<= 1 ulp per sum from the reference's order); 80 instead of ~125 fp64 instructions.
-            const real hx_m_m = UF(-1, -1) + UF(0, -1), hx_0_m = UF(0, -1) + UF(1, -1), hx_p_m = UF(1, -1) + UF(2, -1);
-            const real hx_m_0 = UF(-1, 0) + UF(0, 0), hx_0_0 = UF(0, 0) + UF(1, 0), hx_p_0 = UF(1, 0) + UF(2, 0);
-            const real hx_m_p = UF(-1, 1) + UF(0, 1), hx_0_p = UF(0, 1) + UF(1, 1);
-            const real gy_m_m = VF(-1, -1) + VF(-1, 0), gy_0_m = VF(0, -1) + VF(0, 0), gy_p_m = VF(1, -1) + VF(1, 0);
-            const real gy_m_0 = VF(-1, 0) + VF(-1, 1), gy_0_0 = VF(0, 0) + VF(0, 1), gy_p_0 = VF(1, 0) + VF(1, 1);
-            const real gy_m_p = VF(-1, 1) + VF(-1, 2), gy_0_p = VF(0, 1) + VF(0, 2);
             constexpr real W24 = 1.0 / 24.0, W48 = 1.0 / 48.0;
             const real prs = pott * rds;                 // POTT / dsigma of the own cell (pressure-gradient terms)
             const real own = svb1 * (pvb_kp1 - pvtf) + svb * (pvtf - pvb_k);
             // =============================== dUFLXdt (level k, without vertical advection) ====
             {
-                const real gx_m = VF(-1, -1) + VF(0, -1), gx_0 = VF(-1, 0) + VF(0, 0), gx_p = VF(-1, 1) + VF(0, 1), gx_pp = VF(-1, 2) + VF(0, 2);
                 const real bflx = W24 * (hx_0_m + 2.0 * hx_0_0 + hx_0_p);
                 const real bflx_im1 = W24 * (hx_m_m + 2.0 * hx_m_0 + hx_m_p);
                 const real cflx = w24_lo * (gx_m + 2.0 * gx_0 + gx_p);          // 0 at the southern polar row (dyn_UFLX.py:377-384)
@@ -799,13 +804,12 @@ __global__ __launch_bounds__(FTI *TJ) void k_momentum_dma(Geo g, Ptrs p, int gbx
                 t = t + ((phi - SM(S_PHI, -1, 0)) * pgu_a +
                          pgu_b * ((SM(S_POTT, -1, 0) * rds) * (svb1 * (pvb_im1_kp1 - pvtf_im1) + svb * (pvtf_im1 - pvb_im1_k)) +
                                   prs * own));
-                t = t + dif * (UF(-1, 0) + UF(1, 0) + UF(0, -1) + UF(0, 1) - 4.0 * UF(0, 0));      // dif >= 0; 0 adds nothing
+                t = t + dif * lap_u;      // dif >= 0; 0 adds nothing
                 if (TURB) t = t + tbu;
                 tu_km1 = t;
             }
             // =============================== dVFLXdt ===============================
             if (v_on) {
-                const real hy_m = UF(-1, -1) + UF(-1, 0), hy_0 = UF(0, -1) + UF(0, 0), hy_p = UF(1, -1) + UF(1, 0), hy_pp = UF(2, -1) + UF(2, 0);
                 const real rflx = W24 * (gy_m_0 + 2.0 * gy_0_0 + gy_p_0);
                 const real rflx_jm1 = W24 * (gy_m_m + 2.0 * gy_0_m + gy_p_m);
                 const real qflx = W24 * (hy_m + 2.0 * hy_0 + hy_p);
@@ -824,7 +828,7 @@ __global__ __launch_bounds__(FTI *TJ) void k_momentum_dma(Geo g, Ptrs p, int gbx
                 t = t + ((phi - SM(S_PHI, 0, -1)) * pgv_a +
                          pgv_b * ((SM(S_POTT, 0, -1) * rds) * (svb1 * (pvb_jm1_kp1 - pvtf_jm1) + svb * (pvtf_jm1 - pvb_jm1_k)) +
                                   prs * own));
-                t = t + dif * (VF(-1, 0) + VF(1, 0) + VF(0, -1) + VF(0, 1) - 4.0 * VF(0, 0));
+                t = t + dif * lap_v;
                 if (TURB) t = t + tbv;
                 tv_km1 = t;
             }

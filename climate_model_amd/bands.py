@@ -159,14 +159,16 @@ class _TorchBuffers:
     def __init__(self, halo, device):
         import torch
         self.send, self.recv, self.split_send, self.split_recv = {}, {}, {}, {}
+        # message elements have the working precision of the handle (rows_size counts elements)
+        dt = torch.float32 if str(getattr(halo.core, 'dtype', 'float64')) == 'float32' else torch.float64
         for ph in PHASES:
             sz = halo.sizes(ph)
             ss = sz['send_south'] if halo.has_south else 0
             sn = sz['send_north'] if halo.has_north else 0
             rs = sz['recv_south'] if halo.has_south else 0
             rn = sz['recv_north'] if halo.has_north else 0
-            self.send[ph] = torch.empty(max(ss + sn, 1), dtype=torch.float64, device=device)
-            self.recv[ph] = torch.empty(max(rs + rn, 1), dtype=torch.float64, device=device)
+            self.send[ph] = torch.empty(max(ss + sn, 1), dtype=dt, device=device)
+            self.recv[ph] = torch.empty(max(rs + rn, 1), dtype=dt, device=device)
             self.split_send[ph] = (ss, sn)
             self.split_recv[ph] = (rs, rn)
 
@@ -324,7 +326,7 @@ class DistributedBands:
         import torch
         dist, b = self.dist, self.bufs
         if self.staged:     # gloo: through host memory
-            send, recv = b.send[ph].cpu(), torch.empty(b.recv[ph].shape, dtype=torch.float64)
+            send, recv = b.send[ph].cpu(), torch.empty(b.recv[ph].shape, dtype=b.recv[ph].dtype)
         else:
             send, recv = b.send[ph], b.recv[ph]
         (ss, sn), (rs, rn) = b.split_send[ph], b.split_recv[ph]

@@ -399,7 +399,7 @@ class NativeBands:
 
     @classmethod
     def local(cls, cores):
-        lib = load_library()
+        lib = cores[0].lib              # the build (working precision) the handles belong to
         arr = (C.c_void_p * len(cores))(*[c._h for c in cores])
         b = C.c_void_p()
         rc = lib.dycore_bands_create_local(arr, len(cores), C.byref(b))
@@ -409,7 +409,7 @@ class NativeBands:
 
     @classmethod
     def rccl(cls, core, unique_id, rank, nranks, south, north):
-        lib = load_library()
+        lib = core.lib
         if len(unique_id) != UNIQUE_ID_BYTES:
             raise ValueError('the RCCL id has %d bytes' % UNIQUE_ID_BYTES)
         b = C.c_void_p()

@@ -170,3 +170,47 @@ def test_hip_f32_vs_oracle_f32(nx, ny, nz):
         err, ncmp, bad = rel_max_err(core.download(name), o.F[name], name, nx, ny)
         assert bad == 0 and ncmp > 0 and err <= tol, '%s at %dx%dx%d: rel err %.3e' % (name, nx, ny, nz, err)
     core.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('native', [False, True])
+def test_hip_f32_bands_bitwise_equal_single(native):
+    """Latitude bands of the float library (3 bands, overlapped schedule in Python and inside the library) = its
+    single-domain run, bit for bit -- the band machinery is precision-agnostic."""
+    import torch
+    from climate_model_amd import Namelist, Grid, ModelFields, HipDycore
+    from climate_model_amd.bands import BandLayout, LocalBands, band_grid_arrays, gather_global
+    from climate_model_amd.fields import FIELD_TABLE
+    from climate_model_amd.synthetic import initialize_fields
+    GR = Grid(Namelist(nz=8, dlat_deg=4, dlon_deg=4))
+    F = ModelFields(GR)
+    initialize_fields(GR, F)
+    names = ['HSURF', 'COLP', 'UWIND', 'VWIND', 'POTT', 'WWIND', 'POTTVB']
+    single = HipDycore(GR.nx, GR.ny, GR.nz, dtype=np.float32)
+    assert single.flux_from_winds and single.overlap_parts          # the production kernels, in float
+    single.set_grid(GR.GRF['HIP'])
+    for n in names:
+        single.upload(n, F.host[n])
+    single.primary_diag()
+    single.step_matsuno(GR.dt, 3)
+    check = ['COLP', 'UWIND', 'VWIND', 'POTT', 'PHI', 'WWIND']
+    ref = {n: single.download(n) for n in check}
+    single.close()
+    L = BandLayout(GR.ny, 3)
+    stream = torch.cuda.Stream()
+    cores = []
+    for r in range(3):
+        c = HipDycore(GR.nx, L.ny(r), GR.nz, ny_global=GR.ny, j_offset=L.j_offset(r), stream=stream.cuda_stream, dtype=np.float32)
+        c.set_grid(band_grid_arrays(GR.GRF['HIP'], L, r))
+        for n in names:
+            c.upload(n, L.slice_rows(F.host[n], r, FIELD_TABLE[n][1]))
+        c.primary_diag()
+        cores.append(c)
+    lb = LocalBands(cores, L, torch.device('cuda:0'), overlap=True, native=native)
+    lb.step_matsuno(GR.dt, 3)
+    for n in check:
+        got = gather_global(L, [c.download(n) for c in cores], n)
+        assert got.dtype == np.float32
+        np.testing.assert_array_equal(got, ref[n], err_msg=n)
+    for c in cores:
+        c.close()

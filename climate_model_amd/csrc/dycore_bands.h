@@ -40,7 +40,7 @@ int load_rccl(RcclApi **out)
     static RcclApi api;
     static int state = 0;       // 0 not tried, 1 ok, -1 failed
     if (state == 0) {
-        const char *names[] = {"librccl.so", "librccl.so.1"};
+        const char *names[] = {"librccl.so.1", "librccl.so"};      // the SONAME first: RTLD_NOLOAD matches a loaded copy by it
         for (const char *n : names)
             if ((api.lib = dlopen(n, RTLD_NOW | RTLD_NOLOAD))) break;
         if (!api.lib)
@@ -60,7 +60,7 @@ int load_rccl(RcclApi **out)
                 state = 1;
         }
     }
-    if (state != 1) return fail(DYCORE_ESTATE, "librccl.so could not be loaded: %s", dlerror() ? dlerror() : "symbols missing");
+    if (state != 1) return fail(DYCORE_ESTATE, "librccl.so could not be loaded (or lacks ncclSend / ncclRecv)");
     *out = &api;
     return 0;
 }

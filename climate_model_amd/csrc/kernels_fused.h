@@ -1025,8 +1025,8 @@ __global__ __launch_bounds__(TI *TJ) void k_continuity_reg(Geo g, Ptrs p, real d
     p.WWIND[c] = 0.0;
     p.WWIND[c + (size_t)NZ * g.plane] = 0.0;
 #pragma unroll
-    for (int k = 1; k < NZ; k++)
-        p.WWIND[c + (size_t)k * g.plane] = -pre[k] / colp_new - p.sigma_vb[k] * dcolpdt / colp_new;
+    for (int k = 1; k < NZ; k++)       // streaming stores (nt): 0.405 -> 0.39 ms per launch (profiles/r02_notes.md)
+        __builtin_nontemporal_store((real)(-pre[k] / colp_new - p.sigma_vb[k] * dcolpdt / colp_new), &p.WWIND[c + (size_t)k * g.plane]);
 }
 
 // Fields the fused step does not store, re-derived when somebody asks for them:
@@ -1101,7 +1101,9 @@ __global__ __launch_bounds__(TI *TJ) void k_derive_phivb(Geo g, Ptrs p)
 // of global_load/global_store, where 64-bit pointer arithmetic per access was ~50 VALU
 // instructions per level.  (dycore_create refuses fields of 4 GiB and more.)
 __device__ __forceinline__ real ldb(const real *base, unsigned boff) { return *(const real *)((const char *)base + boff); }
-__device__ __forceinline__ void stb(real *base, unsigned boff, real v) { *(real *)((char *)base + boff) = v; }
+// (streaming store, `nt`: the temperature kernel's five outputs are read again only by later kernels, after ~20 GB of
+// other traffic; k_pott_fused 1.17 -> 1.10 ms per launch, profiles/r02_notes.md)
+__device__ __forceinline__ void stb(real *base, unsigned boff, real v) { __builtin_nontemporal_store(v, (real *)((char *)base + boff)); }
 
 // WRITE_PVTF = false: PVTF is not stored either -- the production momentum kernel forms it from PVTFVB and COLP, every
 // other reader gets it on demand (k_derive_pvtf, the formula of diag_level_pre on the stored PVTFVB: the same bits).

@@ -1101,6 +1101,9 @@ __global__ __launch_bounds__(TI *TJ) void k_derive_phivb(Geo g, Ptrs p)
 // of global_load/global_store, where 64-bit pointer arithmetic per access was ~50 VALU
 // instructions per level.  (dycore_create refuses fields of 4 GiB and more.)
 __device__ __forceinline__ real ldb(const real *base, unsigned boff) { return *(const real *)((const char *)base + boff); }
+// (streaming load, `nt`: for the fields a column reads at its own cell only -- WWIND, POTTVB, the step-start POTT; the
+// neighbour-shared ones keep the default policy.  k_pott_fused 1.051 -> 1.034 ms, step -1.5 %, profiles/r02_notes.md)
+__device__ __forceinline__ real ldn(const real *base, unsigned boff) { return __builtin_nontemporal_load((const real *)((const char *)base + boff)); }
 // (streaming store, `nt`: the temperature kernel's five outputs are read again only by later kernels, after ~20 GB of
 // other traffic; k_pott_fused 1.17 -> 1.10 ms per launch, profiles/r02_notes.md)
 __device__ __forceinline__ void stb(real *base, unsigned boff, real v) { __builtin_nontemporal_store(v, (real *)((char *)base + boff)); }
@@ -1146,7 +1149,7 @@ __global__ __launch_bounds__(TI *TJ) void k_pott_fused(Geo g, Ptrs p, const real
         r.pt = ldb(p.POTT, q); r.im1 = ldb(p.POTT, q - (unsigned)sizeof(real)); r.ip1 = ldb(p.POTT, q + (unsigned)sizeof(real));
         r.jm1 = ldb(p.POTT, q - bP); r.jp1 = ldb(p.POTT, q + bP);
         r.uf = ldb(fu, q); r.uf1 = ldb(fu, q + (unsigned)sizeof(real)); r.vf = ldb(fv, q); r.vf1 = ldb(fv, q + bP);
-        r.w = ldb(p.WWIND, q); r.pvb = ldb(p.POTTVB, q); r.po = ldb(pott_old, q);
+        r.w = ldn(p.WWIND, q); r.pvb = ldn(p.POTTVB, q); r.po = ldn(pott_old, q);
     };
     auto level = [&](int k, In &cur) {
         const unsigned q = bc + (unsigned)k * bpl;

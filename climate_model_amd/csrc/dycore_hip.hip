@@ -147,6 +147,7 @@ struct dycore {
     const real *flx_u = nullptr, *flx_v = nullptr;   // winds the last fused continuity evaluated on
     bool winds_bc_dirty = true;     // UWIND / VWIND came from the host: their lateral BC images (column nx+2!) may be unset
     int n_cu = 256;                 // compute units of the device
+    int mom_tj = 4;                 // tile rows of the LDS-DMA momentum kernel (8: one workgroup per CU; 4: two, each with its own barrier)
     int cell_lin = -1;              // DYCORE_CELL_LINEAR: column-kernel launch, bit 0 = cell runs, bit 1 = XCD-aware order (default 3 or 2)
     int mom_ks = 0;                 // DYCORE_MOM_KS: force the level chunks per momentum tile (1 .. 16)
     int mom_split = 1;              // DYCORE_MOM_SPLIT=0: no second segment (short chunks for the tiles beyond the last full round)
@@ -505,7 +506,14 @@ int do_momentum_fused(dycore *h, const Ptrs &p, const real *u_old, const real *v
         // (9, 10 rows: fewer halo rows, better fit of 90-row bands on 256 CUs) need a third
         // wavefront on one SIMD, which caps the kernel at 168 VGPRs: 2x slower on MI355X
         // (profiles/r01_notes.md).
-        constexpr int tj = FTJ;
+        // 64 x 4 tiles (production; DYCORE_MOM_TJ=8 for 64 x 8): two workgroups of four wavefronts per CU instead of one of
+        // eight.  Each has its own per-level barrier, so one workgroup's LDS reads meet the other's arithmetic (the kernel
+        // without its DMA: 0.94 -> 0.80 ms per launch) at the price of 17 % more rows staged (7 halo rows per 4 instead of
+        // 10 per 8; they hit in L2); the corrector keeps one DMA level in flight (two do not fit 80 KB of LDS).
+        // 1.28-1.30 -> 1.23-1.25 ms per launch, profiles/r02_notes.md.
+        const bool half = h->mom_tj == 4 && !h->g.i_turb && flux_from_winds(h) && (h->fw_mask & 2);
+        const int tj = half ? 4 : FTJ;
+        const int slots = h->n_cu * (half ? 2 : 1);           // workgroups resident at a time
         const int gby2 = (h->g.ny + tj - 1) / tj;
         // level chunks per tile: with one workgroup per CU, `tiles` workgroups of 64 levels take
         // ceil(tiles / CUs) rounds; ks chunks take ceil(tiles*ks / CUs) rounds of (64/ks + 1)
@@ -527,7 +535,7 @@ int do_momentum_fused(dycore *h, const Ptrs &p, const real *u_old, const real *v
         {
             const long tiles = (long)gbx * trows.n;
             const double pro = h->mom_pro;
-            auto rounds = [&](long wg) { return (double)((wg + h->n_cu - 1) / h->n_cu); };
+            auto rounds = [&](long wg) { return (double)((wg + slots - 1) / slots); };
             double best = -1.0;
             // any number of chunks up to 16 (chunk kc covers levels [kc nz / ks, (kc + 1) nz / ks)); a chunk of fewer
             // than 4 levels is all prologue
@@ -537,9 +545,9 @@ int do_momentum_fused(dycore *h, const Ptrs &p, const real *u_old, const real *v
                 if (best < 0 || cost < best - 1e-9) { best = cost; plan.ks_a = cand; }
             }
             if (h->mom_ks) plan.ks_a = h->mom_ks;
-            const long full = tiles / h->n_cu;            // whole rounds of full tiles
-            if (h->mom_split && !h->mom_ks && trows.gap == 0 && full >= 1 && tiles % h->n_cu) {
-                const int r1 = (int)(full * h->n_cu / gbx);       // tile rows inside those rounds
+            const long full = tiles / slots;              // whole rounds of full tiles
+            if (h->mom_split && !h->mom_ks && trows.gap == 0 && full >= 1 && tiles % slots) {
+                const int r1 = (int)(full * slots / gbx);       // tile rows inside those rounds
                 const int r2 = trows.n - r1;
                 if (r1 >= 1 && r2 >= 1) {
                     for (int cand = 1; cand <= 16; cand++) {
@@ -559,11 +567,14 @@ int do_momentum_fused(dycore *h, const Ptrs &p, const real *u_old, const real *v
         const bool cur = (u_old == p.UWIND);
         const bool fw = flux_from_winds(h) && (h->fw_mask & 2);
         // ring depth: two levels in flight for the production (dry / moist, fluxes from the winds) instances
-#define MOM_LAUNCH(CUR_, FW_, TB_, DP_) hipLaunchKernelGGL((k_momentum_dma<CUR_, tj, FW_, TB_, DP_>), gr2, blk, dma_lds_bytes(tj, FW_, CUR_, DP_), h->stream, h->g, p, gbx, plan, jv_lo, u_old, v_old, u_out, v_out, dt)
-        if (h->g.i_turb) { if (cur) MOM_LAUNCH(true, true, true, 1); else MOM_LAUNCH(false, true, true, 1); }
+#define MOM_LAUNCH_T(CUR_, TJ_, FW_, TB_, DP_) hipLaunchKernelGGL((k_momentum_dma<CUR_, TJ_, FW_, TB_, DP_>), gr2, blk, dma_lds_bytes(TJ_, FW_, CUR_, DP_), h->stream, h->g, p, gbx, plan, jv_lo, u_old, v_old, u_out, v_out, dt)
+#define MOM_LAUNCH(CUR_, FW_, TB_, DP_) MOM_LAUNCH_T(CUR_, FTJ, FW_, TB_, DP_)
+        if (half) { if (!cur) MOM_LAUNCH_T(false, 4, true, false, 1); else if (h->mom_depth == 2) MOM_LAUNCH_T(true, 4, true, false, 2); else MOM_LAUNCH_T(true, 4, true, false, 1); }
+        else if (h->g.i_turb) { if (cur) MOM_LAUNCH(true, true, true, 1); else MOM_LAUNCH(false, true, true, 1); }
         else if (cur) { if (!fw) MOM_LAUNCH(true, false, false, 1); else if (h->mom_depth == 2) MOM_LAUNCH(true, true, false, 2); else MOM_LAUNCH(true, true, false, 1); }
         else { if (!fw) MOM_LAUNCH(false, false, false, 1); else if (h->mom_depth == 2) MOM_LAUNCH(false, true, false, 2); else MOM_LAUNCH(false, true, false, 1); }
 #undef MOM_LAUNCH
+#undef MOM_LAUNCH_T
     } else if (u_out)
         hipLaunchKernelGGL(k_momentum_fused<true>, gr, bl, 0, h->stream, h->g, p, gbx, gby, jv_lo, u_old, v_old, u_out, v_out, dt);
     else
@@ -847,6 +858,7 @@ int dycore_create(const DycoreConfig *cfg, dycore_t **out)
     if (const char *e = getenv("DYCORE_FW_MASK")) h->fw_mask = atoi(e);
     if (const char *e = getenv("DYCORE_MOM_KS")) h->mom_ks = atoi(e);
     if (const char *e = getenv("DYCORE_MOM_PATCH")) h->mom_patch = atoi(e) > 1 ? atoi(e) : 1;
+    if (const char *e = getenv("DYCORE_MOM_TJ")) h->mom_tj = atoi(e) == 4 ? 4 : 8;
     if (const char *e = getenv("DYCORE_MOM_DEPTH")) h->mom_depth = atoi(e) == 1 ? 1 : 2;
     if (const char *e = getenv("DYCORE_MOM_SPLIT")) h->mom_split = atoi(e);
     if (const char *e = getenv("DYCORE_MOM_PRO")) h->mom_pro = atof(e);
@@ -856,18 +868,22 @@ int dycore_create(const DycoreConfig *cfg, dycore_t **out)
         if (hipGetDeviceProperties(&prop, cfg->device) == hipSuccess && prop.multiProcessorCount > 0) h->n_cu = prop.multiProcessorCount;
     }
     {   // the LDS-DMA kernel keeps up to 155 KB of tiles in LDS: raise the dynamic-LDS limit of every instantiation once
-        bool ok_plain = true, ok_fw = true, ok_deep = true;
-#define MOM_ATTR(CUR_, FW_, TB_, DP_, FLAG_)                                                                          \
-        if (hipFuncSetAttribute((const void *)k_momentum_dma<CUR_, FTJ, FW_, TB_, DP_>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                (int)dma_lds_bytes(FTJ, FW_, CUR_, DP_)) != hipSuccess) { (void)hipGetLastError(); FLAG_ = false; }
+        bool ok_plain = true, ok_fw = true, ok_deep = true, ok_half = true;
+#define MOM_ATTR_T(CUR_, TJ_, FW_, TB_, DP_, FLAG_)                                                                   \
+        if (hipFuncSetAttribute((const void *)k_momentum_dma<CUR_, TJ_, FW_, TB_, DP_>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                (int)dma_lds_bytes(TJ_, FW_, CUR_, DP_)) != hipSuccess) { (void)hipGetLastError(); FLAG_ = false; }
+#define MOM_ATTR(CUR_, FW_, TB_, DP_, FLAG_) MOM_ATTR_T(CUR_, FTJ, FW_, TB_, DP_, FLAG_)
+        MOM_ATTR_T(true, 4, true, false, 1, ok_half) MOM_ATTR_T(true, 4, true, false, 2, ok_half) MOM_ATTR_T(false, 4, true, false, 1, ok_half)
         MOM_ATTR(true, false, false, 1, ok_plain) MOM_ATTR(false, false, false, 1, ok_plain)
         MOM_ATTR(true, true, false, 1, ok_fw) MOM_ATTR(false, true, false, 1, ok_fw)
         MOM_ATTR(true, true, true, 1, ok_fw) MOM_ATTR(false, true, true, 1, ok_fw)
         MOM_ATTR(true, true, false, 2, ok_deep) MOM_ATTR(false, true, false, 2, ok_deep)
 #undef MOM_ATTR
+#undef MOM_ATTR_T
         if (!ok_plain) h->mom_dma = 0;
         if (!ok_fw) h->lazy_flx = false;
         if (!ok_deep) h->mom_depth = 1;
+        if (!ok_half) h->mom_tj = 8;
     }
     if (cfg->stream) h->stream = (hipStream_t)cfg->stream;
     else {

@@ -355,6 +355,9 @@ constexpr int mom_rows(int f, int tj, bool fw)
     return tj;
 #endif
     if (f == S_PVTF && fw) return 0;        // formed in the thread from PVTFVB and the column pressure (below)
+#ifdef DYC_MOM_NOPHI       // experiment builds only (wrong results): PHI not staged
+    if (f == S_PHI && fw) return 0;
+#endif
     return f == S_UF ? tj + 2 : f == S_VF ? tj + 3 : f == S_UW ? tj + 2 : f == S_VW ? (fw ? tj + 3 : tj + 2) : f == S_W ? tj + 2 : tj + 1;
 }
 // LDS layout (doubles).  A DMA slot holds the staged fields of one level back to back (each rows x FTW), then the
@@ -380,6 +383,21 @@ constexpr size_t dma_lds_bytes(int tj, bool fw, bool cur, int depth)
 #endif
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef const __attribute__((address_space(1))) void gbl_void_t;
+// One LDS-DMA instruction: 16 B per lane from `gp` to LDS byte address `lds` + 16 * lane (`lds` wave-uniform, in M0).
+// Written as assembly, not as __builtin_amdgcn_global_load_lds: the compiler tracks the builtin's LDS writes and puts
+// `s_waitcnt vmcnt(0)` in front of any LDS read it cannot prove disjoint from them -- which drains the levels in flight.
+// Whether it finds such a read depends on details of the loop body (a build that staged one field less ran 9 % slower
+// for one such wait, profiles/r02_notes.md); the level loop does its own counting (wait_vmcnt), so the DMA is kept
+// out of the compiler's bookkeeping altogether.
+__device__ __forceinline__ void lds_dma16(const void *gp, const void *lds)
+{
+    const unsigned m = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(size_t)(lds_void_t *)lds);
+#if DYC_DMA_AUX == 2
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off nt" ::"v"(gp), "s"(m) : "memory", "m0");
+#else
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gp), "s"(m) : "memory", "m0");
+#endif
+}
 
 // a real that is the same in every lane of the wavefront, moved to scalar registers
 __device__ __forceinline__ double wave_uniform(double x)
@@ -421,7 +439,7 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 // The per-level constants (weights of the interface means, 1 / dsigma, sigma_vb, diffusion coefficient: p.mom_c,
 // formed by the library when the vertical grid is set) are wave-uniform scalar loads: they use neither LDS nor vmcnt.
 template <bool OLD_IS_CUR, int TJ, bool FROM_WINDS, bool TURB = false, int DEPTH = 1>
-__global__ __launch_bounds__(FTI *TJ) void k_momentum_dma(Geo g, Ptrs p, int gbx, MomPlan plan, int jv_lo,
+__global__ __launch_bounds__(FTI *TJ, (TJ <= 4 ? 2 : 1)) void k_momentum_dma(Geo g, Ptrs p, int gbx, MomPlan plan, int jv_lo,
                                                       const real *u_old, const real *v_old,
                                                       real *u_out, real *v_out, real dt)
 {
@@ -439,7 +457,9 @@ __global__ __launch_bounds__(FTI *TJ) void k_momentum_dma(Geo g, Ptrs p, int gbx
     constexpr int NS = DEPTH + 1;                                       // slots of the DMA ring
     constexpr int DSLOT = mom_dma_slot(TJ, FROM_WINDS, OLD_IS_CUR), FSLOT = mom_flux_slot(TJ, FROM_WINDS);
     constexpr int OFF_OLD = mom_off(FNF, TJ, FROM_WINDS);
-    static_assert(NSL + 2 <= TJ, "not enough wavefronts for the DMA slices");
+    // the step-start tiles: two wavefronts of their own (8 rows), or one slice more for the first 2 ONSL wavefronts (4 rows)
+    constexpr bool OLD_SHARED = NSL + 2 > TJ;
+    static_assert(NSL <= TJ && 2 * ONSL <= TJ, "not enough wavefronts for the DMA slices");
     extern __shared__ __attribute__((aligned(16))) real dsm[];
     // workgroup -> (tile, level chunk): `ksplit` chunks of the k range per tile give a small
     // latitude band enough workgroups to balance over the CUs (one tile per CU otherwise)
@@ -472,10 +492,11 @@ __global__ __launch_bounds__(FTI *TJ) void k_momentum_dma(Geo g, Ptrs p, int gbx
     }
     // a slice of a step-start tile = VW rows of OCPR chunks (16 B each, i0 is 16-B aligned): lane -> (row, column)
     const int orow = lane / OCPR, ocol = i0 + VW * (lane % OCPR);
-    if (!OLD_IS_CUR && wave >= TJ - 2) n_issue = ONSL;
+    if (!OLD_IS_CUR && !OLD_SHARED && wave >= TJ - 2) n_issue = ONSL;
+    if (!OLD_IS_CUR && OLD_SHARED && wave < 2 * ONSL) n_issue++;
     const real *src[FNF] = {p.UFLX, p.VFLX, p.UWIND, p.VWIND, p.WWIND, p.PHI, p.POTT, p.PVTF, p.PVTFVB};
     const int kofs[FNF] = {0, 0, 0, 0, 1, 0, 0, 0, 1};
-    const real *osrc = (wave == TJ - 2) ? u_old : v_old;
+    const real *osrc = OLD_SHARED ? (wave < ONSL ? u_old : v_old) : ((wave == TJ - 2) ? u_old : v_old);
 
     auto issue = [&](int k, int slot) {
         real *buf = dsm + slot * DSLOT;
@@ -485,16 +506,22 @@ __global__ __launch_bounds__(FTI *TJ) void k_momentum_dma(Geo g, Ptrs p, int gbx
                 for (int f = (FROM_WINDS ? 2 : 0); f < FNF; f++) {
                     if (ch < mom_rows(f, TJ, FROM_WINDS) * CPR) {
                         const real *gp = src[f] + (size_t)(k + kofs[f]) * g.plane + goff;
-                        __builtin_amdgcn_global_load_lds((gbl_void_t *)gp, (lds_void_t *)(buf + mom_off(f, TJ, FROM_WINDS) + wave * 64 * VW), 16, 0, DYC_DMA_AUX);
+                        lds_dma16(gp, buf + mom_off(f, TJ, FROM_WINDS) + wave * 64 * VW);
                     }
                 }
+            }
+        }
+        if (!OLD_IS_CUR && OLD_SHARED) {
+            if (wave < 2 * ONSL) {          // slice wave % ONSL of tile wave / ONSL: consecutive wavefronts, consecutive LDS
+                const real *gp = osrc + (size_t)k * g.plane + min(j0 + VW * (wave % ONSL) + orow, g.NJ - 1) * P + ocol;
+                lds_dma16(gp, buf + OFF_OLD + wave * 64 * VW);
             }
         } else if (!OLD_IS_CUR && wave >= TJ - 2) {
             real *ob = buf + OFF_OLD + (wave - (TJ - 2)) * ON;
 #pragma unroll
             for (int s5 = 0; s5 < ONSL; s5++) {
                 const real *gp = osrc + (size_t)k * g.plane + min(j0 + VW * s5 + orow, g.NJ - 1) * P + ocol;
-                __builtin_amdgcn_global_load_lds((gbl_void_t *)gp, (lds_void_t *)(ob + s5 * 64 * VW), 16, 0, DYC_DMA_AUX);
+                lds_dma16(gp, ob + s5 * 64 * VW);
             }
         }
     };
@@ -1194,7 +1221,9 @@ __global__ __launch_bounds__(TI *TJ) void k_pott_fused(Geo g, Ptrs p, const real
         const real p_km12 = dl.p_km12, pvb_k = dl.pvb_k, pvtf = dl.pvtf, phi = dl.phi, phivb = dl.phivb;
         if (WRITE_PVTF) stb(p.PVTF, q, pvtf);
         stb(p.PVTFVB, q, pvb_k);
+#ifndef DYC_POTT_NOPHI      // experiment builds only (wrong results)
         stb(p.PHI, q, phi);
+#endif
         if (WRITE_PHIVB) stb(p.PHIVB, q, phivb);
         if (k < nz - 1) {
             const real vb = pottvb_between(pvb_kp1, pvtf, pott, pvtf_kp1, pottn_kp1);

@@ -149,3 +149,14 @@ def test_bench_self_launch_command_and_no_gpu_touch(monkeypatch):
     assert cmd[1:3] == ['-m', 'torch.distributed.run'] and '--nproc-per-node' in cmd and cmd[cmd.index('--nproc-per-node') + 1] == '4'
     assert cmd[cmd.index('--master-addr') + 1] == '127.0.0.1'
     assert cmd[-4:] == ['--gpus', '4', '--steps', '2'] and cmd[-5].endswith('bench.py')
+
+
+def test_momentum_level_loop_has_no_compiler_inserted_drain():
+    """The LDS-DMA momentum kernel counts its own DMA instructions; a compiler-inserted `s_waitcnt vmcnt` (or a spill)
+    inside its level loop drains the levels in flight and costs ~10 % of the kernel without changing a result, so only
+    the ISA shows it (profiles/r02_notes.md).  tools/check_mom_isa.py compiles the device code to assembly (no GPU) and
+    returns 1 on a finding in a production instance."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'check_mom_isa.py')], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if 'fw=1 turb=0' in l]
+    assert len(lines) >= 6 and all('findings: none' in l for l in lines), r.stdout

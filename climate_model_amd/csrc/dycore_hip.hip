@@ -142,7 +142,12 @@ struct dycore {
     bool fused_turb = true;         // DYCORE_FUSED_TURB=0: a turbulence-coupled handle steps on the stage kernels
     int fw_mask = 7;                // DYCORE_FW_MASK (debug): 1 continuity stores no fluxes, 2 momentum, 4 temperature/moisture re-form them
     bool lazy_flx = true;           // ... nor UFLX / VFLX: consumers re-form them from the winds (DYCORE_LAZY_FLX=0: store them)
-    bool stale_flxdiv = false, stale_phivb = false, stale_uvflx = false, stale_pvtf = false;
+    bool stale_flxdiv = false, stale_phivb = false, stale_uvflx = false, stale_pvtf = false, stale_phi = false;
+    // ... nor PHI (DYCORE_LAZY_PHI=1; off by default): the LDS-DMA momentum kernel carries it up the column from the surface
+    // geopotential and k_pott_fused stores PHIVB at every 4th interface only.  -2.3 % per step, but a level chunk then
+    // starts from a stored PHIVB while an unchunked column carries its own (1 ulp apart): results depend on the work
+    // list and on the band decomposition at rounding level, which the default does not (profiles/r02_notes.md)
+    bool lazy_phi = false;
     bool lazy_pvtf = true;          // ... nor PVTF (DYCORE_LAZY_PVTF=0: store it); only where the momentum kernel forms its own (flux_from_winds, no i_turb)
     const real *flx_u = nullptr, *flx_v = nullptr;   // winds the last fused continuity evaluated on
     bool winds_bc_dirty = true;     // UWIND / VWIND came from the host: their lateral BC images (column nx+2!) may be unset
@@ -231,7 +236,7 @@ int check_ready(dycore *h)
 }
 
 int join_side(dycore *h);
-enum { LAZY_FLX = 1, LAZY_FLXDIV = 2, LAZY_PHIVB = 4, LAZY_PVTF = 8, LAZY_ALL = 15 };
+enum { LAZY_FLX = 1, LAZY_FLXDIV = 2, LAZY_PHIVB = 4, LAZY_PVTF = 8, LAZY_PHI = 16, LAZY_ALL = 31 };
 int refresh_lazy(dycore *h, int need = LAZY_ALL);
 // stage entry points read what the side stream may still be writing and what the fused step
 // left to be derived (`need`: which of the derived fields the stage reads)
@@ -345,7 +350,7 @@ int do_diag(dycore *h, const Ptrs &p)
 {
     Scope s(h, K_DIAG);
     hipLaunchKernelGGL(k_primary_diag, grid_for(h->g, h->g.nx + 2, h->g.ny + 2), dim3(TI, TJ), 0, h->stream, h->g, p);
-    if (&p == &h->p || p.PVTF == h->p.PVTF) { h->stale_pvtf = false; h->stale_phivb = false; }      // it writes both, whole array
+    if (&p == &h->p || p.PVTF == h->p.PVTF) { h->stale_pvtf = false; h->stale_phivb = false; h->stale_phi = false; }      // it writes all three, whole array
     return launch_check("k_primary_diag");
 }
 int do_rho(dycore *h, const Ptrs &p)
@@ -393,6 +398,9 @@ bool pvtf_on_demand(const dycore *h)
 {
     return h->lazy && h->lazy_pvtf && !h->g.i_turb && flux_from_winds(h) && h->fw_mask == 7;
 }
+// ... and PHI: the same momentum kernel carries it up the column from the surface geopotential (its level chunks start
+// from the PHIVB planes k_pott_fused stores at every PHIVB_STRIDE-th interface)
+bool phi_on_demand(const dycore *h) { return pvtf_on_demand(h) && h->lazy_phi && h->mom_tj == 4; }      // (the 64 x 8 tiles have no registers left for it)
 int do_continuity_fused(dycore *h, const Ptrs &p, real dt)
 {
     const int nz = h->g.nz;
@@ -435,10 +443,12 @@ int do_continuity_fused(dycore *h, const Ptrs &p, real dt)
 int refresh_lazy(dycore *h, int need)
 {
     if (need & LAZY_FLXDIV) need |= LAZY_FLX;          // FLXDIV is derived from UFLX, VFLX
-    if ((need & LAZY_PHIVB) && h->stale_phivb) need |= LAZY_PVTF;      // PHIVB from PHI, POTT, PVTFVB and PVTF
+    if ((need & LAZY_PHIVB) && h->stale_phivb && h->stale_phi) need |= LAZY_PHI;      // k_derive_phi writes PHI and PHIVB
+    if ((need & LAZY_PHIVB) && h->stale_phivb && !(need & LAZY_PHI)) need |= LAZY_PVTF;      // PHIVB from PHI, POTT, PVTFVB and PVTF
+    const bool d_phi = h->stale_phi && (need & LAZY_PHI);
     const bool d_flx = h->stale_uvflx && (need & LAZY_FLX), d_div = h->stale_flxdiv && (need & LAZY_FLXDIV),
-               d_phivb = h->stale_phivb && (need & LAZY_PHIVB), d_pvtf = h->stale_pvtf && (need & LAZY_PVTF);
-    if (!d_flx && !d_div && !d_phivb && !d_pvtf) return 0;
+               d_phivb = h->stale_phivb && (need & LAZY_PHIVB) && !d_phi, d_pvtf = h->stale_pvtf && (need & LAZY_PVTF);
+    if (!d_flx && !d_div && !d_phivb && !d_pvtf && !d_phi) return 0;
     int rc = join_side(h);
     if (rc) return rc;
     Scope s(h, K_DERIVE);
@@ -457,6 +467,12 @@ int refresh_lazy(dycore *h, int need)
         hipLaunchKernelGGL(k_derive_pvtf, grid_for(h->g, h->g.nx + 2, h->g.ny + 2), dim3(TI, TJ), 0, h->stream, h->g, h->p);
         if ((rc = launch_check("k_derive_pvtf"))) return rc;
         h->stale_pvtf = false;
+    }
+    if (d_phi) {
+        hipLaunchKernelGGL(k_derive_phi, grid_for(h->g, h->g.nx + 2, h->g.ny + 2), dim3(TI, TJ), 0, h->stream, h->g, h->p);
+        if ((rc = launch_check("k_derive_phi"))) return rc;
+        h->stale_phi = false;
+        h->stale_phivb = false;
     }
     if (d_phivb) {
         hipLaunchKernelGGL(k_derive_phivb, grid_for(h->g, h->g.nx + 2, h->g.ny + 2), dim3(TI, TJ), 0, h->stream, h->g, h->p);
@@ -492,8 +508,8 @@ int do_momentum_fused(dycore *h, const Ptrs &p, const real *u_old, const real *v
         if (mode == ROWS_INNER) return 0;
         mode = ROWS_ALL;
     }
-    if (!(dma && flux_from_winds(h) && (h->fw_mask & 2))) {       // every other momentum kernel reads the stored PVTF
-        int rc = refresh_lazy(h, LAZY_PVTF);
+    if (!(dma && flux_from_winds(h) && (h->fw_mask & 2))) {       // every other momentum kernel reads the stored PVTF (and PHI)
+        int rc = refresh_lazy(h, LAZY_PVTF | LAZY_PHI);
         if (rc) return rc;
     }
     Scope s(h, dma ? K_MOM_DMA : K_MOM_FUSED);      // stats under the name of the kernel that runs
@@ -539,20 +555,22 @@ int do_momentum_fused(dycore *h, const Ptrs &p, const real *u_old, const real *v
             double best = -1.0;
             // any number of chunks up to 16 (chunk kc covers levels [kc nz / ks, (kc + 1) nz / ks)); a chunk of fewer
             // than 4 levels is all prologue
+            const int nzb = (h->g.nz + PHIVB_STRIDE - 1) / PHIVB_STRIDE;     // level chunks are whole blocks of PHIVB_STRIDE levels (k_momentum_dma)
+            auto chunk_levels = [&](int cand) { return (double)std::min(h->g.nz, PHIVB_STRIDE * ((nzb + cand - 1) / cand)); };
             for (int cand = 1; cand <= 16; cand++) {
-                if (h->g.nz / cand < 4) break;
-                const double cost = rounds(tiles * cand) * (ceil((double)h->g.nz / cand) + (cand > 1 ? pro : 0.0));
+                if (cand > nzb) break;
+                const double cost = rounds(tiles * cand) * (chunk_levels(cand) + (cand > 1 ? pro : 0.0));
                 if (best < 0 || cost < best - 1e-9) { best = cost; plan.ks_a = cand; }
             }
-            if (h->mom_ks) plan.ks_a = h->mom_ks;
+            if (h->mom_ks) plan.ks_a = std::min(h->mom_ks, nzb);
             const long full = tiles / slots;              // whole rounds of full tiles
             if (h->mom_split && !h->mom_ks && trows.gap == 0 && full >= 1 && tiles % slots) {
                 const int r1 = (int)(full * slots / gbx);       // tile rows inside those rounds
                 const int r2 = trows.n - r1;
                 if (r1 >= 1 && r2 >= 1) {
                     for (int cand = 1; cand <= 16; cand++) {
-                        if (h->g.nz / cand < 4) break;
-                        const double cost = rounds((long)gbx * r1) * h->g.nz + rounds((long)gbx * r2 * cand) * (ceil((double)h->g.nz / cand) + (cand > 1 ? pro : 0.0));
+                        if (cand > nzb) break;
+                        const double cost = rounds((long)gbx * r1) * h->g.nz + rounds((long)gbx * r2 * cand) * (chunk_levels(cand) + (cand > 1 ? pro : 0.0));
                         if (cost < best - 1e-9) {
                             best = cost;
                             plan.a = {trows.first, r1, r1, 0}; plan.ks_a = 1;
@@ -567,14 +585,18 @@ int do_momentum_fused(dycore *h, const Ptrs &p, const real *u_old, const real *v
         const bool cur = (u_old == p.UWIND);
         const bool fw = flux_from_winds(h) && (h->fw_mask & 2);
         // ring depth: two levels in flight for the production (dry / moist, fluxes from the winds) instances
-#define MOM_LAUNCH_T(CUR_, TJ_, FW_, TB_, DP_) hipLaunchKernelGGL((k_momentum_dma<CUR_, TJ_, FW_, TB_, DP_>), gr2, blk, dma_lds_bytes(TJ_, FW_, CUR_, DP_), h->stream, h->g, p, gbx, plan, jv_lo, u_old, v_old, u_out, v_out, dt)
+#define MOM_LAUNCH_P(CUR_, TJ_, FW_, TB_, DP_, PL_) hipLaunchKernelGGL((k_momentum_dma<CUR_, TJ_, FW_, TB_, DP_, PL_>), gr2, blk, dma_lds_bytes(TJ_, FW_, CUR_, DP_, PL_), h->stream, h->g, p, gbx, plan, jv_lo, u_old, v_old, u_out, v_out, dt)
+#define MOM_LAUNCH_T(CUR_, TJ_, FW_, TB_, DP_) MOM_LAUNCH_P(CUR_, TJ_, FW_, TB_, DP_, false)
 #define MOM_LAUNCH(CUR_, FW_, TB_, DP_) MOM_LAUNCH_T(CUR_, FTJ, FW_, TB_, DP_)
-        if (half) { if (!cur) MOM_LAUNCH_T(false, 4, true, false, 1); else if (h->mom_depth == 2) MOM_LAUNCH_T(true, 4, true, false, 2); else MOM_LAUNCH_T(true, 4, true, false, 1); }
+        const bool pl = phi_on_demand(h);
+        if (half && pl) { if (!cur) MOM_LAUNCH_P(false, 4, true, false, 1, true); else if (h->mom_depth == 2) MOM_LAUNCH_P(true, 4, true, false, 2, true); else MOM_LAUNCH_P(true, 4, true, false, 1, true); }
+        else if (half) { if (!cur) MOM_LAUNCH_T(false, 4, true, false, 1); else if (h->mom_depth == 2) MOM_LAUNCH_T(true, 4, true, false, 2); else MOM_LAUNCH_T(true, 4, true, false, 1); }
         else if (h->g.i_turb) { if (cur) MOM_LAUNCH(true, true, true, 1); else MOM_LAUNCH(false, true, true, 1); }
         else if (cur) { if (!fw) MOM_LAUNCH(true, false, false, 1); else if (h->mom_depth == 2) MOM_LAUNCH(true, true, false, 2); else MOM_LAUNCH(true, true, false, 1); }
         else { if (!fw) MOM_LAUNCH(false, false, false, 1); else if (h->mom_depth == 2) MOM_LAUNCH(false, true, false, 2); else MOM_LAUNCH(false, true, false, 1); }
 #undef MOM_LAUNCH
 #undef MOM_LAUNCH_T
+#undef MOM_LAUNCH_P
     } else if (u_out)
         hipLaunchKernelGGL(k_momentum_fused<true>, gr, bl, 0, h->stream, h->g, p, gbx, gby, jv_lo, u_old, v_old, u_out, v_out, dt);
     else
@@ -586,17 +608,20 @@ int do_pott_fused(dycore *h, const Ptrs &p, const real *pott_old, real *pott_out
     Scope s(h, K_POTT_FUSED);
     const dim3 gr = grid_cells(h), bl(TI, TJ);
     const int lin = cells_linear(h);
-#define POTT_LAUNCH(W_, F_, T_, V_) hipLaunchKernelGGL((k_pott_fused<W_, F_, T_, V_>), gr, bl, 0, h->stream, h->g, p, pott_old, pott_out, dt, lin)
+#define POTT_LAUNCH_P(W_, F_, T_, V_, P_) hipLaunchKernelGGL((k_pott_fused<W_, F_, T_, V_, P_>), gr, bl, 0, h->stream, h->g, p, pott_old, pott_out, dt, lin)
+#define POTT_LAUNCH(W_, F_, T_, V_) POTT_LAUNCH_P(W_, F_, T_, V_, true)
     if (h->g.i_turb) {                  // fused turbulence-coupled step: PHIVB is an input of k_turb_tendencies, so it is stored
         POTT_LAUNCH(true, true, true, true);
     } else if (h->lazy) {
-        if (pvtf_on_demand(h)) { POTT_LAUNCH(false, true, false, false); h->stale_pvtf = true; }
+        if (phi_on_demand(h)) { POTT_LAUNCH_P(false, true, false, false, false); h->stale_pvtf = true; h->stale_phi = true; }
+        else if (pvtf_on_demand(h)) { POTT_LAUNCH(false, true, false, false); h->stale_pvtf = true; }
         else if (flux_from_winds(h) && (h->fw_mask & 4)) POTT_LAUNCH(false, true, false, true);
         else POTT_LAUNCH(false, false, false, true);
         h->stale_phivb = true;
     } else
         POTT_LAUNCH(true, false, false, true);
 #undef POTT_LAUNCH
+#undef POTT_LAUNCH_P
     return launch_check("k_pott_fused");
 }
 // the turbulent tendencies of the fused turbulence-coupled step (one launch per substep)
@@ -765,7 +790,8 @@ int substep_part(dycore *h, real dt, int sub, int part)
             if (h->g.i_moist && (rc = do_moist(h, q, p.QV, p.QC, qv_out, qc_out, dt))) return rc;
             const int nz = h->g.nz;
             if (h->g.i_moist && (rc = do_halo(h, {{qv_out, 0, 0, nz}, {qc_out, 0, 0, nz}}))) return rc;
-            std::vector<HaloSpec> hl = {{t_out, 0, 0, nz}, {p.PVTFVB, 0, 0, nz + 1}, {p.PHI, 0, 0, nz}, {p.POTTVB, 0, 0, nz + 1}};
+            std::vector<HaloSpec> hl = {{t_out, 0, 0, nz}, {p.PVTFVB, 0, 0, nz + 1}, {p.POTTVB, 0, 0, nz + 1}};
+            if (!phi_on_demand(h)) hl.push_back({p.PHI, 0, 0, nz});
             if (!pvtf_on_demand(h)) hl.push_back({p.PVTF, 0, 0, nz});
             if (!h->lazy || h->g.i_turb) hl.push_back({p.PHIVB, 0, 0, nz + 1});
             hl.push_back({u_out, 1, 0, nz});   // owned rows and pole rows only: rows in flight from a neighbour are not touched
@@ -854,6 +880,7 @@ int dycore_create(const DycoreConfig *cfg, dycore_t **out)
     if (const char *e = getenv("DYCORE_LAZY")) h->lazy = atoi(e) != 0;
     if (const char *e = getenv("DYCORE_LAZY_FLX")) h->lazy_flx = atoi(e) != 0;
     if (const char *e = getenv("DYCORE_LAZY_PVTF")) h->lazy_pvtf = atoi(e) != 0;
+    if (const char *e = getenv("DYCORE_LAZY_PHI")) h->lazy_phi = atoi(e) != 0;
     if (const char *e = getenv("DYCORE_FUSED_TURB")) h->fused_turb = atoi(e) != 0;
     if (const char *e = getenv("DYCORE_FW_MASK")) h->fw_mask = atoi(e);
     if (const char *e = getenv("DYCORE_MOM_KS")) h->mom_ks = atoi(e);
@@ -869,9 +896,13 @@ int dycore_create(const DycoreConfig *cfg, dycore_t **out)
     }
     {   // the LDS-DMA kernel keeps up to 155 KB of tiles in LDS: raise the dynamic-LDS limit of every instantiation once
         bool ok_plain = true, ok_fw = true, ok_deep = true, ok_half = true;
-#define MOM_ATTR_T(CUR_, TJ_, FW_, TB_, DP_, FLAG_)                                                                   \
-        if (hipFuncSetAttribute((const void *)k_momentum_dma<CUR_, TJ_, FW_, TB_, DP_>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                (int)dma_lds_bytes(TJ_, FW_, CUR_, DP_)) != hipSuccess) { (void)hipGetLastError(); FLAG_ = false; }
+#define MOM_ATTR_P(CUR_, TJ_, FW_, TB_, DP_, PL_, FLAG_)                                                              \
+        if (hipFuncSetAttribute((const void *)k_momentum_dma<CUR_, TJ_, FW_, TB_, DP_, PL_>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                (int)dma_lds_bytes(TJ_, FW_, CUR_, DP_, PL_)) != hipSuccess) { (void)hipGetLastError(); FLAG_ = false; }
+#define MOM_ATTR_T(CUR_, TJ_, FW_, TB_, DP_, FLAG_) MOM_ATTR_P(CUR_, TJ_, FW_, TB_, DP_, false, FLAG_)
+        bool ok_pl = true;
+        MOM_ATTR_P(true, 4, true, false, 1, true, ok_pl) MOM_ATTR_P(true, 4, true, false, 2, true, ok_pl) MOM_ATTR_P(false, 4, true, false, 1, true, ok_pl)
+        if (!ok_pl) h->lazy_phi = false;
 #define MOM_ATTR(CUR_, FW_, TB_, DP_, FLAG_) MOM_ATTR_T(CUR_, FTJ, FW_, TB_, DP_, FLAG_)
         MOM_ATTR_T(true, 4, true, false, 1, ok_half) MOM_ATTR_T(true, 4, true, false, 2, ok_half) MOM_ATTR_T(false, 4, true, false, 1, ok_half)
         MOM_ATTR(true, false, false, 1, ok_plain) MOM_ATTR(false, false, false, 1, ok_plain)
@@ -880,6 +911,7 @@ int dycore_create(const DycoreConfig *cfg, dycore_t **out)
         MOM_ATTR(true, true, false, 2, ok_deep) MOM_ATTR(false, true, false, 2, ok_deep)
 #undef MOM_ATTR
 #undef MOM_ATTR_T
+#undef MOM_ATTR_P
         if (!ok_plain) h->mom_dma = 0;
         if (!ok_fw) h->lazy_flx = false;
         if (!ok_deep) h->mom_depth = 1;
@@ -1103,7 +1135,7 @@ int dycore_upload(dycore_t *h, const char *name, const real *host)
     if (rc) return rc;
     if (!host) return fail(DYCORE_EINVAL, "null host pointer");
     if (d->member == &Ptrs::UWIND || d->member == &Ptrs::VWIND) h->winds_bc_dirty = true;
-    if (d->member == &Ptrs::UFLX || d->member == &Ptrs::VFLX || d->member == &Ptrs::FLXDIV || d->member == &Ptrs::PHIVB || d->member == &Ptrs::PVTF)
+    if (d->member == &Ptrs::UFLX || d->member == &Ptrs::VFLX || d->member == &Ptrs::FLXDIV || d->member == &Ptrs::PHIVB || d->member == &Ptrs::PVTF || d->member == &Ptrs::PHI)
         if ((rc = refresh_lazy(h))) return rc;      // a caller's value must not be overwritten by a later derivation
     const Geo &g = h->g;
     const int n0 = g.nx + 2 + d->stgx, n1 = g.ny + 2 + d->stgy, n2 = h->nk_of(d->nk);
@@ -1123,6 +1155,7 @@ static int lazy_need(const FieldDesc *d)
     if (d->member == &Ptrs::FLXDIV) return LAZY_FLXDIV;
     if (d->member == &Ptrs::PHIVB) return LAZY_PHIVB;
     if (d->member == &Ptrs::PVTF) return LAZY_PVTF;
+    if (d->member == &Ptrs::PHI) return LAZY_PHI;
     return 0;
 }
 
@@ -1195,13 +1228,13 @@ int dycore_euler_forward(dycore_t *h, double dt) { int rc = ready_join(h); retur
 int dycore_primary_diag(dycore_t *h) { int rc = ready_join(h); return rc ? rc : do_diag(h, h->p); }
 int dycore_secondary_diag_rho(dycore_t *h) { int rc = ready_join(h, LAZY_PVTF); return rc ? rc : do_rho(h, h->p); }
 int dycore_secondary_diag(dycore_t *h) { int rc = ready_join(h, LAZY_PVTF); return rc ? rc : do_secondary(h, h->p); }
-int dycore_compute_turbulence(dycore_t *h) { int rc = ready_join(h, LAZY_PHIVB); return rc ? rc : do_turbulence(h, h->p); }
+int dycore_compute_turbulence(dycore_t *h) { int rc = ready_join(h, LAZY_PHIVB | LAZY_PHI); return rc ? rc : do_turbulence(h, h->p); }
 
 int dycore_radiation(dycore_t *h, double solar_constant, int32_t nbins, const double *lambdas_center, const double *dlambdas)
 {
     if (!h) return fail(DYCORE_EINVAL, "null handle");
     if (!h->g.i_rad) return fail(DYCORE_ESTATE, "handle created without i_radiation");
-    int rc = ready_join(h, LAZY_PHIVB);
+    int rc = ready_join(h, LAZY_PHIVB | LAZY_PHI);
     if (rc) return rc;
     if (!lambdas_center || !dlambdas || nbins < 1 || nbins > RAD_MAX_BINS)
         return fail(DYCORE_EINVAL, "need 1..%d spectral bins", RAD_MAX_BINS);

@@ -338,6 +338,7 @@ __global__ __launch_bounds__(FNT) void k_momentum_fused(Geo g, Ptrs p, int gbx, 
 // `s_waitcnt vmcnt(n)` with n = the instructions this wave issued for level k+2 means "my part of level k+1
 // has landed" while level k+2 stays in flight.  The two stores of an iteration are issued BEFORE that
 // iteration's DMA, so they are older than it and the count is exact.
+constexpr int PHIVB_STRIDE = 4;                  // k_pott_fused stores PHIVB at every 4th interface when PHI is not stored (chunks of the momentum kernel start there)
 constexpr int DMAXZ = 160;                        // levels up to which the LDS-DMA kernel is used (beyond: k_momentum_fused)
 
 // Tile rows a staged field needs from row j0-1 on: UFLX, UWIND, WWIND j-1..j+1 (TJ+2 rows), VFLX (and VWIND
@@ -349,33 +350,31 @@ constexpr int DMAXZ = 160;                        // levels up to which the LDS-
 // through the DMA per level.  The kernel's time is its data movement (profiles/r02_notes.md), the arithmetic
 // rides along.  The quotient differs from the stored PVTF by the rounding of p[k+1] - p[k] (~4e-15 relative).
 enum { S_UF = 0, S_VF, S_UW, S_VW, S_W, S_PHI, S_POTT, S_PVTF, S_PVB };
-constexpr int mom_rows(int f, int tj, bool fw)
+constexpr int mom_rows(int f, int tj, bool fw, bool pl = false)
 {
 #ifdef DYC_MOM_NOHALO       // experiment builds only (wrong results): no halo rows staged
     return tj;
 #endif
     if (f == S_PVTF && fw) return 0;        // formed in the thread from PVTFVB and the column pressure (below)
-#ifdef DYC_MOM_NOPHI       // experiment builds only (wrong results): PHI not staged
-    if (f == S_PHI && fw) return 0;
-#endif
+    if (f == S_PHI && pl) return 0;         // `pl` (PHI_LOCAL): carried up the column by the thread (below)
     return f == S_UF ? tj + 2 : f == S_VF ? tj + 3 : f == S_UW ? tj + 2 : f == S_VW ? (fw ? tj + 3 : tj + 2) : f == S_W ? tj + 2 : tj + 1;
 }
 // LDS layout (doubles).  A DMA slot holds the staged fields of one level back to back (each rows x FTW), then the
 // two step-start tiles of the corrector (tj rows each); with `fw` (fluxes re-formed from the winds) UFLX / VFLX
 // are not staged: they live in their own two-slot ring, written by the DMA wavefronts (flux_own).
-constexpr int mom_off(int f, int tj, bool fw)     // offset of field f inside its slot; f = FNF: the step-start tiles
+constexpr int mom_off(int f, int tj, bool fw, bool pl = false)     // offset of field f inside its slot; f = FNF: the step-start tiles
 {
     if (fw && f < 2) return f == S_UF ? 0 : (tj + 2) * FTW;
     int o = 0;
-    for (int g = (fw ? 2 : 0); g < f; g++) o += mom_rows(g, tj, fw) * FTW;
+    for (int g = (fw ? 2 : 0); g < f; g++) o += mom_rows(g, tj, fw, pl) * FTW;
     return o;
 }
-constexpr int mom_dma_slot(int tj, bool fw, bool cur) { return mom_off(FNF, tj, fw) + (cur ? 0 : 2 * FTI * tj); }   // step-start tiles: own cells only, FTI wide
+constexpr int mom_dma_slot(int tj, bool fw, bool cur, bool pl = false) { return mom_off(FNF, tj, fw, pl) + (cur ? 0 : 2 * FTI * tj); }   // step-start tiles: own cells only, FTI wide
 constexpr int mom_flux_slot(int tj, bool fw) { return fw ? (2 * tj + 5) * FTW : 0; }
 // ... then (fw) two factor tiles, dyis (tj+2 rows) and dxjs (tj+3 rows), shaped like the UFLX / VFLX tiles
-constexpr size_t dma_lds_bytes(int tj, bool fw, bool cur, int depth)
+constexpr size_t dma_lds_bytes(int tj, bool fw, bool cur, int depth, bool pl = false)
 {
-    return ((size_t)(depth + 1) * mom_dma_slot(tj, fw, cur) + 3 * (size_t)mom_flux_slot(tj, fw)) * sizeof(real);
+    return ((size_t)(depth + 1) * mom_dma_slot(tj, fw, cur, pl) + 3 * (size_t)mom_flux_slot(tj, fw)) * sizeof(real);
 }
 
 #ifndef DYC_DMA_AUX
@@ -424,6 +423,22 @@ __device__ __forceinline__ void wait_vmcnt(int n)
     default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
     }
 }
+// Expressions that k_momentum_dma evaluates at two places -- inside the level loop, and in the prologue / epilogue of a
+// level chunk for the interface the chunk shares with its neighbour -- with the contraction to FMA written out: left
+// to the compiler, a0*b0 + a1*b1 may become fma(a0, b0, a1*b1) at one place and fma(a1, b1, a0*b0) at the other, and the
+// result of a step would depend on how the work list cuts the columns (one element in 6e7 did, by one ulp).
+__device__ __forceinline__ real mul_rn(real a, real b)
+{
+#pragma clang fp contract(off)
+    return a * b;
+}
+__device__ __forceinline__ real mix2(real a, real x, real b, real y) { return fma(a, x, mul_rn(b, y)); }
+__device__ __forceinline__ real dot6(const real (&w)[6], real x0, real x1, real x2, real x3, real x4, real x5)
+{
+    real s = mul_rn(w[0], x0);
+    s = fma(w[1], x1, s); s = fma(w[2], x2, s); s = fma(w[3], x3, s); s = fma(w[4], x4, s);
+    return fma(w[5], x5, s);
+}
 // workgroup barrier that publishes this wave's LDS writes but leaves its vector-memory operations in flight
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
@@ -438,13 +453,16 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 // registers) join the sums; DEPTH = 1 (the compiler's own waits for those loads drain the DMA anyway).
 // The per-level constants (weights of the interface means, 1 / dsigma, sigma_vb, diffusion coefficient: p.mom_c,
 // formed by the library when the vertical grid is set) are wave-uniform scalar loads: they use neither LDS nor vmcnt.
-template <bool OLD_IS_CUR, int TJ, bool FROM_WINDS, bool TURB = false, int DEPTH = 1>
+template <bool OLD_IS_CUR, int TJ, bool FROM_WINDS, bool TURB = false, int DEPTH = 1, bool PHI_LOCAL = false>
 __global__ __launch_bounds__(FTI *TJ, (TJ <= 4 ? 2 : 1)) void k_momentum_dma(Geo g, Ptrs p, int gbx, MomPlan plan, int jv_lo,
                                                       const real *u_old, const real *v_old,
                                                       real *u_out, real *v_out, real dt)
 {
     static_assert(DEPTH == 1 || DEPTH == 2, "ring of 2 or 3 slots");
     static_assert(!(TURB && DEPTH != 1), "the turbulence-coupled variant keeps vector loads in the loop");
+    static_assert(!PHI_LOCAL || FROM_WINDS, "PHI in the thread needs PVTF in the thread");
+#define MROWS(f) mom_rows(f, TJ, FROM_WINDS, PHI_LOCAL)
+#define MOFF(f) mom_off(f, TJ, FROM_WINDS, PHI_LOCAL)
     // segment of the work list this workgroup belongs to (MomPlan)
     const bool seg_b = (int)blockIdx.x >= plan.nblk_a;
     const RowSet trows = seg_b ? plan.b : plan.a;
@@ -455,8 +473,8 @@ __global__ __launch_bounds__(FTI *TJ, (TJ <= 4 ? 2 : 1)) void k_momentum_dma(Geo
     constexpr int ON = FTI * TJ, OCPR = FTI / VW, ONSL = ON / VW / 64;  // step-start ("old") tiles: own cells, FTI wide; 64-chunk slices
     static_assert(ON % (VW * 64) == 0, "whole slices");
     constexpr int NS = DEPTH + 1;                                       // slots of the DMA ring
-    constexpr int DSLOT = mom_dma_slot(TJ, FROM_WINDS, OLD_IS_CUR), FSLOT = mom_flux_slot(TJ, FROM_WINDS);
-    constexpr int OFF_OLD = mom_off(FNF, TJ, FROM_WINDS);
+    constexpr int DSLOT = mom_dma_slot(TJ, FROM_WINDS, OLD_IS_CUR, PHI_LOCAL), FSLOT = mom_flux_slot(TJ, FROM_WINDS);
+    constexpr int OFF_OLD = MOFF(FNF);
     // the step-start tiles: two wavefronts of their own (8 rows), or one slice more for the first 2 ONSL wavefronts (4 rows)
     constexpr bool OLD_SHARED = NSL + 2 > TJ;
     static_assert(NSL <= TJ && 2 * ONSL <= TJ, "not enough wavefronts for the DMA slices");
@@ -467,7 +485,10 @@ __global__ __launch_bounds__(FTI *TJ, (TJ <= 4 ? 2 : 1)) void k_momentum_dma(Geo
     if (!xcd_tile_at((int)blockIdx.x - (seg_b ? plan.nblk_a : 0), gbx, gby * ksplit, bx, by, ksplit == 1 ? plan.patch : 1)) return;
     const int kc = by / gby;
     by = rowset_row(trows, by - kc * gby);
-    const int k0 = (int)((long long)kc * g.nz / ksplit), k1 = (int)((long long)(kc + 1) * g.nz / ksplit);
+    // level chunks are whole blocks of PHIVB_STRIDE levels: a chunk starts its hydrostatic integration from a stored PHIVB plane
+    const int nzb = (g.nz + PHIVB_STRIDE - 1) / PHIVB_STRIDE;
+    const int k0 = min(g.nz, PHIVB_STRIDE * (int)((long long)kc * nzb / ksplit)), k1 = min(g.nz, PHIVB_STRIDE * (int)((long long)(kc + 1) * nzb / ksplit));
+    if (k1 <= k0) return;
     const int tx = threadIdx.x, ty = threadIdx.y;
     const int tid = ty * FTI + tx;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
@@ -488,14 +509,13 @@ __global__ __launch_bounds__(FTI *TJ, (TJ <= 4 ? 2 : 1)) void k_momentum_dma(Geo
         goff = min(j0 - 1 + r, g.NJ - 1) * P + min(i0 - FXO + c2, P - VW);
 #pragma unroll
         for (int f = (FROM_WINDS ? 2 : 0); f < FNF; f++)
-            if (wave * 64 < mom_rows(f, TJ, FROM_WINDS) * CPR) n_issue++;
+            if (wave * 64 < MROWS(f) * CPR) n_issue++;
     }
     // a slice of a step-start tile = VW rows of OCPR chunks (16 B each, i0 is 16-B aligned): lane -> (row, column)
     const int orow = lane / OCPR, ocol = i0 + VW * (lane % OCPR);
     if (!OLD_IS_CUR && !OLD_SHARED && wave >= TJ - 2) n_issue = ONSL;
     if (!OLD_IS_CUR && OLD_SHARED && wave < 2 * ONSL) n_issue++;
     const real *src[FNF] = {p.UFLX, p.VFLX, p.UWIND, p.VWIND, p.WWIND, p.PHI, p.POTT, p.PVTF, p.PVTFVB};
-    const int kofs[FNF] = {0, 0, 0, 0, 1, 0, 0, 0, 1};
     const real *osrc = OLD_SHARED ? (wave < ONSL ? u_old : v_old) : ((wave == TJ - 2) ? u_old : v_old);
 
     auto issue = [&](int k, int slot) {
@@ -504,9 +524,9 @@ __global__ __launch_bounds__(FTI *TJ, (TJ <= 4 ? 2 : 1)) void k_momentum_dma(Geo
             if (dma_on) {
 #pragma unroll
                 for (int f = (FROM_WINDS ? 2 : 0); f < FNF; f++) {
-                    if (ch < mom_rows(f, TJ, FROM_WINDS) * CPR) {
-                        const real *gp = src[f] + (size_t)(k + kofs[f]) * g.plane + goff;
-                        lds_dma16(gp, buf + mom_off(f, TJ, FROM_WINDS) + wave * 64 * VW);
+                    if (ch < MROWS(f) * CPR) {
+                        const real *gp = src[f] + (size_t)k * g.plane + goff;
+                        lds_dma16(gp, buf + MOFF(f) + wave * 64 * VW);
                     }
                 }
             }
@@ -606,27 +626,38 @@ __global__ __launch_bounds__(FTI *TJ, (TJ <= 4 ? 2 : 1)) void k_momentum_dma(Geo
     // ... and the pressure-weighted Euler step X_new = X_old * P_old / P + dt * dX / P (dyn_timestep.py:34-79) as
     // X_old * eu1 + dX * eu2 with eu1 = P_old * (1 / P), eu2 = dt * (1 / P) per column
     const real eu1 = cao_is * (1.0 / ca_is), eu2 = dt * (1.0 / ca_is), ev1 = cao_js * (1.0 / ca_js), ev2 = dt * (1.0 / ca_js);
-    const size_t c0 = c + (size_t)k0 * g.plane;
-    real pvb_k = p.PVTFVB[c0], pvb_im1_k = p.PVTFVB[c0 - 1], pvb_jm1_k = p.PVTFVB[c0 - P];
     // PVTF in the thread (FROM_WINDS): 1 / ((1 + kappa) COLP) at the own cell and its western / southern neighbour
     const real rcp_c = 1.0 / ((1.0 + CON_KAPPA) * colp), rcp_im1 = 1.0 / ((1.0 + CON_KAPPA) * colp_im1), rcp_jm1 = 1.0 / ((1.0 + CON_KAPPA) * colp_jm1);
 
     const int lx = tx + FXO, ly = ty + 1; // tile column 0 is longitude i0 - FXO (16-B aligned in HBM)
     // field f of the level being computed: `db` = its DMA slot, `fb` = its flux slot
-#define SM(f, a, b) ((FROM_WINDS && (f) < 2) ? fb : db)[mom_off(f, TJ, FROM_WINDS) + (ly + (b)) * FTW + (lx + (a))]
+#define SM(f, a, b) ((FROM_WINDS && (f) < 2) ? fb : db)[MOFF(f) + (ly + (b)) * FTW + (lx + (a))]
 
-    // carried across levels
-    real su_k = 0.0, sv_k = 0.0;          // six-point COLP_NEW*A*WWIND sums at interface k
-    real wu_km1 = 0.0, wv_km1 = 0.0;      // WWIND*U, WWIND*V at interface k-1
-    real u_km1 = 0.0, v_km1 = 0.0, uo_km1 = 0.0, vo_km1 = 0.0;
-    real tu_km1 = 0.0, tv_km1 = 0.0;      // tendencies of level k-1 without the vertical advection
-    if (k0 > 0) {       // a chunk that starts inside the column: interface k0 and the winds above it
-#define WG(a, b) p.WWIND[c0 + (b) * P + (a)]
-        su_k = wu[0] * WG(-1, 1) + wu[1] * WG(0, 1) + wu[2] * WG(-1, 0) + wu[3] * WG(0, 0) + wu[4] * WG(-1, -1) + wu[5] * WG(0, -1);
-        sv_k = wv[0] * WG(1, -1) + wv[1] * WG(1, 0) + wv[2] * WG(0, -1) + wv[3] * WG(0, 0) + wv[4] * WG(-1, -1) + wv[5] * WG(-1, 0);
+    // carried across levels.  The column is walked BOTTOM-UP (level k1-1 first), the direction of the hydrostatic
+    // integration, so that PHI can be carried along (PHI_LOCAL); the vertical advection of a level is closed one
+    // iteration late, when the winds of the level above it are at hand for its upper interface
+    real su_kp1 = 0.0, sv_kp1 = 0.0;      // six-point COLP_NEW*A*WWIND sums at interface k+1
+    real wu_b = 0.0, wv_b = 0.0;          // WWIND*U, WWIND*V at interface k+2 (0 at the surface)
+    real u_kp1 = 0.0, v_kp1 = 0.0, uo_kp1 = 0.0, vo_kp1 = 0.0;
+    real tu_kp1 = 0.0, tv_kp1 = 0.0;      // tendencies of level k+1 without the vertical advection
+    const size_t c1 = c + (size_t)k1 * g.plane;         // interface k1, the lower end of the chunk
+    real pvb_kp1 = p.PVTFVB[c1], pvb_im1_kp1 = p.PVTFVB[c1 - 1], pvb_jm1_kp1 = p.PVTFVB[c1 - P];
+    if (k1 < nz) {      // a chunk that ends inside the column: interface k1 and the winds below it
+#define WG(a, b) p.WWIND[c1 + (b) * P + (a)]
+        su_kp1 = dot6(wu, WG(-1, 1), WG(0, 1), WG(-1, 0), WG(0, 0), WG(-1, -1), WG(0, -1));
+        sv_kp1 = dot6(wv, WG(1, -1), WG(1, 0), WG(0, -1), WG(0, 0), WG(-1, -1), WG(-1, 0));
 #undef WG
-        u_km1 = p.UWIND[c0 - g.plane];
-        v_km1 = p.VWIND[c0 - g.plane];
+        u_kp1 = p.UWIND[c1];
+        v_kp1 = p.VWIND[c1];
+    }
+    // PHIVB at interface k1 of the own column and its western / southern neighbour: the surface geopotential, or
+    // (chunks) what k_pott_fused stored for every PHIVB_STRIDE-th interface.  The western neighbour of i = 1 is taken
+    // from its periodic image (misc_boundaries.py:22-31): nobody refreshes the lateral halo of those planes.
+    real phivb_c = 0.0, phivb_w = 0.0, phivb_s = 0.0;
+    if (PHI_LOCAL) {
+        const size_t cw = (active && i == 1) ? c - 1 + g.nx : c - 1;
+        if (k1 == nz) { phivb_c = p.HSURF[c] * CON_G; phivb_w = p.HSURF[cw] * CON_G; phivb_s = p.HSURF[c - P] * CON_G; }
+        else { const size_t o = (size_t)k1 * g.plane; phivb_c = p.PHIVB[c + o]; phivb_w = p.PHIVB[cw + o]; phivb_s = p.PHIVB[c - P + o]; }
     }
 
     // per-level constants (p.mom_c, stride nz + 2): weights c_wa[k], c_wb[k] of the winds of levels k-1 and k in the
@@ -681,36 +712,40 @@ __global__ __launch_bounds__(FTI *TJ, (TJ <= 4 ? 2 : 1)) void k_momentum_dma(Geo
             }
         }
     };
-    // ---- prologue: the first DEPTH levels go out; level k0 lands and its flux tiles are formed ----
-    issue(k0, 0);
-    if (DEPTH == 2 && k0 + 1 < k1) issue(k0 + 1, 1);
+    // the values loaded above are complete before the level loop starts: left to itself the compiler waits for them at
+    // their first use, inside the loop, where a vector-memory wait drains the DMA levels in flight
+    asm volatile("" : "+v"(su_kp1), "+v"(sv_kp1), "+v"(u_kp1), "+v"(v_kp1), "+v"(pvb_kp1), "+v"(pvb_im1_kp1), "+v"(pvb_jm1_kp1), "+v"(phivb_c), "+v"(phivb_w), "+v"(phivb_s));
+    // ---- prologue: the first DEPTH levels go out; level k1-1 lands and its flux tiles are formed ----
+    issue(k1 - 1, 0);
+    if (DEPTH == 2 && k1 - 2 >= k0) issue(k1 - 2, 1);
     real tbu_nx = 0.0, tbv_nx = 0.0;  // turbulent tendencies of the next level
-    if (TURB) { tbu_nx = p.TURB_U[c + (size_t)k0 * g.plane]; tbv_nx = v_on ? p.TURB_V[c + (size_t)k0 * g.plane] : 0.0; }
-    wait_vmcnt((DEPTH == 2 && k0 + 1 < k1) ? n_issue : 0);
-    flux_own(0, k0 & 1);
+    if (TURB) { tbu_nx = p.TURB_U[c + (size_t)(k1 - 1) * g.plane]; tbv_nx = v_on ? p.TURB_V[c + (size_t)(k1 - 1) * g.plane] : 0.0; }
+    wait_vmcnt((DEPTH == 2 && k1 - 2 >= k0) ? n_issue : 0);
+    flux_own(0, (k1 - 1) & 1);
     lds_barrier();
 #ifndef DYC_MOM_MODE
 #define DYC_MOM_MODE 0      // experiment builds only: 1 = data movement without the arithmetic, 2 = arithmetic without the data movement
 #endif
     int slot = 0;                       // ring slot of level k
 #pragma unroll 1
-    for (int k = k0; k < k1; k++) {
-        int slot1 = slot + 1;           // ... of level k+1
+    for (int k = k1 - 1; k >= k0; k--) {
+        int slot1 = slot + 1;           // ... of level k-1
         if (slot1 == NS) slot1 = 0;
-        // DEPTH 1: level k+1 goes out first thing.  DEPTH 2: level k+2 goes out after this iteration's two stores
+        // DEPTH 1: level k-1 goes out first thing.  DEPTH 2: level k-2 goes out after this iteration's two stores
         // (below), so that every older vector-memory operation of the wave precedes it and `vmcnt(n_issue)` at the
-        // end of the iteration means exactly "level k+1 has landed"
-        if (DEPTH == 1 && k + 1 < k1 && DYC_MOM_MODE != 2) issue(k + 1, slot1);
+        // end of the iteration means exactly "level k-1 has landed"
+        if (DEPTH == 1 && k - 1 >= k0 && DYC_MOM_MODE != 2) issue(k - 1, slot1);
         const real tbu = tbu_nx, tbv = tbv_nx;
-        if (TURB && k + 1 < k1) { tbu_nx = p.TURB_U[c + (size_t)(k + 1) * g.plane]; tbv_nx = v_on ? p.TURB_V[c + (size_t)(k + 1) * g.plane] : 0.0; }
+        if (TURB && k - 1 >= k0) { tbu_nx = p.TURB_U[c + (size_t)(k - 1) * g.plane]; tbv_nx = v_on ? p.TURB_V[c + (size_t)(k - 1) * g.plane] : 0.0; }
         const real *db = dsm + slot * DSLOT;
         const real *fb = dsm + NS * DSLOT + (k & 1) * FSLOT;
         (void)fb;
         real u = 0.0, v = 0.0, uo = 0.0, vo = 0.0;
+        real su_k = 0.0, sv_k = 0.0;
         if (DYC_MOM_MODE == 1) {
             if (active) {
                 const size_t qm = c + (size_t)k * g.plane;
-                u_out[qm] = SM(S_UW, 0, 0) + SM(S_PHI, 0, 0) + SM(S_UF, 1, 0);
+                u_out[qm] = SM(S_UW, 0, 0) + SM(S_POTT, 0, 0) + SM(S_UF, 1, 0);
                 if (v_on) v_out[qm] = SM(S_VW, 0, 0) + SM(S_PVB, 0, 0) + SM(S_VF, 0, 1) + (OLD_IS_CUR ? 0.0 : db[OFF_OLD + ty * FTI + tx] + db[OFF_OLD + ON + ty * FTI + tx]);
             }
         } else if (active) {
@@ -720,30 +755,30 @@ __global__ __launch_bounds__(FTI *TJ, (TJ <= 4 ? 2 : 1)) void k_momentum_dma(Geo
                 uo = db[OFF_OLD + ty * FTI + tx];
                 vo = db[OFF_OLD + ON + ty * FTI + tx];
             }
-            // ---- interface k closes level k-1 ----
-            if (k >= 1) {
-                const real wa = c_wa[k], wb = c_wb[k];
-                const real wu_k = su_k * (wa * u_km1 + wb * u);
-                const real wv_k = sv_k * (wa * v_km1 + wb * v);
-                if (k > k0) {
-                    const size_t qm = c + (size_t)(k - 1) * g.plane;
-                    const real rds1 = c_rds[k - 1];
-                    const real tu = tu_km1 + (wu_km1 - wu_k) * rds1;
-                    u_out[qm] = uo_km1 * eu1 + tu * eu2;
+            // ---- interface k+1 closes level k+1 ----
+            if (k + 1 < nz) {
+                const real wa = c_wa[k + 1], wb = c_wb[k + 1];
+                const real wu_t = mul_rn(su_kp1, mix2(wa, u, wb, u_kp1));
+                const real wv_t = mul_rn(sv_kp1, mix2(wa, v, wb, v_kp1));
+                if (k + 1 < k1) {
+                    const size_t qm = c + (size_t)(k + 1) * g.plane;
+                    const real rds1 = c_rds[k + 1];
+                    const real tu = fma(wu_t - wu_b, rds1, tu_kp1);
+                    u_out[qm] = mix2(uo_kp1, eu1, tu, eu2);
                     if (v_on) {
-                        const real tv = tv_km1 + (wv_km1 - wv_k) * rds1;
-                        v_out[qm] = vo_km1 * ev1 + tv * ev2;
+                        const real tv = fma(wv_t - wv_b, rds1, tv_kp1);
+                        v_out[qm] = mix2(vo_kp1, ev1, tv, ev2);
                     }
                 }
-                wu_km1 = wu_k; wv_km1 = wv_k;
+                wu_b = wu_t; wv_b = wv_t;
             }
         }
         if (DEPTH == 2) {
             asm volatile("" ::: "memory");      // the stores above stay above the DMA below
-            if (k + 2 < k1 && DYC_MOM_MODE != 2) {
+            if (k - 2 >= k0 && DYC_MOM_MODE != 2) {
                 int slot2 = slot1 + 1;
                 if (slot2 == NS) slot2 = 0;
-                issue(k + 2, slot2);
+                issue(k - 2, slot2);
             }
         }
         if (DYC_MOM_MODE != 1 && active) {
@@ -781,17 +816,18 @@ __global__ __launch_bounds__(FTI *TJ, (TJ <= 4 ? 2 : 1)) void k_momentum_dma(Geo
             for (int b = 0; b < 3; b++)
 #pragma unroll
                 for (int a = 0; a < 3; a++) { uw[b][a] = SM(S_UW, a - 1, b - 1); vw[b][a] = SM(S_VW, a - 1, b - 1); }
-            // ---- six-point sums at interface k+1 (dyn_functions.py:211-270) ----
-            if (k + 1 < nz) {
+            // ---- six-point sums at interface k, the upper one of this level (dyn_functions.py:211-270); sigma-dot
+            // is zero at the model top ----
+            if (k > 0) {
                 const real w_c = SM(S_W, 0, 0), w_w = SM(S_W, -1, 0), w_s = SM(S_W, 0, -1), w_sw = SM(S_W, -1, -1);
-                su_k = wu[0] * SM(S_W, -1, 1) + wu[1] * SM(S_W, 0, 1) + wu[2] * w_w + wu[3] * w_c + wu[4] * w_sw + wu[5] * w_s;
-                sv_k = wv[0] * SM(S_W, 1, -1) + wv[1] * SM(S_W, 1, 0) + wv[2] * w_s + wv[3] * w_c + wv[4] * w_sw + wv[5] * w_w;
+                su_k = dot6(wu, SM(S_W, -1, 1), SM(S_W, 0, 1), w_w, w_c, w_sw, w_s);
+                sv_k = dot6(wv, SM(S_W, 1, -1), SM(S_W, 1, 0), w_s, w_c, w_sw, w_w);
             }
             const real svb = c_svb[k], svb1 = c_svb[k + 1];
             const real dif = c_dif[k];
             const real rds = c_rds[k];
-            const real pvb_kp1 = SM(S_PVB, 0, 0), pvb_im1_kp1 = SM(S_PVB, -1, 0), pvb_jm1_kp1 = SM(S_PVB, 0, -1);
-            const real phi = SM(S_PHI, 0, 0), pott = SM(S_POTT, 0, 0);
+            const real pvb_k = SM(S_PVB, 0, 0), pvb_im1_k = SM(S_PVB, -1, 0), pvb_jm1_k = SM(S_PVB, 0, -1);
+            const real pott = SM(S_POTT, 0, 0), pott_im1 = SM(S_POTT, -1, 0), pott_jm1 = SM(S_POTT, 0, -1);
             real pvtf, pvtf_im1, pvtf_jm1;
             if (FROM_WINDS) {
                 // (double intermediates: the difference of the two products cancels five digits; a no-op in the double build)
@@ -803,6 +839,21 @@ __global__ __launch_bounds__(FTI *TJ, (TJ <= 4 ? 2 : 1)) void k_momentum_dma(Geo
                 pvtf_jm1 = (pvb_jm1_kp1 * pk1_s - pvb_jm1_k * pk_s) * (rcp_jm1 * rds);
             } else {
                 pvtf = SM(S_PVTF, 0, 0); pvtf_im1 = SM(S_PVTF, -1, 0); pvtf_jm1 = SM(S_PVTF, 0, -1);
+            }
+            // PHI at the own cell and its western / southern neighbour (dyn_diagnostics.py:160-174): staged, or
+            // (PHI_LOCAL) carried up the column from the surface geopotential -- PHIVB[k+1] is at hand from the level
+            // below, PHI[k] = PHIVB[k+1] - cp POTT (PVTF - PVTFVB[k+1]), PHIVB[k] = PHI[k] - cp POTT (PVTFVB[k] - PVTF),
+            // the expressions of diag_level_pre on the thread's own PVTF
+            real phi, phi_im1, phi_jm1;
+            if (PHI_LOCAL) {
+                phi = phivb_c - CON_CP * (pott * (pvtf - pvb_kp1));
+                phi_im1 = phivb_w - CON_CP * (pott_im1 * (pvtf_im1 - pvb_im1_kp1));
+                phi_jm1 = phivb_s - CON_CP * (pott_jm1 * (pvtf_jm1 - pvb_jm1_kp1));
+                phivb_c = phi - CON_CP * (pott * (pvb_k - pvtf));
+                phivb_w = phi_im1 - CON_CP * (pott_im1 * (pvb_im1_k - pvtf_im1));
+                phivb_s = phi_jm1 - CON_CP * (pott_jm1 * (pvb_jm1_k - pvtf_jm1));
+            } else {
+                phi = SM(S_PHI, 0, 0); phi_im1 = SM(S_PHI, -1, 0); phi_jm1 = SM(S_PHI, 0, -1);
             }
             constexpr real W24 = 1.0 / 24.0, W48 = 1.0 / 48.0;
             const real prs = pott * rds;                 // POTT / dsigma of the own cell (pressure-gradient terms)
@@ -828,12 +879,12 @@ __global__ __launch_bounds__(FTI *TJ, (TJ <= 4 ? 2 : 1)) void k_momentum_dma(Geo
                          cor_c * (V(0, 0) + V(0, 1)) * (kc_is + up * hsin_is));
                 // pressure gradient (dyn_functions.py:177-207) with the per-column factors pg_a = -dy (COLP + COLP[i-1]) / 2,
                 // pg_b = -dy (COLP - COLP[i-1]) cp / 2 formed once and POTT / dsigma as POTT * (1 / dsigma)
-                t = t + ((phi - SM(S_PHI, -1, 0)) * pgu_a +
-                         pgu_b * ((SM(S_POTT, -1, 0) * rds) * (svb1 * (pvb_im1_kp1 - pvtf_im1) + svb * (pvtf_im1 - pvb_im1_k)) +
+                t = t + ((phi - phi_im1) * pgu_a +
+                         pgu_b * ((pott_im1 * rds) * (svb1 * (pvb_im1_kp1 - pvtf_im1) + svb * (pvtf_im1 - pvb_im1_k)) +
                                   prs * own));
                 t = t + dif * lap_u;      // dif >= 0; 0 adds nothing
                 if (TURB) t = t + tbu;
-                tu_km1 = t;
+                tu_kp1 = t;
             }
             // =============================== dVFLXdt ===============================
             if (v_on) {
@@ -852,40 +903,43 @@ __global__ __launch_bounds__(FTI *TJ, (TJ <= 4 ? 2 : 1)) void k_momentum_dma(Geo
                 // dyn_VFLX.py:39-64; us = 2 x the mean u at the v-point, cov_* = -metric / 2 * COLP, hsin = sin / 2
                 const real us_jm1 = U(0, -1) + U(1, -1), us = U(0, 0) + U(1, 0);
                 t = t + (cov_jm1 * us_jm1 * (kc_jm1 + us_jm1 * hsin_jm1) + cov_c * us * (kc_c + us * hsin_c));
-                t = t + ((phi - SM(S_PHI, 0, -1)) * pgv_a +
-                         pgv_b * ((SM(S_POTT, 0, -1) * rds) * (svb1 * (pvb_jm1_kp1 - pvtf_jm1) + svb * (pvtf_jm1 - pvb_jm1_k)) +
+                t = t + ((phi - phi_jm1) * pgv_a +
+                         pgv_b * ((pott_jm1 * rds) * (svb1 * (pvb_jm1_kp1 - pvtf_jm1) + svb * (pvtf_jm1 - pvb_jm1_k)) +
                                   prs * own));
                 t = t + dif * lap_v;
                 if (TURB) t = t + tbv;
-                tv_km1 = t;
+                tv_kp1 = t;
             }
 #undef UF
 #undef VF
 #undef U
 #undef V
-            u_km1 = u; v_km1 = v; uo_km1 = uo; vo_km1 = vo;
-            pvb_k = pvb_kp1; pvb_im1_k = pvb_im1_kp1; pvb_jm1_k = pvb_jm1_kp1;
+            u_kp1 = u; v_kp1 = v; uo_kp1 = uo; vo_kp1 = vo;
+            su_kp1 = su_k; sv_kp1 = sv_k;
+            pvb_kp1 = pvb_k; pvb_im1_kp1 = pvb_im1_k; pvb_jm1_kp1 = pvb_jm1_k;
         }
-        // this wave's part of level k+1 has landed (the deeper prefetch stays in flight); form its flux entries
-        if (k + 1 < k1 && DYC_MOM_MODE != 2) {
-            wait_vmcnt((DEPTH == 2 && k + 2 < k1) ? n_issue : 0);
-            flux_own(slot1, (k + 1) & 1);
+        // this wave's part of level k-1 has landed (the deeper prefetch stays in flight); form its flux entries
+        if (k - 1 >= k0 && DYC_MOM_MODE != 2) {
+            wait_vmcnt((DEPTH == 2 && k - 2 >= k0) ? n_issue : 0);
+            flux_own(slot1, (k - 1) & 1);
         }
-        lds_barrier();         // level k+1 is in LDS for every wave; slot `slot` is free again
+        lds_barrier();         // level k-1 is in LDS for every wave; slot `slot` is free again
         slot = slot1;
     }
-    // ---- the last level of the chunk: its lower interface is k1 (WWIND*U = 0 at the surface) ----
+    // ---- the top level of the chunk: its upper interface is k0 (WWIND*U = 0 at the model top) ----
     if (active) {
-        const size_t qm = c + (size_t)(k1 - 1) * g.plane;
-        real wu_k = 0.0, wv_k = 0.0;
-        if (k1 < nz) {
-            wu_k = su_k * (c_wa[k1] * u_km1 + c_wb[k1] * p.UWIND[qm + g.plane]);
-            wv_k = sv_k * (c_wa[k1] * v_km1 + c_wb[k1] * p.VWIND[qm + g.plane]);
+        const size_t qm = c + (size_t)k0 * g.plane;
+        real wu_t = 0.0, wv_t = 0.0;
+        if (k0 > 0) {
+            wu_t = mul_rn(su_kp1, mix2(c_wa[k0], p.UWIND[qm - g.plane], c_wb[k0], u_kp1));
+            wv_t = mul_rn(sv_kp1, mix2(c_wa[k0], p.VWIND[qm - g.plane], c_wb[k0], v_kp1));
         }
-        u_out[qm] = uo_km1 * eu1 + (tu_km1 + (wu_km1 - wu_k) * c_rds[k1 - 1]) * eu2;
-        if (v_on) v_out[qm] = vo_km1 * ev1 + (tv_km1 + (wv_km1 - wv_k) * c_rds[k1 - 1]) * ev2;
+        u_out[qm] = mix2(uo_kp1, eu1, fma(wu_t - wu_b, c_rds[k0], tu_kp1), eu2);
+        if (v_on) v_out[qm] = mix2(vo_kp1, ev1, fma(wv_t - wv_b, c_rds[k0], tv_kp1), ev2);
     }
 #undef SM
+#undef MROWS
+#undef MOFF
 }
 // ------------------------------------------------------------------------------------
 // k_turb_tendencies: the vertical-turbulence terms of the momentum, temperature and moisture
@@ -1099,6 +1153,26 @@ __global__ __launch_bounds__(TI *TJ) void k_derive_pvtf(Geo g, Ptrs p)
         p_km12 = p_kp12; pvb_k = pvb_kp1;
     }
 }
+// PHI and PHIVB (dyn_diagnostics.py:160-174) from POTT, PVTFVB, COLP and HSURF: whole array including halos, the
+// expressions of diag_level_pre on the stored PVTFVB -- the bits k_pott_fused would have stored
+__global__ __launch_bounds__(TI *TJ) void k_derive_phi(Geo g, Ptrs p)
+{
+    DYC_IJ(0, 0)
+    if (i > g.nx + 1 || j > g.ny + 1) return;
+    const size_t c = at2(g, i, j);
+    const int nz = g.nz;
+    const real colp = p.COLP[c];
+    real p_kp12 = interface_pressure(g.pair_top, p.sigma_vb[nz], colp), pvb_kp1 = p.PVTFVB[c + (size_t)nz * g.plane];
+    real phivb_kp1 = p.HSURF[c] * CON_G;
+    p.PHIVB[c + (size_t)nz * g.plane] = phivb_kp1;
+    for (int k = nz - 1; k >= 0; k--) {
+        const size_t q = c + (size_t)k * g.plane;
+        const DiagLevel dl = diag_level_pre(interface_pressure(g.pair_top, p.sigma_vb[k], colp), p.PVTFVB[q], p.POTT[q], p_kp12, pvb_kp1, phivb_kp1);
+        p.PHI[q] = dl.phi;
+        p.PHIVB[q] = dl.phivb;
+        p_kp12 = dl.p_km12; pvb_kp1 = dl.pvb_k; phivb_kp1 = dl.phivb;
+    }
+}
 __global__ __launch_bounds__(TI *TJ) void k_derive_phivb(Geo g, Ptrs p)
 {
     DYC_IJ(0, 0)
@@ -1137,7 +1211,10 @@ __device__ __forceinline__ void stb(real *base, unsigned boff, real v) { __built
 
 // WRITE_PVTF = false: PVTF is not stored either -- the production momentum kernel forms it from PVTFVB and COLP, every
 // other reader gets it on demand (k_derive_pvtf, the formula of diag_level_pre on the stored PVTFVB: the same bits).
-template <bool WRITE_PHIVB, bool FROM_WINDS, bool TURB = false, bool WRITE_PVTF = true>
+// WRITE_PHI = false: PHI is not stored either -- the production momentum kernel carries it up the column (PHI_LOCAL) from
+// the surface geopotential; for its level chunks PHIVB is stored at every PHIVB_STRIDE-th interface (1/4 of a pass
+// instead of one).  Every other reader gets PHI (and PHIVB) on demand from k_derive_phi.
+template <bool WRITE_PHIVB, bool FROM_WINDS, bool TURB = false, bool WRITE_PVTF = true, bool WRITE_PHI = true>
 __global__ __launch_bounds__(TI *TJ) void k_pott_fused(Geo g, Ptrs p, const real *pott_old, real *pott_out, real dt, int lin)
 {
     int i, j;
@@ -1221,10 +1298,8 @@ __global__ __launch_bounds__(TI *TJ) void k_pott_fused(Geo g, Ptrs p, const real
         const real p_km12 = dl.p_km12, pvb_k = dl.pvb_k, pvtf = dl.pvtf, phi = dl.phi, phivb = dl.phivb;
         if (WRITE_PVTF) stb(p.PVTF, q, pvtf);
         stb(p.PVTFVB, q, pvb_k);
-#ifndef DYC_POTT_NOPHI      // experiment builds only (wrong results)
-        stb(p.PHI, q, phi);
-#endif
-        if (WRITE_PHIVB) stb(p.PHIVB, q, phivb);
+        if (WRITE_PHI) stb(p.PHI, q, phi);
+        if (WRITE_PHIVB || (!WRITE_PHI && k % PHIVB_STRIDE == 0)) stb(p.PHIVB, q, phivb);
         if (k < nz - 1) {
             const real vb = pottvb_between(pvb_kp1, pvtf, pott, pvtf_kp1, pottn_kp1);
             stb(p.POTTVB, q + bpl, vb);

@@ -47,6 +47,9 @@ KERNEL_PASSES = {
     'k_pott_tendency': 6, 'k_euler_forward': 9, 'k_primary_diag': 5, 'k_diag_rho': 6,
     'k_momentum_dma': 9.0,       # R UWIND,VWIND,WWIND,PHI,POTT,PVTFVB (+2 old in the corrector) W UWIND,VWIND (PVTF is formed in the thread)
     'k_momentum_fused': 10.0,    # its register-staged fallback (nz > 160): the same fields + PVTF
+    # momentum + temperature of a substep in one launch (single GPU): R UWIND,VWIND,WWIND,PHI,POTT,PVTFVB,POTTVB (+3 old in the
+    # corrector) W UWIND,VWIND,POTT,PVTFVB,PHI,POTTVB -- the temperature wavefronts read the tiles the momentum wavefronts stage
+    'k_substep_fused': 14.5,
     'k_pott_fused': 9.5,         # R POTT,UWIND,VWIND,WWIND,POTTVB (+1 old) W POTT,PVTFVB,PHI,POTTVB (PVTF is derived on demand)
     'k_moist': 8.0,              # R QV,QC,UWIND,VWIND,WWIND (+2 old) W QV,QC
     'k_turb_tendencies': 16.0,   # R UWIND,VWIND,PHI,PHIVB,RHO,RHOVB,KMOM,KHEAT,POTT(,QV,QC) W TURB_U,V,T(,QV,QC)

@@ -106,12 +106,12 @@ constexpr int kNGrid = sizeof(kGrid) / sizeof(kGrid[0]);
 
 // kernels tracked by the profiler
 enum KernelId {
-    K_CONTINUITY = 0, K_PREPARE, K_UFLX, K_VFLX, K_POTT, K_EULER, K_DIAG, K_RHO, K_EXCHANGE, K_COPY, K_HALO, K_MOM_FUSED, K_POTT_FUSED, K_DIAG_ROWS, K_HALO_MULTI, K_CONT_REG, K_DERIVE, K_MOIST, K_SECONDARY, K_TURB, K_RAD, K_TURB_TEND, K_MOM_DMA,
+    K_CONTINUITY = 0, K_PREPARE, K_UFLX, K_VFLX, K_POTT, K_EULER, K_DIAG, K_RHO, K_EXCHANGE, K_COPY, K_HALO, K_MOM_FUSED, K_POTT_FUSED, K_DIAG_ROWS, K_HALO_MULTI, K_CONT_REG, K_DERIVE, K_MOIST, K_SECONDARY, K_TURB, K_RAD, K_TURB_TEND, K_MOM_DMA, K_SUBSTEP,
     K_COUNT
 };
 const char *kKernelNames[K_COUNT] = {
     "k_continuity", "k_prepare", "k_uflx_tendency", "k_vflx_tendency", "k_pott_tendency",
-    "k_euler_forward", "k_primary_diag", "k_diag_rho", "k_exchange_bc", "copy_field", "k_rows", "k_momentum_fused", "k_pott_fused", "k_primary_diag_rows", "k_halo_multi", "k_continuity_reg", "k_derive", "k_moist", "k_diag_secondary", "k_turbulence", "k_radiation", "k_turb_tendencies", "k_momentum_dma",
+    "k_euler_forward", "k_primary_diag", "k_diag_rho", "k_exchange_bc", "copy_field", "k_rows", "k_momentum_fused", "k_pott_fused", "k_primary_diag_rows", "k_halo_multi", "k_continuity_reg", "k_derive", "k_moist", "k_diag_secondary", "k_turbulence", "k_radiation", "k_turb_tendencies", "k_momentum_dma", "k_substep_fused",
 };
 
 struct ProfRec { int kid; hipEvent_t a, b; };
@@ -152,6 +152,16 @@ struct dycore {
     const real *flx_u = nullptr, *flx_v = nullptr;   // winds the last fused continuity evaluated on
     bool winds_bc_dirty = true;     // UWIND / VWIND came from the host: their lateral BC images (column nx+2!) may be unset
     int n_cu = 256;                 // compute units of the device
+    // momentum + temperature of a substep in ONE launch (k_momentum_dma<..., WITH_TEMP>; DYCORE_STEP_FUSED=0: two kernels):
+    // the whole grid on one GPU, dry or moist, no turbulence coupling, no radiative heating
+#ifdef DYCORE_FLOAT32
+    // (float build: off -- there the compiler contracts the momentum arithmetic of the two instantiations differently, a few
+    // cells per 1e4 differ by rounding between a band on the separate kernels and the single-GPU run, tests/test_f32.py)
+    bool step_fused = false;
+#else
+    bool step_fused = true;
+#endif
+    real *pvb_alt = nullptr, *phi_alt = nullptr;       // the buffers that launch writes the new PVTFVB / PHI into (swapped in afterwards)
     int mom_tj = 4;                 // tile rows of the LDS-DMA momentum kernel (8: one workgroup per CU; 4: two, each with its own barrier)
     int cell_lin = -1;              // DYCORE_CELL_LINEAR: column-kernel launch, bit 0 = cell runs, bit 1 = XCD-aware order (default 3 or 2)
     int mom_ks = 0;                 // DYCORE_MOM_KS: force the level chunks per momentum tile (1 .. 16)
@@ -200,7 +210,7 @@ struct Scope {          // brackets one launch with events when profiling is on
     dycore *h; int kid; ProfRec r; bool on;
     Scope(dycore *h_, int kid_) : h(h_), kid(kid_), on(false)
     {
-        if (!h->prof || (h->prof == 2 && kid != K_MOM_FUSED && kid != K_MOM_DMA)) return;
+        if (!h->prof || (h->prof == 2 && kid != K_MOM_FUSED && kid != K_MOM_DMA && kid != K_SUBSTEP)) return;
         if (get_event(h, &r.a) || get_event(h, &r.b)) return;
         r.kid = kid;
         on = hipEventRecord(r.a, h->stream) == hipSuccess;
@@ -585,7 +595,7 @@ int do_momentum_fused(dycore *h, const Ptrs &p, const real *u_old, const real *v
         const bool cur = (u_old == p.UWIND);
         const bool fw = flux_from_winds(h) && (h->fw_mask & 2);
         // ring depth: two levels in flight for the production (dry / moist, fluxes from the winds) instances
-#define MOM_LAUNCH_P(CUR_, TJ_, FW_, TB_, DP_, PL_) hipLaunchKernelGGL((k_momentum_dma<CUR_, TJ_, FW_, TB_, DP_, PL_>), gr2, blk, dma_lds_bytes(TJ_, FW_, CUR_, DP_, PL_), h->stream, h->g, p, gbx, plan, jv_lo, u_old, v_old, u_out, v_out, dt)
+#define MOM_LAUNCH_P(CUR_, TJ_, FW_, TB_, DP_, PL_) hipLaunchKernelGGL((k_momentum_dma<CUR_, TJ_, FW_, TB_, DP_, PL_>), gr2, blk, dma_lds_bytes(TJ_, FW_, CUR_, DP_, PL_), h->stream, h->g, p, gbx, plan, jv_lo, u_old, v_old, u_out, v_out, dt, TempArgs{nullptr, nullptr, nullptr, nullptr})
 #define MOM_LAUNCH_T(CUR_, TJ_, FW_, TB_, DP_) MOM_LAUNCH_P(CUR_, TJ_, FW_, TB_, DP_, false)
 #define MOM_LAUNCH(CUR_, FW_, TB_, DP_) MOM_LAUNCH_T(CUR_, FTJ, FW_, TB_, DP_)
         const bool pl = phi_on_demand(h);
@@ -602,6 +612,35 @@ int do_momentum_fused(dycore *h, const Ptrs &p, const real *u_old, const real *v
     else
         hipLaunchKernelGGL(k_momentum_fused<false>, gr, bl, 0, h->stream, h->g, p, gbx, gby, jv_lo, u_old, v_old, u_out, v_out, dt);
     return launch_check(dma ? "k_momentum_dma" : "k_momentum_fused");
+}
+// momentum + temperature in one launch: see k_momentum_dma<..., WITH_TEMP>
+bool substep_fused(const dycore *h)
+{
+    return h->step_fused && h->pvb_alt && h->phi_alt && h->g.pole_s && h->g.pole_n && !h->g.i_rad && pvtf_on_demand(h) && !phi_on_demand(h) &&
+           h->mom_tj == 4 && h->g.nz >= 2;
+}
+int do_substep_fused(dycore *h, const Ptrs &p, const real *u_old, const real *v_old, const real *pott_old,
+                     real *u_out, real *v_out, real *pott_out, real dt)
+{
+    Scope s(h, K_SUBSTEP);
+    constexpr int tj = 4;
+    const int gbx = (h->g.nx + FTI - 1) / FTI, gby = (h->g.ny + tj - 1) / tj;
+    MomPlan plan = {{0, gby, gby, 0}, 1, 8 * ((gbx * gby + 7) / 8), {0, 0, 0, 0}, 1, h->mom_patch};
+    const dim3 gr(plan.nblk_a), blk(FTI, 2 * tj);
+    const bool cur = (u_old == p.UWIND);
+    const TempArgs ta = {pott_old, pott_out, h->pvb_alt, h->phi_alt};
+    const int jv_lo = 2;        // pole_s
+    if (cur) hipLaunchKernelGGL((k_momentum_dma<true, tj, true, false, 2, false, true>), gr, blk, dma_lds_bytes(tj, true, true, 2, false, true), h->stream,
+                                h->g, p, gbx, plan, jv_lo, u_old, v_old, u_out, v_out, dt, ta);
+    else hipLaunchKernelGGL((k_momentum_dma<false, tj, true, false, 2, false, true>), gr, blk, dma_lds_bytes(tj, true, false, 2, false, true), h->stream,
+                            h->g, p, gbx, plan, jv_lo, u_old, v_old, u_out, v_out, dt, ta);
+    int rc = launch_check("k_substep_fused");
+    if (rc) return rc;
+    std::swap(h->p.PVTFVB, h->pvb_alt);
+    std::swap(h->p.PHI, h->phi_alt);
+    h->stale_pvtf = true;
+    h->stale_phivb = true;
+    return 0;
 }
 int do_pott_fused(dycore *h, const Ptrs &p, const real *pott_old, real *pott_out, real dt)
 {
@@ -780,12 +819,16 @@ int substep_part(dycore *h, real dt, int sub, int part)
             return do_momentum_fused(h, q, p.UWIND, p.VWIND, u_out, v_out, dt, ROWS_EDGE);
         case 1:
         case DYCORE_PART_TEMP: {    // momentum reads the old diagnostics, so it runs first
-            if (part == 1) {
-                if ((rc = join_side(h))) return rc;
-                if (h->g.i_turb && (rc = do_turb_tendencies(h, q))) return rc;
-                if ((rc = do_momentum_fused(h, q, p.UWIND, p.VWIND, u_out, v_out, dt))) return rc;
+            if (part == 1 && substep_fused(h)) {
+                if ((rc = do_substep_fused(h, q, p.UWIND, p.VWIND, p.POTT, u_out, v_out, t_out, dt))) return rc;
+            } else {
+                if (part == 1) {
+                    if ((rc = join_side(h))) return rc;
+                    if (h->g.i_turb && (rc = do_turb_tendencies(h, q))) return rc;
+                    if ((rc = do_momentum_fused(h, q, p.UWIND, p.VWIND, u_out, v_out, dt))) return rc;
+                }
+                if ((rc = do_pott_fused(h, q, p.POTT, t_out, dt))) return rc;
             }
-            if ((rc = do_pott_fused(h, q, p.POTT, t_out, dt))) return rc;
             real *qv_out = sub == 0 ? p.QV_EST : p.QV, *qc_out = sub == 0 ? p.QC_EST : p.QC;
             if (h->g.i_moist && (rc = do_moist(h, q, p.QV, p.QC, qv_out, qc_out, dt))) return rc;
             const int nz = h->g.nz;
@@ -886,6 +929,7 @@ int dycore_create(const DycoreConfig *cfg, dycore_t **out)
     if (const char *e = getenv("DYCORE_MOM_KS")) h->mom_ks = atoi(e);
     if (const char *e = getenv("DYCORE_MOM_PATCH")) h->mom_patch = atoi(e) > 1 ? atoi(e) : 1;
     if (const char *e = getenv("DYCORE_MOM_TJ")) h->mom_tj = atoi(e) == 4 ? 4 : 8;
+    if (const char *e = getenv("DYCORE_STEP_FUSED")) h->step_fused = atoi(e) != 0;
     if (const char *e = getenv("DYCORE_MOM_DEPTH")) h->mom_depth = atoi(e) == 1 ? 1 : 2;
     if (const char *e = getenv("DYCORE_MOM_SPLIT")) h->mom_split = atoi(e);
     if (const char *e = getenv("DYCORE_MOM_PRO")) h->mom_pro = atof(e);
@@ -903,6 +947,12 @@ int dycore_create(const DycoreConfig *cfg, dycore_t **out)
         bool ok_pl = true;
         MOM_ATTR_P(true, 4, true, false, 1, true, ok_pl) MOM_ATTR_P(true, 4, true, false, 2, true, ok_pl) MOM_ATTR_P(false, 4, true, false, 1, true, ok_pl)
         if (!ok_pl) h->lazy_phi = false;
+        bool ok_wt = true;
+        if (hipFuncSetAttribute((const void *)k_momentum_dma<true, 4, true, false, 2, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)dma_lds_bytes(4, true, true, 2, false, true)) != hipSuccess) { (void)hipGetLastError(); ok_wt = false; }
+        if (hipFuncSetAttribute((const void *)k_momentum_dma<false, 4, true, false, 2, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)dma_lds_bytes(4, true, false, 2, false, true)) != hipSuccess) { (void)hipGetLastError(); ok_wt = false; }
+        if (!ok_wt) h->step_fused = false;
 #define MOM_ATTR(CUR_, FW_, TB_, DP_, FLAG_) MOM_ATTR_T(CUR_, FTJ, FW_, TB_, DP_, FLAG_)
         MOM_ATTR_T(true, 4, true, false, 1, ok_half) MOM_ATTR_T(true, 4, true, false, 2, ok_half) MOM_ATTR_T(false, 4, true, false, 1, ok_half)
         MOM_ATTR(true, false, false, 1, ok_plain) MOM_ATTR(false, false, false, 1, ok_plain)
@@ -990,6 +1040,10 @@ int dycore_create(const DycoreConfig *cfg, dycore_t **out)
         real *d = nullptr;
         rc = alloc((size_t)(5 * (g.nz + 2)), &d);
         h->p.mom_c = d;
+    }
+    if (!rc && h->step_fused && g.pole_s && g.pole_n && !g.i_turb && !g.i_rad) {       // (substep_fused: the other conditions can change with the grid)
+        rc = alloc(h->field_elems(-1), &h->pvb_alt);         // nz + 1 planes
+        if (!rc) rc = alloc(h->field_elems(0), &h->phi_alt);
     }
     if (!rc) {
         h->stage_elems = (size_t)(g.nx + 3) * (g.ny + 3) * (g.nz + 1);

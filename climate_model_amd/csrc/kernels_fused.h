@@ -350,35 +350,41 @@ constexpr int DMAXZ = 160;                        // levels up to which the LDS-
 // through the DMA per level.  The kernel's time is its data movement (profiles/r02_notes.md), the arithmetic
 // rides along.  The quotient differs from the stored PVTF by the rounding of p[k+1] - p[k] (~4e-15 relative).
 enum { S_UF = 0, S_VF, S_UW, S_VW, S_W, S_PHI, S_POTT, S_PVTF, S_PVB };
-constexpr int mom_rows(int f, int tj, bool fw, bool pl = false)
+constexpr int mom_rows(int f, int tj, bool fw, bool pl = false, bool wt = false)
 {
 #ifdef DYC_MOM_NOHALO       // experiment builds only (wrong results): no halo rows staged
     return tj;
 #endif
     if (f == S_PVTF && fw) return 0;        // formed in the thread from PVTFVB and the column pressure (below)
     if (f == S_PHI && pl) return 0;         // `pl` (PHI_LOCAL): carried up the column by the thread (below)
+    if (f == S_POTT && wt) return tj + 2;   // `wt` (WITH_TEMP): the temperature wavefronts read POTT at j+1 as well
     return f == S_UF ? tj + 2 : f == S_VF ? tj + 3 : f == S_UW ? tj + 2 : f == S_VW ? (fw ? tj + 3 : tj + 2) : f == S_W ? tj + 2 : tj + 1;
 }
 // LDS layout (doubles).  A DMA slot holds the staged fields of one level back to back (each rows x FTW), then the
 // two step-start tiles of the corrector (tj rows each); with `fw` (fluxes re-formed from the winds) UFLX / VFLX
 // are not staged: they live in their own two-slot ring, written by the DMA wavefronts (flux_own).
-constexpr int mom_off(int f, int tj, bool fw, bool pl = false)     // offset of field f inside its slot; f = FNF: the step-start tiles
+constexpr int mom_off(int f, int tj, bool fw, bool pl = false, bool wt = false)     // offset of field f inside its slot; f = FNF: the step-start tiles
 {
     if (fw && f < 2) return f == S_UF ? 0 : (tj + 2) * FTW;
     int o = 0;
-    for (int g = (fw ? 2 : 0); g < f; g++) o += mom_rows(g, tj, fw, pl) * FTW;
+    for (int g = (fw ? 2 : 0); g < f; g++) o += mom_rows(g, tj, fw, pl, wt) * FTW;
     return o;
 }
-constexpr int mom_dma_slot(int tj, bool fw, bool cur, bool pl = false) { return mom_off(FNF, tj, fw, pl) + (cur ? 0 : 2 * FTI * tj); }   // step-start tiles: own cells only, FTI wide
+// own-cell tiles behind the staged ones (FTI wide): the step-start winds of the corrector; WITH_TEMP: + POTTVB, + the step-start POTT of the corrector
+constexpr int mom_own_tiles(bool cur, bool wt) { return (cur ? 0 : 2) + (wt ? (cur ? 1 : 2) : 0); }
+constexpr int mom_dma_slot(int tj, bool fw, bool cur, bool pl = false, bool wt = false) { return mom_off(FNF, tj, fw, pl, wt) + mom_own_tiles(cur, wt) * FTI * tj; }
 constexpr int mom_flux_slot(int tj, bool fw) { return fw ? (2 * tj + 5) * FTW : 0; }
 // ... then (fw) two factor tiles, dyis (tj+2 rows) and dxjs (tj+3 rows), shaped like the UFLX / VFLX tiles
-constexpr size_t dma_lds_bytes(int tj, bool fw, bool cur, int depth, bool pl = false)
+constexpr size_t dma_lds_bytes(int tj, bool fw, bool cur, int depth, bool pl = false, bool wt = false)
 {
-    return ((size_t)(depth + 1) * mom_dma_slot(tj, fw, cur, pl) + 3 * (size_t)mom_flux_slot(tj, fw)) * sizeof(real);
+    return ((size_t)(depth + 1) * mom_dma_slot(tj, fw, cur, pl, wt) + 3 * (size_t)mom_flux_slot(tj, fw)) * sizeof(real);
 }
 
 #ifndef DYC_DMA_AUX
 #define DYC_DMA_AUX 0       // cache policy of the LDS-DMA loads (2 = nt)
+#endif
+#ifndef DYC_MOM_MODE
+#define DYC_MOM_MODE 0      // experiment builds only: 1 = data movement without the arithmetic, 2 = arithmetic without the data movement
 #endif
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef const __attribute__((address_space(1))) void gbl_void_t;
@@ -390,7 +396,8 @@ typedef const __attribute__((address_space(1))) void gbl_void_t;
 // out of the compiler's bookkeeping altogether.
 __device__ __forceinline__ void lds_dma16(const void *gp, const void *lds)
 {
-    const unsigned m = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(size_t)(lds_void_t *)lds);
+    // (the low half of a generic pointer into LDS is the LDS byte address)
+    const unsigned m = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(size_t)lds);
 #if DYC_DMA_AUX == 2
     asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off nt" ::"v"(gp), "s"(m) : "memory", "m0");
 #else
@@ -439,6 +446,36 @@ __device__ __forceinline__ real dot6(const real (&w)[6], real x0, real x1, real 
     s = fma(w[1], x1, s); s = fma(w[2], x2, s); s = fma(w[3], x3, s); s = fma(w[4], x4, s);
     return fma(w[5], x5, s);
 }
+// One level of the temperature kernel's arithmetic, shared by k_pott_fused and the temperature wavefronts of the
+// whole-substep kernel (k_momentum_dma<..., WITH_TEMP>): dPOTTdt (dyn_POTT.py:180-216; horizontal advection, vertical
+// advection, diffusion, radiative heating) and the pressure-weighted Euler step (dyn_timestep.py:70-79).  Every
+// multiply-add is written out, so both kernels produce the same bits (a latitude band steps on the separate kernels
+// and must reproduce the single-GPU run).  The "/ 2" of the four face means is applied once (a power of two passes
+// through every rounding unchanged); sums are associated left to right as in the reference, with FMA.
+struct TempCol { real colp, cnew, cold, c_im1, c_ip1, c_jm1, c_jp1, hr_area, r_cnew; };
+__device__ __forceinline__ real temp_new_pott(const TempCol &tc, real uf, real uf1, real vf, real vf1,
+                                              real pt, real p_im1, real p_ip1, real p_jm1, real p_jp1,
+                                              real w_k, real pvbo_k, real w_kp1, real pvbo_kp1, real rds, real dif,
+                                              bool has_turb, real turb, bool has_rad, real rad, real po, real dt)
+{
+#pragma clang fp contract(off)
+    real s = mul_rn(uf, p_im1 + pt);
+    s = fma(-uf1, pt + p_ip1, s);
+    s = fma(vf, p_jm1 + pt, s);
+    s = fma(-vf1, pt + p_jp1, s);
+    real t = mul_rn(s, tc.hr_area);
+    const real v = fma(w_k, pvbo_k, -mul_rn(w_kp1, pvbo_kp1));      // w_k = pvbo_k = 0 at the model top
+    t = fma(mul_rn(tc.cnew, v), rds, t);
+    if (has_turb) t = t + turb;
+    if (dif > 0.0) {
+        real d = mul_rn(tc.c_im1, p_im1);
+        d = fma(tc.c_ip1, p_ip1, d); d = fma(tc.c_jm1, p_jm1, d); d = fma(tc.c_jp1, p_jp1, d);
+        d = fma((real)-4.0 * tc.colp, pt, d);
+        t = fma(dif, d, t);
+    }
+    if (has_rad) t = fma(rad, tc.colp, t);
+    return fma(mul_rn(dt, t), tc.r_cnew, mul_rn(mul_rn(po, tc.cold), tc.r_cnew));
+}
 // workgroup barrier that publishes this wave's LDS writes but leaves its vector-memory operations in flight
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
@@ -453,16 +490,26 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 // registers) join the sums; DEPTH = 1 (the compiler's own waits for those loads drain the DMA anyway).
 // The per-level constants (weights of the interface means, 1 / dsigma, sigma_vb, diffusion coefficient: p.mom_c,
 // formed by the library when the vertical grid is set) are wave-uniform scalar loads: they use neither LDS nor vmcnt.
-template <bool OLD_IS_CUR, int TJ, bool FROM_WINDS, bool TURB = false, int DEPTH = 1, bool PHI_LOCAL = false>
-__global__ __launch_bounds__(FTI *TJ, (TJ <= 4 ? 2 : 1)) void k_momentum_dma(Geo g, Ptrs p, int gbx, MomPlan plan, int jv_lo,
+// WITH_TEMP (the whole-substep kernel of a single-GPU dry step): TJ more wavefronts per workgroup run k_pott_fused's
+// column sweep -- dPOTTdt, Euler step, primary diagnostics of the new column -- on the SAME tiles: the temperature
+// kernel reads POTT, UWIND, VWIND, WWIND like the momentum kernel, so one staging serves both (4 of its 5 read passes
+// disappear: 14.5 instead of 18.5 field passes per substep).  Each SIMD then holds one momentum and one temperature
+// wavefront -- two different instruction streams between the same per-level barriers.  The new PVTFVB and PHI go to
+// alternate buffers (the momentum wavefronts of neighbouring tiles still read the old ones), which the library swaps in
+// after the launch.  Whole columns only (the diagnostics integrate from the surface): no level chunks, so a latitude
+// band, whose few tiles need them to fill the chip, keeps the two separate kernels.
+struct TempArgs { const real *pott_old; real *pott_out, *pvb_out, *phi_out; };
+template <bool OLD_IS_CUR, int TJ, bool FROM_WINDS, bool TURB = false, int DEPTH = 1, bool PHI_LOCAL = false, bool WITH_TEMP = false>
+__global__ __launch_bounds__(FTI *TJ *(WITH_TEMP ? 2 : 1), ((TJ <= 4 && !WITH_TEMP) ? 2 : 1)) void k_momentum_dma(Geo g, Ptrs p, int gbx, MomPlan plan, int jv_lo,
                                                       const real *u_old, const real *v_old,
-                                                      real *u_out, real *v_out, real dt)
+                                                      real *u_out, real *v_out, real dt, TempArgs ta)
 {
+    static_assert(!WITH_TEMP || (FROM_WINDS && !TURB && !PHI_LOCAL && DEPTH == 2), "the temperature wavefronts read the re-formed flux tiles and the staged PHI");
     static_assert(DEPTH == 1 || DEPTH == 2, "ring of 2 or 3 slots");
     static_assert(!(TURB && DEPTH != 1), "the turbulence-coupled variant keeps vector loads in the loop");
     static_assert(!PHI_LOCAL || FROM_WINDS, "PHI in the thread needs PVTF in the thread");
-#define MROWS(f) mom_rows(f, TJ, FROM_WINDS, PHI_LOCAL)
-#define MOFF(f) mom_off(f, TJ, FROM_WINDS, PHI_LOCAL)
+#define MROWS(f) mom_rows(f, TJ, FROM_WINDS, PHI_LOCAL, WITH_TEMP)
+#define MOFF(f) mom_off(f, TJ, FROM_WINDS, PHI_LOCAL, WITH_TEMP)
     // segment of the work list this workgroup belongs to (MomPlan)
     const bool seg_b = (int)blockIdx.x >= plan.nblk_a;
     const RowSet trows = seg_b ? plan.b : plan.a;
@@ -472,8 +519,12 @@ __global__ __launch_bounds__(FTI *TJ, (TJ <= 4 ? 2 : 1)) void k_momentum_dma(Geo
     constexpr int NCH = (TJ + 3) * CPR, NSL = (NCH + 63) / 64;          // chunks of the tallest tile, 64-chunk slices
     constexpr int ON = FTI * TJ, OCPR = FTI / VW, ONSL = ON / VW / 64;  // step-start ("old") tiles: own cells, FTI wide; 64-chunk slices
     static_assert(ON % (VW * 64) == 0, "whole slices");
-    constexpr int NS = DEPTH + 1;                                       // slots of the DMA ring
-    constexpr int DSLOT = mom_dma_slot(TJ, FROM_WINDS, OLD_IS_CUR, PHI_LOCAL), FSLOT = mom_flux_slot(TJ, FROM_WINDS);
+    // levels of DMA in flight / slots of the ring.  (WITH_TEMP with a third level in flight, and with the flux tiles formed by
+    // the temperature wavefronts instead -- which that makes possible --, was tried: +3 % / +10 % per launch; the
+    // temperature wavefront is the slower of the two on a SIMD, profiles/r02_notes.md)
+    constexpr int AHEAD = DEPTH;
+    constexpr int NS = AHEAD + 1;
+    constexpr int DSLOT = mom_dma_slot(TJ, FROM_WINDS, OLD_IS_CUR, PHI_LOCAL, WITH_TEMP), FSLOT = mom_flux_slot(TJ, FROM_WINDS);
     constexpr int OFF_OLD = MOFF(FNF);
     // the step-start tiles: two wavefronts of their own (8 rows), or one slice more for the first 2 ONSL wavefronts (4 rows)
     constexpr bool OLD_SHARED = NSL + 2 > TJ;
@@ -489,9 +540,12 @@ __global__ __launch_bounds__(FTI *TJ, (TJ <= 4 ? 2 : 1)) void k_momentum_dma(Geo
     const int nzb = (g.nz + PHIVB_STRIDE - 1) / PHIVB_STRIDE;
     const int k0 = min(g.nz, PHIVB_STRIDE * (int)((long long)kc * nzb / ksplit)), k1 = min(g.nz, PHIVB_STRIDE * (int)((long long)(kc + 1) * nzb / ksplit));
     if (k1 <= k0) return;
-    const int tx = threadIdx.x, ty = threadIdx.y;
-    const int tid = ty * FTI + tx;
+    constexpr int NTW = TJ * (WITH_TEMP ? 2 : 1);                       // wavefronts per workgroup
+    const int tx = threadIdx.x;
+    const int tid = (int)threadIdx.y * FTI + tx;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const bool role_t = WITH_TEMP && wave >= TJ;                        // a temperature wavefront (wave-uniform)
+    const int ty = role_t ? (int)threadIdx.y - TJ : (int)threadIdx.y;   // its row of the tile
     const int i0 = bx * FTI + 1, j0 = by * TJ + 1;
     const int i = i0 + tx, j = j0 + ty;
     const int P = g.P, nz = g.nz;
@@ -513,8 +567,14 @@ __global__ __launch_bounds__(FTI *TJ, (TJ <= 4 ? 2 : 1)) void k_momentum_dma(Geo
     }
     // a slice of a step-start tile = VW rows of OCPR chunks (16 B each, i0 is 16-B aligned): lane -> (row, column)
     const int orow = lane / OCPR, ocol = i0 + VW * (lane % OCPR);
-    if (!OLD_IS_CUR && !OLD_SHARED && wave >= TJ - 2) n_issue = ONSL;
-    if (!OLD_IS_CUR && OLD_SHARED && wave < 2 * ONSL) n_issue++;
+    constexpr int NOWN = mom_own_tiles(OLD_IS_CUR, WITH_TEMP);         // own-cell tiles: [u_old, v_old,] [POTTVB, [pott_old]]
+    if (WITH_TEMP) {            // the temperature wavefronts move them: slice s (of NOWN * ONSL) by wavefront TJ + s % TJ
+        if (role_t)
+            for (int s5 = wave - TJ; s5 < NOWN * ONSL; s5 += TJ) n_issue++;
+    } else {
+        if (!OLD_IS_CUR && !OLD_SHARED && wave >= TJ - 2) n_issue = ONSL;
+        if (!OLD_IS_CUR && OLD_SHARED && wave < 2 * ONSL) n_issue++;
+    }
     const real *src[FNF] = {p.UFLX, p.VFLX, p.UWIND, p.VWIND, p.WWIND, p.PHI, p.POTT, p.PVTF, p.PVTFVB};
     const real *osrc = OLD_SHARED ? (wave < ONSL ? u_old : v_old) : ((wave == TJ - 2) ? u_old : v_old);
 
@@ -531,7 +591,18 @@ __global__ __launch_bounds__(FTI *TJ, (TJ <= 4 ? 2 : 1)) void k_momentum_dma(Geo
                 }
             }
         }
-        if (!OLD_IS_CUR && OLD_SHARED) {
+        if (WITH_TEMP) {
+            if (role_t) {
+                const real *own[4] = {OLD_IS_CUR ? p.POTTVB : u_old, OLD_IS_CUR ? nullptr : v_old, p.POTTVB, ta.pott_old};
+#pragma unroll
+                for (int s5 = 0; s5 < NOWN * ONSL; s5++) {
+                    if (s5 % TJ == wave - TJ) {
+                        const real *gp = own[s5 / ONSL] + (size_t)k * g.plane + min(j0 + VW * (s5 % ONSL) + orow, g.NJ - 1) * P + ocol;
+                        lds_dma16(gp, buf + OFF_OLD + s5 * 64 * VW);
+                    }
+                }
+            }
+        } else if (!OLD_IS_CUR && OLD_SHARED) {
             if (wave < 2 * ONSL) {          // slice wave % ONSL of tile wave / ONSL: consecutive wavefronts, consecutive LDS
                 const real *gp = osrc + (size_t)k * g.plane + min(j0 + VW * (wave % ONSL) + orow, g.NJ - 1) * P + ocol;
                 lds_dma16(gp, buf + OFF_OLD + wave * 64 * VW);
@@ -546,6 +617,159 @@ __global__ __launch_bounds__(FTI *TJ, (TJ <= 4 ? 2 : 1)) void k_momentum_dma(Geo
         }
     };
 
+    // per-level constants (p.mom_c, stride nz + 2): weights c_wa[k], c_wb[k] of the winds of levels k-1 and k in the
+    // dsigma-weighted mean at interface k (dyn_functions.py:236-241), dsigma[k] / (dsigma[k] + dsigma[k-1]) and
+    // dsigma[k-1] / (...); c_rds = 1 / dsigma; sigma_vb; UVFLX_dif_coef
+    // Read through the constant address space: the kernel stores through u_out / v_out, so the compiler cannot prove
+    // a plain global load unclobbered and would issue it as a VECTOR load -- whose wait (vmcnt is in order) drains the
+    // DMA prefetch.  Constant-address-space loads at a wave-uniform index are scalar loads (s_load, lgkmcnt).
+    const int cs = nz + 2;
+    typedef const __attribute__((address_space(4))) real cdouble_t;
+    cdouble_t *c_wa = (cdouble_t *)p.mom_c, *c_wb = c_wa + cs, *c_rds = c_wa + 2 * cs, *c_svb = c_wa + 3 * cs, *c_dif = c_wa + 4 * cs;
+    // factors of the flux-tile entries this lane forms (FROM_WINDS), same element -> grid cell map as its DMA chunks
+    // (the column pressures in registers, the metric factors dyis / dxjs in two LDS tiles: the register file is full)
+    const int chf = ch;
+    const bool flux_lane = wave < NSL && dma_on;
+    real f_uc[VW], f_vc[VW];
+#pragma unroll
+    for (int d = 0; d < VW; d++) { f_uc[d] = 0.0; f_vc[d] = 0.0; }
+    real *fac = dsm + NS * DSLOT + 2 * FSLOT;
+    if (FROM_WINDS) {
+        for (int e = tid; e < (TJ + 3) * FTW; e += FTI * NTW) {
+            const int r = e / FTW, cc = e - r * FTW, c2 = cc - cc % VW;
+            const int gi = min(i0 - FXO + c2, P - VW) + (cc - c2);
+            const int o = min(j0 - 1 + r, g.NJ - 1) * P + gi;
+            // the reference never fills column nx+2 of its x-staggered grid arrays (main_grid.py:317-357):
+            // take the periodic image the UFLX halo copy would have delivered
+            if (e < (TJ + 2) * FTW) fac[mom_off(S_UF, TJ, true) + e] = p.dyis[gi == g.nx + 2 ? o - g.nx : o];
+            fac[mom_off(S_VF, TJ, true) + e] = p.dxjs[o];
+        }
+        if (flux_lane) {
+#pragma unroll
+            for (int d = 0; d < VW; d++) {
+                const int e = VW * chf + d;
+                const int r = e / FTW, cc = e - r * FTW, c2 = cc - cc % VW;
+                const int o = min(j0 - 1 + r, g.NJ - 1) * P + min(i0 - FXO + c2, P - VW) + (cc - c2);
+                f_uc[d] = p.UCOL[o];
+                f_vc[d] = p.VCOL[o];
+            }
+        }
+        lds_barrier();          // the factor tiles are complete before the first flux entries are formed
+    }
+    // flux tiles of a level (FROM_WINDS): every DMA lane turns the chunks IT moved into UFLX / VFLX
+    // entries as soon as its own loads have landed -- no barrier between the DMA and this step, the one at
+    // the end of the level publishes both
+    auto flux_own = [&](int slot, int fslot) {
+        if (FROM_WINDS && flux_lane) {
+            const real *nb = dsm + slot * DSLOT;
+            real *nf = dsm + NS * DSLOT + fslot * FSLOT;
+            const int e = VW * chf;
+#pragma unroll
+            for (int d = 0; d < VW; d++) {
+                if (e + d < (TJ + 2) * FTW) nf[mom_off(S_UF, TJ, true) + e + d] = f_uc[d] * nb[mom_off(S_UW, TJ, true) + e + d] * fac[mom_off(S_UF, TJ, true) + e + d];
+                nf[mom_off(S_VF, TJ, true) + e + d] = f_vc[d] * nb[mom_off(S_VW, TJ, true) + e + d] * fac[mom_off(S_VF, TJ, true) + e + d];
+            }
+        }
+    };
+    const int lx = tx + FXO, ly = ty + 1; // tile column 0 is longitude i0 - FXO (16-B aligned in HBM)
+    // field f of the level being computed: `db` = its DMA slot, `fb` = its flux slot
+#define SM(f, a, b) ((FROM_WINDS && (f) < 2) ? fb : db)[MOFF(f) + (ly + (b)) * FTW + (lx + (a))]
+
+    // =====================================================================================================
+    // temperature wavefronts (WITH_TEMP): k_pott_fused's bottom-up sweep of one column on the tiles the momentum
+    // wavefronts stage -- same helper functions, same bits.  They move the own-cell tiles and keep step with the
+    // momentum wavefronts' barriers; the four outputs of a level are stored at the start of the next iteration,
+    // in front of that iteration's DMA, like the momentum wavefronts' (counted vmcnt, above).
+    if (WITH_TEMP && role_t) {
+        const size_t c = at2(g, active ? i : 1, active ? j : 1);
+        const real cnew = p.COLP_NEW[c];
+        const TempCol tc = {p.COLP[c], cnew, p.COLP_OLD[c], p.COLP[c - 1], p.COLP[c + 1], p.COLP[c - P], p.COLP[c + P],
+                            (real)(0.5 * (1.0 / p.A[c])), (real)(1.0 / cnew)};
+        cdouble_t *c_sig = (cdouble_t *)p.sigma_vb, *c_rdst = (cdouble_t *)p.rdsigma, *c_tdif = (cdouble_t *)p.POTT_dif_coef;
+        const size_t pl = (size_t)g.plane;
+        real p_kp12 = interface_pressure(g.pair_top, c_sig[nz], cnew);
+        real pvb_kp1 = exner_vb(p_kp12);
+        real phivb_kp1 = p.HSURF[c] * CON_G;
+        real w_kp1 = p.WWIND[c + (size_t)nz * pl], pvbo_kp1 = p.POTTVB[c + (size_t)nz * pl];
+        real pottn_kp1 = 0.0, pvtf_kp1 = 0.0, pottvb_first = 0.0;
+        real p_up = interface_pressure(g.pair_top, c_sig[nz - 1], cnew), pvb_up = exner_vb(p_up);
+        if (active) ta.pvb_out[c + (size_t)nz * pl] = pvb_kp1;
+        real o_pott = 0.0, o_pvb = 0.0, o_phi = 0.0, o_vb = 0.0, o_sfc = 0.0;       // outputs of level k+1, stored one iteration late
+        {   // every value loaded above is complete before the level loop starts (see the momentum wavefronts)
+            real t0 = tc.colp, t1 = tc.cold, t2 = tc.c_im1, t3 = tc.c_ip1, t4 = tc.c_jm1, t5 = tc.c_jp1, t6 = tc.hr_area, t7 = tc.r_cnew;
+            asm volatile("" : "+v"(t0), "+v"(t1), "+v"(t2), "+v"(t3), "+v"(t4), "+v"(t5), "+v"(t6), "+v"(t7), "+v"(phivb_kp1), "+v"(w_kp1), "+v"(pvbo_kp1), "+v"(pvb_up));
+        }
+        constexpr int OWN_PVB = OFF_OLD + (OLD_IS_CUR ? 0 : 2) * ON, OWN_PO = OFF_OLD + 3 * ON;
+        issue(nz - 1, 0);
+        if (nz >= 2) issue(nz - 2, 1);
+        wait_vmcnt(nz >= 2 ? n_issue : 0);
+        lds_barrier();          // (the flux tiles of level nz-1: the momentum wavefronts)
+        int slot = 0;
+#pragma unroll 1
+        for (int k = nz - 1; k >= 0; k--) {
+            int slot1 = slot + 1;
+            if (slot1 == NS) slot1 = 0;
+            // ---- the outputs of level k+1 ----
+            if (active && k + 1 < nz) {
+                const size_t q1 = c + (size_t)(k + 1) * pl;
+                __builtin_nontemporal_store(o_pott, ta.pott_out + q1);
+                __builtin_nontemporal_store(o_pvb, ta.pvb_out + q1);
+                __builtin_nontemporal_store(o_phi, ta.phi_out + q1);
+                if (k + 1 < nz - 1) {
+                    __builtin_nontemporal_store(o_vb, p.POTTVB + q1 + pl);
+                    if (k + 1 == nz - 2 && nz > 2) __builtin_nontemporal_store(o_sfc, p.POTTVB + c + (size_t)nz * pl);   // surface extrapolation
+                }
+            }
+            asm volatile("" ::: "memory");      // the stores above stay above the DMA below
+            if (k - 2 >= 0 && DYC_MOM_MODE != 2) issue(k - 2, (slot + 2) % NS);
+            const real *db = dsm + slot * DSLOT;
+            const real *fb = dsm + NS * DSLOT + (k & 1) * FSLOT;
+            if (active && DYC_MOM_MODE != 1) {
+                const real pt = SM(S_POTT, 0, 0);
+                real w_k = 0.0, pvbo_k = 0.0;
+                if (k > 0) { w_k = SM(S_W, 0, 0); pvbo_k = db[OWN_PVB + ty * FTI + tx]; }
+                const real po = OLD_IS_CUR ? pt : db[OWN_PO + ty * FTI + tx];
+                // tendency and Euler step on the re-formed mass-flux tiles (the values k_pott_fused re-forms itself)
+                const real pott = temp_new_pott(tc, SM(S_UF, 0, 0), SM(S_UF, 1, 0), SM(S_VF, 0, 0), SM(S_VF, 0, 1),
+                                                pt, SM(S_POTT, -1, 0), SM(S_POTT, 1, 0), SM(S_POTT, 0, -1), SM(S_POTT, 0, 1),
+                                                w_k, pvbo_k, w_kp1, pvbo_kp1, c_rdst[k], c_tdif[k], false, (real)0.0, false, (real)0.0, po, dt);
+                // diagnostics of the new column, level k (k_pott_fused: the pow of the next interface one level ahead)
+                const DiagLevel dl = diag_level_pre(p_up, pvb_up, pott, p_kp12, pvb_kp1, phivb_kp1);
+                if (k > 0) {
+                    p_up = interface_pressure(g.pair_top, c_sig[k - 1], cnew);
+                    pvb_up = exner_vb(p_up);
+                }
+                real vb = 0.0;
+                if (k < nz - 1) {
+                    vb = pottvb_between(pvb_kp1, dl.pvtf, pott, pvtf_kp1, pottn_kp1);
+                    if (k == nz - 2) o_sfc = pottn_kp1 - (vb - pottn_kp1);      // dyn_diagnostics.py:191-194, from the level below
+                    if (k == 0) pottvb_first = vb;
+                }
+                o_pott = pott; o_pvb = dl.pvb_k; o_phi = dl.phi; o_vb = vb;
+                p_kp12 = dl.p_km12; pvb_kp1 = dl.pvb_k; phivb_kp1 = dl.phivb;
+                pottn_kp1 = pott; pvtf_kp1 = dl.pvtf;
+                w_kp1 = w_k; pvbo_kp1 = pvbo_k;
+            }
+            if (k - 1 >= 0 && DYC_MOM_MODE != 2) wait_vmcnt(k - 2 >= 0 ? n_issue : 0);      // level k-1 has landed
+            lds_barrier();
+            slot = slot1;
+        }
+        if (active) {       // level 0 and the model top
+            __builtin_nontemporal_store(o_pott, ta.pott_out + c);
+            __builtin_nontemporal_store(o_pvb, ta.pvb_out + c);
+            __builtin_nontemporal_store(o_phi, ta.phi_out + c);
+            if (nz >= 2) {
+                __builtin_nontemporal_store(o_vb, p.POTTVB + c + pl);
+                __builtin_nontemporal_store(pottn_kp1 - (pottvb_first - pottn_kp1), p.POTTVB + c);
+            }
+        }
+        return;
+    }
+    // =====================================================================================================
+    // momentum wavefronts
+    // (their instruction stream has the LDS reads the level's arithmetic waits for: issue priority over the temperature
+    // wavefront of the same SIMD, -2 % per launch)
+    if (WITH_TEMP) __builtin_amdgcn_s_setprio(3);
     // ---- per-column (2-D) quantities ----
     const size_t c = at2(g, active ? i : 1, active ? j : 1);
     const int jg = j + g.joff;
@@ -629,10 +853,6 @@ __global__ __launch_bounds__(FTI *TJ, (TJ <= 4 ? 2 : 1)) void k_momentum_dma(Geo
     // PVTF in the thread (FROM_WINDS): 1 / ((1 + kappa) COLP) at the own cell and its western / southern neighbour
     const real rcp_c = 1.0 / ((1.0 + CON_KAPPA) * colp), rcp_im1 = 1.0 / ((1.0 + CON_KAPPA) * colp_im1), rcp_jm1 = 1.0 / ((1.0 + CON_KAPPA) * colp_jm1);
 
-    const int lx = tx + FXO, ly = ty + 1; // tile column 0 is longitude i0 - FXO (16-B aligned in HBM)
-    // field f of the level being computed: `db` = its DMA slot, `fb` = its flux slot
-#define SM(f, a, b) ((FROM_WINDS && (f) < 2) ? fb : db)[MOFF(f) + (ly + (b)) * FTW + (lx + (a))]
-
     // carried across levels.  The column is walked BOTTOM-UP (level k1-1 first), the direction of the hydrostatic
     // integration, so that PHI can be carried along (PHI_LOCAL); the vertical advection of a level is closed one
     // iteration late, when the winds of the level above it are at hand for its upper interface
@@ -660,72 +880,18 @@ __global__ __launch_bounds__(FTI *TJ, (TJ <= 4 ? 2 : 1)) void k_momentum_dma(Geo
         else { const size_t o = (size_t)k1 * g.plane; phivb_c = p.PHIVB[c + o]; phivb_w = p.PHIVB[cw + o]; phivb_s = p.PHIVB[c - P + o]; }
     }
 
-    // per-level constants (p.mom_c, stride nz + 2): weights c_wa[k], c_wb[k] of the winds of levels k-1 and k in the
-    // dsigma-weighted mean at interface k (dyn_functions.py:236-241), dsigma[k] / (dsigma[k] + dsigma[k-1]) and
-    // dsigma[k-1] / (...); c_rds = 1 / dsigma; sigma_vb; UVFLX_dif_coef
-    // Read through the constant address space: the kernel stores through u_out / v_out, so the compiler cannot prove
-    // a plain global load unclobbered and would issue it as a VECTOR load -- whose wait (vmcnt is in order) drains the
-    // DMA prefetch.  Constant-address-space loads at a wave-uniform index are scalar loads (s_load, lgkmcnt).
-    const int cs = nz + 2;
-    typedef const __attribute__((address_space(4))) real cdouble_t;
-    cdouble_t *c_wa = (cdouble_t *)p.mom_c, *c_wb = c_wa + cs, *c_rds = c_wa + 2 * cs, *c_svb = c_wa + 3 * cs, *c_dif = c_wa + 4 * cs;
-    // factors of the flux-tile entries this lane forms (FROM_WINDS), same element -> grid cell map as its DMA chunks
-    // (the column pressures in registers, the metric factors dyis / dxjs in two LDS tiles: the register file is full)
-    real f_uc[VW], f_vc[VW];
-#pragma unroll
-    for (int d = 0; d < VW; d++) { f_uc[d] = 0.0; f_vc[d] = 0.0; }
-    real *fac = dsm + NS * DSLOT + 2 * FSLOT;
-    if (FROM_WINDS) {
-        for (int e = tid; e < (TJ + 3) * FTW; e += FTI * TJ) {
-            const int r = e / FTW, cc = e - r * FTW, c2 = cc - cc % VW;
-            const int gi = min(i0 - FXO + c2, P - VW) + (cc - c2);
-            const int o = min(j0 - 1 + r, g.NJ - 1) * P + gi;
-            // the reference never fills column nx+2 of its x-staggered grid arrays (main_grid.py:317-357):
-            // take the periodic image the UFLX halo copy would have delivered
-            if (e < (TJ + 2) * FTW) fac[mom_off(S_UF, TJ, true) + e] = p.dyis[gi == g.nx + 2 ? o - g.nx : o];
-            fac[mom_off(S_VF, TJ, true) + e] = p.dxjs[o];
-        }
-        if (wave < NSL && dma_on) {
-#pragma unroll
-            for (int d = 0; d < VW; d++) {
-                const int e = VW * ch + d;
-                const int r = e / FTW, cc = e - r * FTW, c2 = cc - cc % VW;
-                const int o = min(j0 - 1 + r, g.NJ - 1) * P + min(i0 - FXO + c2, P - VW) + (cc - c2);
-                f_uc[d] = p.UCOL[o];
-                f_vc[d] = p.VCOL[o];
-            }
-        }
-        lds_barrier();          // the factor tiles are complete before the first flux entries are formed
-    }
-    // flux tiles of a level (FROM_WINDS): every DMA lane turns the chunks IT moved into UFLX / VFLX
-    // entries as soon as its own loads have landed -- no barrier between the DMA and this step, the one at
-    // the end of the level publishes both
-    auto flux_own = [&](int slot, int fslot) {
-        if (FROM_WINDS && wave < NSL && dma_on) {
-            const real *nb = dsm + slot * DSLOT;
-            real *nf = dsm + NS * DSLOT + fslot * FSLOT;
-            const int e = VW * ch;
-#pragma unroll
-            for (int d = 0; d < VW; d++) {
-                if (e + d < (TJ + 2) * FTW) nf[mom_off(S_UF, TJ, true) + e + d] = f_uc[d] * nb[mom_off(S_UW, TJ, true) + e + d] * fac[mom_off(S_UF, TJ, true) + e + d];
-                nf[mom_off(S_VF, TJ, true) + e + d] = f_vc[d] * nb[mom_off(S_VW, TJ, true) + e + d] * fac[mom_off(S_VF, TJ, true) + e + d];
-            }
-        }
-    };
     // the values loaded above are complete before the level loop starts: left to itself the compiler waits for them at
     // their first use, inside the loop, where a vector-memory wait drains the DMA levels in flight
     asm volatile("" : "+v"(su_kp1), "+v"(sv_kp1), "+v"(u_kp1), "+v"(v_kp1), "+v"(pvb_kp1), "+v"(pvb_im1_kp1), "+v"(pvb_jm1_kp1), "+v"(phivb_c), "+v"(phivb_w), "+v"(phivb_s));
     // ---- prologue: the first DEPTH levels go out; level k1-1 lands and its flux tiles are formed ----
     issue(k1 - 1, 0);
-    if (DEPTH == 2 && k1 - 2 >= k0) issue(k1 - 2, 1);
+    if (AHEAD >= 2 && k1 - 2 >= k0) issue(k1 - 2, 1);
+    if (AHEAD >= 3 && k1 - 3 >= k0) issue(k1 - 3, 2);
     real tbu_nx = 0.0, tbv_nx = 0.0;  // turbulent tendencies of the next level
     if (TURB) { tbu_nx = p.TURB_U[c + (size_t)(k1 - 1) * g.plane]; tbv_nx = v_on ? p.TURB_V[c + (size_t)(k1 - 1) * g.plane] : 0.0; }
-    wait_vmcnt((DEPTH == 2 && k1 - 2 >= k0) ? n_issue : 0);
+    wait_vmcnt((AHEAD >= 2 && k1 - AHEAD >= k0) ? n_issue : 0);        // everything but the last level issued has landed
     flux_own(0, (k1 - 1) & 1);
     lds_barrier();
-#ifndef DYC_MOM_MODE
-#define DYC_MOM_MODE 0      // experiment builds only: 1 = data movement without the arithmetic, 2 = arithmetic without the data movement
-#endif
     int slot = 0;                       // ring slot of level k
 #pragma unroll 1
     for (int k = k1 - 1; k >= k0; k--) {
@@ -775,11 +941,7 @@ __global__ __launch_bounds__(FTI *TJ, (TJ <= 4 ? 2 : 1)) void k_momentum_dma(Geo
         }
         if (DEPTH == 2) {
             asm volatile("" ::: "memory");      // the stores above stay above the DMA below
-            if (k - 2 >= k0 && DYC_MOM_MODE != 2) {
-                int slot2 = slot1 + 1;
-                if (slot2 == NS) slot2 = 0;
-                issue(k - 2, slot2);
-            }
+            if (k - AHEAD >= k0 && DYC_MOM_MODE != 2) issue(k - AHEAD, (slot + AHEAD) % NS);
         }
         if (DYC_MOM_MODE != 1 && active) {
             real uf[3][4], vf[4][3], uw[3][3], vw[3][3];
@@ -920,7 +1082,7 @@ __global__ __launch_bounds__(FTI *TJ, (TJ <= 4 ? 2 : 1)) void k_momentum_dma(Geo
         }
         // this wave's part of level k-1 has landed (the deeper prefetch stays in flight); form its flux entries
         if (k - 1 >= k0 && DYC_MOM_MODE != 2) {
-            wait_vmcnt((DEPTH == 2 && k - 2 >= k0) ? n_issue : 0);
+            wait_vmcnt((DEPTH == 2 && k - AHEAD >= k0) ? n_issue : 0);        // level k - AHEAD + 1 has landed
             flux_own(slot1, (k - 1) & 1);
         }
         lds_barrier();         // level k-1 is in LDS for every wave; slot `slot` is free again
@@ -1227,7 +1389,7 @@ __global__ __launch_bounds__(TI *TJ) void k_pott_fused(Geo g, Ptrs p, const real
     const real area = p.A[c];
     // as in k_momentum_dma: divisions by per-column / per-level quantities as multiplications by
     // reciprocals formed once (<= 1 ulp per operation); the diagnostics below keep their divisions
-    const real r_area = 1.0 / area, r_cnew = 1.0 / cnew;
+    const TempCol tc = {colp, cnew, cold, c_im1, c_ip1, c_jm1, c_jp1, (real)(0.5 * (1.0 / area)), (real)(1.0 / cnew)};
     // surface interface of the new column
     real p_kp12 = interface_pressure(g.pair_top, p.sigma_vb[nz], cnew);
     real pvb_kp1 = exner_vb(p_kp12);
@@ -1263,28 +1425,12 @@ __global__ __launch_bounds__(TI *TJ) void k_pott_fused(Geo g, Ptrs p, const real
             cur.vf = (c_jm1 + colp) / 2.0 * cur.vf * m_dx0;
             cur.vf1 = (colp + c_jp1) / 2.0 * cur.vf1 * m_dx1;
         }
-        const real pt = cur.pt;
-        const real p_im1 = cur.im1, p_ip1 = cur.ip1, p_jm1 = cur.jm1, p_jp1 = cur.jp1;
-        const real rds = p.rdsigma[k];
-        real t = 0.0;
-        t = t + (+cur.uf * (p_im1 + pt) / 2.0 - cur.uf1 * (pt + p_ip1) / 2.0
-                 + cur.vf * (p_jm1 + pt) / 2.0 - cur.vf1 * (pt + p_jp1) / 2.0)
-                * r_area;
         real w_k = 0.0, pvbo_k = 0.0;
-        if (k == 0) {
-            t = t + cnew * (-w_kp1 * pvbo_kp1) * rds;
-        } else {
-            w_k = cur.w;
-            pvbo_k = cur.pvb;
-            t = t + cnew * (+w_k * pvbo_k - w_kp1 * pvbo_kp1) * rds;
-        }
-        if (TURB) t = t + cur.tb;                       // k_turb_tendencies (dyn_functions.py:26-67)
-        const real dif = p.POTT_dif_coef[k];
-        if (dif > 0.0)
-            t = t + dif * (c_im1 * p_im1 + c_ip1 * p_ip1 + c_jm1 * p_jm1 + c_jp1 * p_jp1 - 4.0 * colp * pt);
-        if (g.i_rad) t = t + ldb(p.dPOTTdt_RAD, q) * colp;
-        // Euler forward, pressure weighted
-        const real pott = cur.po * cold * r_cnew + dt * t * r_cnew;
+        if (k > 0) { w_k = cur.w; pvbo_k = cur.pvb; }
+        // tendency (turbulent part from k_turb_tendencies, dyn_functions.py:26-67) and Euler forward, pressure weighted
+        const real pott = temp_new_pott(tc, cur.uf, cur.uf1, cur.vf, cur.vf1, cur.pt, cur.im1, cur.ip1, cur.jm1, cur.jp1,
+                                        w_k, pvbo_k, w_kp1, pvbo_kp1, p.rdsigma[k], p.POTT_dif_coef[k],
+                                        TURB, cur.tb, g.i_rad, g.i_rad ? ldb(p.dPOTTdt_RAD, q) : (real)0.0, cur.po, dt);
         stb(pott_out, q, pott);
         // diagnostics of the new column, level k
         // the interface pressure of this level's upper interface and its Exner value (one pow) were formed during the

@@ -27,31 +27,36 @@ def main():
         name = L[st].split(':')[0]
         en = next(i for i in range(st, len(L)) if L[i].strip().startswith('.Lfunc_end'))
         body = L[st:en]
-        m = re.search(r'k_momentum_dmaILb([01])ELi(\d+)ELb([01])ELb([01])ELi(\d)E', name)
-        cur, tj, fw, turb, depth = m.groups()
+        m = re.search(r'k_momentum_dmaILb([01])ELi(\d+)ELb([01])ELb([01])ELi(\d)ELb([01])ELb([01])E', name)
+        cur, tj, fw, turb, depth, pl, wt = m.groups()
         # the level loop: the loop (lines grouped by their header label) that contains the DMA instructions
         groups = {}
         for i, l in enumerate(body):
             mm = re.search(r'Loop: Header=(BB\d+_\d+)', l) or re.search(r'^\.L(BB\d+_\d+):.*This Inner Loop Header', l)
             if mm: groups.setdefault(mm.group(1), []).append(i)
-        lo = hi = 0
+        spans = []
         for hdr, idx in groups.items():
             a = min(idx)
             b = next((i for i in range(max(idx) + 1, len(body)) if re.match(r'^\.LBB\d+_\d+:', body[i])), len(body))
-            if any('global_load_lds' in l for l in body[a:b]) and b - a > hi - lo: lo, hi = a, b
+            if any('global_load_lds' in l for l in body[a:b]): spans.append((a, b))
+        # innermost DMA loops only (a WITH_TEMP instance has two: the momentum and the temperature wavefronts')
+        spans = [sp for sp in spans if not any(o != sp and sp[0] <= o[0] and o[1] <= sp[1] for o in spans)]
         found = []
-        for i in range(lo, hi):
-            l = body[i].strip()
-            if l.startswith('s_waitcnt') and 'vmcnt' in l:
-                # the kernel's own waits sit between ASMSTART / ASMEND markers
-                own = any('ASMSTART' in body[j] for j in range(max(lo, i - 3), i))
-                if not own: found.append('line %d: %s' % (i, l))
-            if re.match(r'scratch_|buffer_(load|store)', l): found.append('line %d: %s (spill)' % (i, l))
-        ndma = sum('global_load_lds' in l for l in body[lo:hi])
+        ndma = 0
+        for lo, hi in spans:
+            for i in range(lo, hi):
+                l = body[i].strip()
+                if l.startswith('s_waitcnt') and 'vmcnt' in l:
+                    # the kernel's own waits sit between ASMSTART / ASMEND markers
+                    own = any('ASMSTART' in body[j] for j in range(max(lo, i - 3), i))
+                    if not own: found.append('line %d: %s' % (i, l))
+                if re.match(r'scratch_|buffer_(load|store)', l): found.append('line %d: %s (spill)' % (i, l))
+            ndma += sum('global_load_lds' in l for l in body[lo:hi])
+        lo, hi = (min(a for a, b in spans), max(b for a, b in spans)) if spans else (0, 0)
         tag = 'predictor' if cur == '1' else 'corrector'
         prod = fw == '1' and turb == '0'
-        print('%-9s TJ=%s fw=%s turb=%s depth=%s: loop %d lines, %d DMA instructions, findings: %s' % (
-            tag, tj, fw, turb, depth, hi - lo, ndma, found or 'none'))
+        print('%-9s TJ=%s fw=%s turb=%s depth=%s phi_local=%s with_temp=%s: %d level loop(s), %d DMA instructions, findings: %s' % (
+            tag, tj, fw, turb, depth, pl, wt, len(spans), ndma, found or 'none'))
         if found and prod: bad = 1
     return bad
 

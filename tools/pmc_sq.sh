@@ -13,7 +13,7 @@ for f in glob.glob('$R/gpurun_out/pmc_sq_$1/**/*counter_collection.csv', recursi
         k = row['Kernel_Name'].split('(')[0].replace('void ', '')
         tot[k][row['Counter_Name']] += float(row['Counter_Value']); n[k].add(row['Dispatch_Id'])
 for k in sorted(tot):
-    if 'momentum' in k or 'pott' in k or 'continuity_reg' in k or 'moist' in k:
+    if 'momentum' in k or 'substep' in k or 'pott' in k or 'continuity_reg' in k or 'moist' in k:
         t = tot[k]; nl = len(n[k]); wc = t['SQ_WAVE_CYCLES'] or 1
         print('%-34s n=%2d waves %.0f  wave_cycles %.3e  wait_any %.0f%%  wait_inst %.0f%%  active_any %.0f%%  active_valu %.0f%%  valu insts/wave %.0f' % (
             k[:34], nl, t['SQ_WAVES'] / nl, wc / nl, 100 * t['SQ_WAIT_ANY'] / wc, 100 * t['SQ_WAIT_INST_ANY'] / wc,

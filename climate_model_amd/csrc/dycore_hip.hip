@@ -153,7 +153,7 @@ struct dycore {
     bool winds_bc_dirty = true;     // UWIND / VWIND came from the host: their lateral BC images (column nx+2!) may be unset
     int n_cu = 256;                 // compute units of the device
     // momentum + temperature of a substep in ONE launch (k_momentum_dma<..., WITH_TEMP>; DYCORE_STEP_FUSED=0: two kernels):
-    // the whole grid on one GPU, dry or moist, no turbulence coupling, no radiative heating
+    // the whole grid on one GPU, dry or moist, with or without radiative heating, no turbulence coupling
 #ifdef DYCORE_FLOAT32
     // (float build: off -- there the compiler contracts the momentum arithmetic of the two instantiations differently, a few
     // cells per 1e4 differ by rounding between a band on the separate kernels and the single-GPU run, tests/test_f32.py)
@@ -616,7 +616,7 @@ int do_momentum_fused(dycore *h, const Ptrs &p, const real *u_old, const real *v
 // momentum + temperature in one launch: see k_momentum_dma<..., WITH_TEMP>
 bool substep_fused(const dycore *h)
 {
-    return h->step_fused && h->pvb_alt && h->phi_alt && h->g.pole_s && h->g.pole_n && !h->g.i_rad && pvtf_on_demand(h) && !phi_on_demand(h) &&
+    return h->step_fused && h->pvb_alt && h->phi_alt && h->g.pole_s && h->g.pole_n && pvtf_on_demand(h) && !phi_on_demand(h) &&
            h->mom_tj == 4 && h->g.nz >= 2;
 }
 int do_substep_fused(dycore *h, const Ptrs &p, const real *u_old, const real *v_old, const real *pott_old,
@@ -1041,7 +1041,7 @@ int dycore_create(const DycoreConfig *cfg, dycore_t **out)
         rc = alloc((size_t)(5 * (g.nz + 2)), &d);
         h->p.mom_c = d;
     }
-    if (!rc && h->step_fused && g.pole_s && g.pole_n && !g.i_turb && !g.i_rad) {       // (substep_fused: the other conditions can change with the grid)
+    if (!rc && h->step_fused && g.pole_s && g.pole_n && !g.i_turb) {       // (substep_fused: the other conditions can change with the grid)
         rc = alloc(h->field_elems(-1), &h->pvb_alt);         // nz + 1 planes
         if (!rc) rc = alloc(h->field_elems(0), &h->phi_alt);
     }

@@ -370,8 +370,8 @@ constexpr int mom_off(int f, int tj, bool fw, bool pl = false, bool wt = false) 
     for (int g = (fw ? 2 : 0); g < f; g++) o += mom_rows(g, tj, fw, pl, wt) * FTW;
     return o;
 }
-// own-cell tiles behind the staged ones (FTI wide): the step-start winds of the corrector; WITH_TEMP: + POTTVB, + the step-start POTT of the corrector
-constexpr int mom_own_tiles(bool cur, bool wt) { return (cur ? 0 : 2) + (wt ? (cur ? 1 : 2) : 0); }
+// own-cell tiles behind the staged ones (FTI wide): the step-start winds of the corrector; WITH_TEMP: + POTTVB, + the step-start POTT of the corrector, + dPOTTdt_RAD
+constexpr int mom_own_tiles(bool cur, bool wt) { return (cur ? 0 : 2) + (wt ? (cur ? 1 : 2) + 1 : 0); }       // (+ 1: the radiative heating rate, staged only on a handle with i_radiation)
 constexpr int mom_dma_slot(int tj, bool fw, bool cur, bool pl = false, bool wt = false) { return mom_off(FNF, tj, fw, pl, wt) + mom_own_tiles(cur, wt) * FTI * tj; }
 constexpr int mom_flux_slot(int tj, bool fw) { return fw ? (2 * tj + 5) * FTW : 0; }
 // ... then (fw) two factor tiles, dyis (tj+2 rows) and dxjs (tj+3 rows), shaped like the UFLX / VFLX tiles
@@ -382,6 +382,9 @@ constexpr size_t dma_lds_bytes(int tj, bool fw, bool cur, int depth, bool pl = f
 
 #ifndef DYC_DMA_AUX
 #define DYC_DMA_AUX 0       // cache policy of the LDS-DMA loads (2 = nt)
+#endif
+#ifndef DYC_WT_SKIP
+#define DYC_WT_SKIP 0       // experiment builds only (wrong results): WITH_TEMP without the temperature (1) / momentum (2) arithmetic
 #endif
 #ifndef DYC_MOM_MODE
 #define DYC_MOM_MODE 0      // experiment builds only: 1 = data movement without the arithmetic, 2 = arithmetic without the data movement
@@ -567,10 +570,11 @@ __global__ __launch_bounds__(FTI *TJ *(WITH_TEMP ? 2 : 1), ((TJ <= 4 && !WITH_TE
     }
     // a slice of a step-start tile = VW rows of OCPR chunks (16 B each, i0 is 16-B aligned): lane -> (row, column)
     const int orow = lane / OCPR, ocol = i0 + VW * (lane % OCPR);
-    constexpr int NOWN = mom_own_tiles(OLD_IS_CUR, WITH_TEMP);         // own-cell tiles: [u_old, v_old,] [POTTVB, [pott_old]]
-    if (WITH_TEMP) {            // the temperature wavefronts move them: slice s (of NOWN * ONSL) by wavefront TJ + s % TJ
+    constexpr int NOWN = mom_own_tiles(OLD_IS_CUR, WITH_TEMP);         // own-cell tiles: [u_old, v_old,] [POTTVB, [pott_old,]] [dPOTTdt_RAD]
+    const int nown = (WITH_TEMP && !g.i_rad) ? NOWN - 1 : NOWN;        // ... the last one only with radiative heating
+    if (WITH_TEMP) {            // the temperature wavefronts move them: slice s (of nown * ONSL) by wavefront TJ + s % TJ
         if (role_t)
-            for (int s5 = wave - TJ; s5 < NOWN * ONSL; s5 += TJ) n_issue++;
+            for (int s5 = wave - TJ; s5 < nown * ONSL; s5 += TJ) n_issue++;
     } else {
         if (!OLD_IS_CUR && !OLD_SHARED && wave >= TJ - 2) n_issue = ONSL;
         if (!OLD_IS_CUR && OLD_SHARED && wave < 2 * ONSL) n_issue++;
@@ -593,10 +597,10 @@ __global__ __launch_bounds__(FTI *TJ *(WITH_TEMP ? 2 : 1), ((TJ <= 4 && !WITH_TE
         }
         if (WITH_TEMP) {
             if (role_t) {
-                const real *own[4] = {OLD_IS_CUR ? p.POTTVB : u_old, OLD_IS_CUR ? nullptr : v_old, p.POTTVB, ta.pott_old};
+                const real *own[5] = {OLD_IS_CUR ? p.POTTVB : u_old, OLD_IS_CUR ? p.dPOTTdt_RAD : v_old, p.POTTVB, ta.pott_old, p.dPOTTdt_RAD};
 #pragma unroll
                 for (int s5 = 0; s5 < NOWN * ONSL; s5++) {
-                    if (s5 % TJ == wave - TJ) {
+                    if (s5 % TJ == wave - TJ && s5 < nown * ONSL) {
                         const real *gp = own[s5 / ONSL] + (size_t)k * g.plane + min(j0 + VW * (s5 % ONSL) + orow, g.NJ - 1) * P + ocol;
                         lds_dma16(gp, buf + OFF_OLD + s5 * 64 * VW);
                     }
@@ -699,7 +703,8 @@ __global__ __launch_bounds__(FTI *TJ *(WITH_TEMP ? 2 : 1), ((TJ <= 4 && !WITH_TE
             real t0 = tc.colp, t1 = tc.cold, t2 = tc.c_im1, t3 = tc.c_ip1, t4 = tc.c_jm1, t5 = tc.c_jp1, t6 = tc.hr_area, t7 = tc.r_cnew;
             asm volatile("" : "+v"(t0), "+v"(t1), "+v"(t2), "+v"(t3), "+v"(t4), "+v"(t5), "+v"(t6), "+v"(t7), "+v"(phivb_kp1), "+v"(w_kp1), "+v"(pvbo_kp1), "+v"(pvb_up));
         }
-        constexpr int OWN_PVB = OFF_OLD + (OLD_IS_CUR ? 0 : 2) * ON, OWN_PO = OFF_OLD + 3 * ON;
+        constexpr int OWN_PVB = OFF_OLD + (OLD_IS_CUR ? 0 : 2) * ON, OWN_PO = OFF_OLD + 3 * ON, OWN_RAD = OFF_OLD + (NOWN - 1) * ON;
+        const bool has_rad = g.i_rad;
         issue(nz - 1, 0);
         if (nz >= 2) issue(nz - 2, 1);
         wait_vmcnt(nz >= 2 ? n_issue : 0);
@@ -724,15 +729,17 @@ __global__ __launch_bounds__(FTI *TJ *(WITH_TEMP ? 2 : 1), ((TJ <= 4 && !WITH_TE
             if (k - 2 >= 0 && DYC_MOM_MODE != 2) issue(k - 2, (slot + 2) % NS);
             const real *db = dsm + slot * DSLOT;
             const real *fb = dsm + NS * DSLOT + (k & 1) * FSLOT;
-            if (active && DYC_MOM_MODE != 1) {
+            if (active && DYC_MOM_MODE != 1 && DYC_WT_SKIP != 1) {
                 const real pt = SM(S_POTT, 0, 0);
                 real w_k = 0.0, pvbo_k = 0.0;
                 if (k > 0) { w_k = SM(S_W, 0, 0); pvbo_k = db[OWN_PVB + ty * FTI + tx]; }
                 const real po = OLD_IS_CUR ? pt : db[OWN_PO + ty * FTI + tx];
+                const real l_uf = SM(S_UF, 0, 0), l_uf1 = SM(S_UF, 1, 0), l_vf = SM(S_VF, 0, 0), l_vf1 = SM(S_VF, 0, 1);
+                const real l_im1 = SM(S_POTT, -1, 0), l_ip1 = SM(S_POTT, 1, 0), l_jm1 = SM(S_POTT, 0, -1), l_jp1 = SM(S_POTT, 0, 1);
                 // tendency and Euler step on the re-formed mass-flux tiles (the values k_pott_fused re-forms itself)
-                const real pott = temp_new_pott(tc, SM(S_UF, 0, 0), SM(S_UF, 1, 0), SM(S_VF, 0, 0), SM(S_VF, 0, 1),
-                                                pt, SM(S_POTT, -1, 0), SM(S_POTT, 1, 0), SM(S_POTT, 0, -1), SM(S_POTT, 0, 1),
-                                                w_k, pvbo_k, w_kp1, pvbo_kp1, c_rdst[k], c_tdif[k], false, (real)0.0, false, (real)0.0, po, dt);
+                const real pott = temp_new_pott(tc, l_uf, l_uf1, l_vf, l_vf1, pt, l_im1, l_ip1, l_jm1, l_jp1,
+                                                w_k, pvbo_k, w_kp1, pvbo_kp1, c_rdst[k], c_tdif[k], false, (real)0.0,
+                                                has_rad, has_rad ? db[OWN_RAD + ty * FTI + tx] : (real)0.0, po, dt);
                 // diagnostics of the new column, level k (k_pott_fused: the pow of the next interface one level ahead)
                 const DiagLevel dl = diag_level_pre(p_up, pvb_up, pott, p_kp12, pvb_kp1, phivb_kp1);
                 if (k > 0) {
@@ -943,7 +950,7 @@ __global__ __launch_bounds__(FTI *TJ *(WITH_TEMP ? 2 : 1), ((TJ <= 4 && !WITH_TE
             asm volatile("" ::: "memory");      // the stores above stay above the DMA below
             if (k - AHEAD >= k0 && DYC_MOM_MODE != 2) issue(k - AHEAD, (slot + AHEAD) % NS);
         }
-        if (DYC_MOM_MODE != 1 && active) {
+        if (DYC_MOM_MODE != 1 && active && !(WITH_TEMP && DYC_WT_SKIP == 2)) {
             real uf[3][4], vf[4][3], uw[3][3], vw[3][3];
 #pragma unroll
             for (int b = 0; b < 3; b++)

@@ -67,7 +67,7 @@ def test_fused_substep_is_what_a_single_gpu_step_runs():
     from climate_model_amd import Namelist, Grid, ModelFields, HipDycore
     from climate_model_amd.synthetic import initialize_fields
     GR = Grid(Namelist(nz=8, dlat_deg=4, dlon_deg=4))
-    for kw, want in ((dict(), True), (dict(i_radiation=1), False), (dict(i_turb=1), False)):
+    for kw, want in ((dict(), True), (dict(i_radiation=1), True), (dict(i_turb=1), False)):
         core = HipDycore(GR.nx, GR.ny, GR.nz, **kw)
         core.set_grid(GR.GRF['HIP'])
         F = ModelFields(GR, core); initialize_fields(GR, F); F.copy_host_to_device()

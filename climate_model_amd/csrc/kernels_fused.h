@@ -454,31 +454,28 @@ __device__ __forceinline__ real dot6(const real (&w)[6], real x0, real x1, real 
 // advection, diffusion, radiative heating) and the pressure-weighted Euler step (dyn_timestep.py:70-79).  Every
 // multiply-add is written out, so both kernels produce the same bits (a latitude band steps on the separate kernels
 // and must reproduce the single-GPU run).  The "/ 2" of the four face means is applied once (a power of two passes
-// through every rounding unchanged); sums are associated left to right as in the reference, with FMA.
-struct TempCol { real colp, cnew, cold, c_im1, c_ip1, c_jm1, c_jp1, hr_area, r_cnew; };
-__device__ __forceinline__ real temp_new_pott(const TempCol &tc, real uf, real uf1, real vf, real vf1,
-                                              real pt, real p_im1, real p_ip1, real p_jm1, real p_jp1,
-                                              real w_k, real pvbo_k, real w_kp1, real pvbo_kp1, real rds, real dif,
-                                              bool has_turb, real turb, bool has_rad, real rad, real po, real dt)
-{
-#pragma clang fp contract(off)
-    real s = mul_rn(uf, p_im1 + pt);
-    s = fma(-uf1, pt + p_ip1, s);
-    s = fma(vf, p_jm1 + pt, s);
-    s = fma(-vf1, pt + p_jp1, s);
-    real t = mul_rn(s, tc.hr_area);
-    const real v = fma(w_k, pvbo_k, -mul_rn(w_kp1, pvbo_kp1));      // w_k = pvbo_k = 0 at the model top
-    t = fma(mul_rn(tc.cnew, v), rds, t);
-    if (has_turb) t = t + turb;
-    if (dif > 0.0) {
-        real d = mul_rn(tc.c_im1, p_im1);
-        d = fma(tc.c_ip1, p_ip1, d); d = fma(tc.c_jm1, p_jm1, d); d = fma(tc.c_jp1, p_jp1, d);
-        d = fma((real)-4.0 * tc.colp, pt, d);
-        t = fma(dif, d, t);
+// through every rounding unchanged).  A macro, not a function: as a function (arguments in a struct or not) it cost
+// k_pott_fused 24 VGPRs and its third wavefront per SIMD (1.06 -> 1.29 ms per launch).
+// COLP_ ... RCN_: colp, cnew, cold, c_im1, c_ip1, c_jm1, c_jp1, hr_area = 0.5 / A, r_cnew = 1 / cnew as separate scalars (in a
+// struct they cost the same registers as the function)
+#define TEMP_NEW_POTT(OUT_, COLP_, CNEW_, COLD_, CIM1_, CIP1_, CJM1_, CJP1_, HRA_, RCN_, UF_, UF1_, VF_, VF1_, PT_, PIM1_, PIP1_, PJM1_, PJP1_, WK_, PVBOK_, WKP1_, PVBOKP1_, RDS_, DIF_, HAS_TURB_, TURB_, HAS_RAD_, RAD_, PO_, DT_) \
+    real OUT_;                                                                                                          \
+    {                                                                                                                   \
+        const real sx_ = fma(-(UF1_), (PT_) + (PIP1_), mul_rn((UF_), (PIM1_) + (PT_)));                                 \
+        const real sy_ = fma(-(VF1_), (PT_) + (PJP1_), mul_rn((VF_), (PJM1_) + (PT_)));                                 \
+        real t_ = mul_rn(sx_ + sy_, (HRA_));                                                                            \
+        t_ = fma(mul_rn((CNEW_), fma((WK_), (PVBOK_), -mul_rn((WKP1_), (PVBOKP1_)))), (RDS_), t_);   /* w = 0 at the model top */ \
+        if (HAS_TURB_) t_ = t_ + (TURB_);                                                                               \
+        const real dif_ = (DIF_);                                                                                       \
+        if (dif_ > 0.0) {                                                                                               \
+            real d_ = mul_rn((CIM1_), (PIM1_));                                                                         \
+            d_ = fma((CIP1_), (PIP1_), d_); d_ = fma((CJM1_), (PJM1_), d_); d_ = fma((CJP1_), (PJP1_), d_);             \
+            d_ = fma((real)-4.0 * (COLP_), (PT_), d_);                                                                  \
+            t_ = fma(dif_, d_, t_);                                                                                     \
+        }                                                                                                               \
+        if (HAS_RAD_) t_ = fma((RAD_), (COLP_), t_);                                                                    \
+        OUT_ = fma(mul_rn((DT_), t_), (RCN_), mul_rn(mul_rn((PO_), (COLD_)), (RCN_)));                                  \
     }
-    if (has_rad) t = fma(rad, tc.colp, t);
-    return fma(mul_rn(dt, t), tc.r_cnew, mul_rn(mul_rn(po, tc.cold), tc.r_cnew));
-}
 // workgroup barrier that publishes this wave's LDS writes but leaves its vector-memory operations in flight
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
@@ -687,8 +684,8 @@ __global__ __launch_bounds__(FTI *TJ *(WITH_TEMP ? 2 : 1), ((TJ <= 4 && !WITH_TE
     if (WITH_TEMP && role_t) {
         const size_t c = at2(g, active ? i : 1, active ? j : 1);
         const real cnew = p.COLP_NEW[c];
-        const TempCol tc = {p.COLP[c], cnew, p.COLP_OLD[c], p.COLP[c - 1], p.COLP[c + 1], p.COLP[c - P], p.COLP[c + P],
-                            (real)(0.5 * (1.0 / p.A[c])), (real)(1.0 / cnew)};
+        real colp = p.COLP[c], cold = p.COLP_OLD[c], c_im1 = p.COLP[c - 1], c_ip1 = p.COLP[c + 1], c_jm1 = p.COLP[c - P], c_jp1 = p.COLP[c + P];
+        real hr_area = (real)(0.5 * (1.0 / p.A[c])), r_cnew = (real)(1.0 / cnew);
         cdouble_t *c_sig = (cdouble_t *)p.sigma_vb, *c_rdst = (cdouble_t *)p.rdsigma, *c_tdif = (cdouble_t *)p.POTT_dif_coef;
         const size_t pl = (size_t)g.plane;
         real p_kp12 = interface_pressure(g.pair_top, c_sig[nz], cnew);
@@ -700,8 +697,7 @@ __global__ __launch_bounds__(FTI *TJ *(WITH_TEMP ? 2 : 1), ((TJ <= 4 && !WITH_TE
         if (active) ta.pvb_out[c + (size_t)nz * pl] = pvb_kp1;
         real o_pott = 0.0, o_pvb = 0.0, o_phi = 0.0, o_vb = 0.0, o_sfc = 0.0;       // outputs of level k+1, stored one iteration late
         {   // every value loaded above is complete before the level loop starts (see the momentum wavefronts)
-            real t0 = tc.colp, t1 = tc.cold, t2 = tc.c_im1, t3 = tc.c_ip1, t4 = tc.c_jm1, t5 = tc.c_jp1, t6 = tc.hr_area, t7 = tc.r_cnew;
-            asm volatile("" : "+v"(t0), "+v"(t1), "+v"(t2), "+v"(t3), "+v"(t4), "+v"(t5), "+v"(t6), "+v"(t7), "+v"(phivb_kp1), "+v"(w_kp1), "+v"(pvbo_kp1), "+v"(pvb_up));
+            asm volatile("" : "+v"(colp), "+v"(cold), "+v"(c_im1), "+v"(c_ip1), "+v"(c_jm1), "+v"(c_jp1), "+v"(hr_area), "+v"(r_cnew), "+v"(phivb_kp1), "+v"(w_kp1), "+v"(pvbo_kp1), "+v"(pvb_up));
         }
         constexpr int OWN_PVB = OFF_OLD + (OLD_IS_CUR ? 0 : 2) * ON, OWN_PO = OFF_OLD + 3 * ON, OWN_RAD = OFF_OLD + (NOWN - 1) * ON;
         const bool has_rad = g.i_rad;
@@ -734,12 +730,11 @@ __global__ __launch_bounds__(FTI *TJ *(WITH_TEMP ? 2 : 1), ((TJ <= 4 && !WITH_TE
                 real w_k = 0.0, pvbo_k = 0.0;
                 if (k > 0) { w_k = SM(S_W, 0, 0); pvbo_k = db[OWN_PVB + ty * FTI + tx]; }
                 const real po = OLD_IS_CUR ? pt : db[OWN_PO + ty * FTI + tx];
-                const real l_uf = SM(S_UF, 0, 0), l_uf1 = SM(S_UF, 1, 0), l_vf = SM(S_VF, 0, 0), l_vf1 = SM(S_VF, 0, 1);
-                const real l_im1 = SM(S_POTT, -1, 0), l_ip1 = SM(S_POTT, 1, 0), l_jm1 = SM(S_POTT, 0, -1), l_jp1 = SM(S_POTT, 0, 1);
                 // tendency and Euler step on the re-formed mass-flux tiles (the values k_pott_fused re-forms itself)
-                const real pott = temp_new_pott(tc, l_uf, l_uf1, l_vf, l_vf1, pt, l_im1, l_ip1, l_jm1, l_jp1,
-                                                w_k, pvbo_k, w_kp1, pvbo_kp1, c_rdst[k], c_tdif[k], false, (real)0.0,
-                                                has_rad, has_rad ? db[OWN_RAD + ty * FTI + tx] : (real)0.0, po, dt);
+                TEMP_NEW_POTT(pott, colp, cnew, cold, c_im1, c_ip1, c_jm1, c_jp1, hr_area, r_cnew, SM(S_UF, 0, 0), SM(S_UF, 1, 0), SM(S_VF, 0, 0), SM(S_VF, 0, 1),
+                              pt, SM(S_POTT, -1, 0), SM(S_POTT, 1, 0), SM(S_POTT, 0, -1), SM(S_POTT, 0, 1),
+                              w_k, pvbo_k, w_kp1, pvbo_kp1, c_rdst[k], c_tdif[k], false, (real)0.0,
+                              has_rad, db[OWN_RAD + ty * FTI + tx], po, dt)
                 // diagnostics of the new column, level k (k_pott_fused: the pow of the next interface one level ahead)
                 const DiagLevel dl = diag_level_pre(p_up, pvb_up, pott, p_kp12, pvb_kp1, phivb_kp1);
                 if (k > 0) {
@@ -1383,6 +1378,8 @@ __device__ __forceinline__ void stb(real *base, unsigned boff, real v) { __built
 // WRITE_PHI = false: PHI is not stored either -- the production momentum kernel carries it up the column (PHI_LOCAL) from
 // the surface geopotential; for its level chunks PHIVB is stored at every PHIVB_STRIDE-th interface (1/4 of a pass
 // instead of one).  Every other reader gets PHI (and PHIVB) on demand from k_derive_phi.
+// (three workgroups of four wavefronts per CU = three wavefronts per SIMD, <= 168 VGPRs: the kernel waits for its own
+// dependent fp64 chain, a third wavefront is worth 7 %; without the bound the register allocator takes 191)
 template <bool WRITE_PHIVB, bool FROM_WINDS, bool TURB = false, bool WRITE_PVTF = true, bool WRITE_PHI = true>
 __global__ __launch_bounds__(TI *TJ) void k_pott_fused(Geo g, Ptrs p, const real *pott_old, real *pott_out, real dt, int lin)
 {
@@ -1396,7 +1393,7 @@ __global__ __launch_bounds__(TI *TJ) void k_pott_fused(Geo g, Ptrs p, const real
     const real area = p.A[c];
     // as in k_momentum_dma: divisions by per-column / per-level quantities as multiplications by
     // reciprocals formed once (<= 1 ulp per operation); the diagnostics below keep their divisions
-    const TempCol tc = {colp, cnew, cold, c_im1, c_ip1, c_jm1, c_jp1, (real)(0.5 * (1.0 / area)), (real)(1.0 / cnew)};
+    const real hr_area = (real)(0.5 * (1.0 / area)), r_cnew = (real)(1.0 / cnew);
     // surface interface of the new column
     real p_kp12 = interface_pressure(g.pair_top, p.sigma_vb[nz], cnew);
     real pvb_kp1 = exner_vb(p_kp12);
@@ -1435,9 +1432,8 @@ __global__ __launch_bounds__(TI *TJ) void k_pott_fused(Geo g, Ptrs p, const real
         real w_k = 0.0, pvbo_k = 0.0;
         if (k > 0) { w_k = cur.w; pvbo_k = cur.pvb; }
         // tendency (turbulent part from k_turb_tendencies, dyn_functions.py:26-67) and Euler forward, pressure weighted
-        const real pott = temp_new_pott(tc, cur.uf, cur.uf1, cur.vf, cur.vf1, cur.pt, cur.im1, cur.ip1, cur.jm1, cur.jp1,
-                                        w_k, pvbo_k, w_kp1, pvbo_kp1, p.rdsigma[k], p.POTT_dif_coef[k],
-                                        TURB, cur.tb, g.i_rad, g.i_rad ? ldb(p.dPOTTdt_RAD, q) : (real)0.0, cur.po, dt);
+        TEMP_NEW_POTT(pott, colp, cnew, cold, c_im1, c_ip1, c_jm1, c_jp1, hr_area, r_cnew, cur.uf, cur.uf1, cur.vf, cur.vf1, cur.pt, cur.im1, cur.ip1, cur.jm1, cur.jp1,
+                      w_k, pvbo_k, w_kp1, pvbo_kp1, p.rdsigma[k], p.POTT_dif_coef[k], TURB, cur.tb, g.i_rad, ldb(p.dPOTTdt_RAD, q), cur.po, dt)
         stb(pott_out, q, pott);
         // diagnostics of the new column, level k
         // the interface pressure of this level's upper interface and its Exner value (one pow) were formed during the

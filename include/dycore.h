@@ -102,7 +102,11 @@ int dycore_field_shape(dycore_t *h, const char *name, int32_t shape[3]);
 int dycore_upload(dycore_t *h, const char *name, const dycore_real_t *host);
 int dycore_download(dycore_t *h, const char *name, dycore_real_t *host);   /* synchronises */
 /* raw device view for callers that keep data resident (torch, other kernels):
- * element (i,j,k) is dev[(k*rows + j)*pitch + i] */
+ * element (i,j,k) is dev[(k*rows + j)*pitch + i].
+ * PVTFVB and PHI of a single-GPU handle are double-buffered by the whole-substep kernel (one swap per substep): a pointer
+ * handed out here is that field's again after every WHOLE step (dycore_step_matsuno), not between the two substeps of
+ * one (dycore_substep_part); ask again there.  The derived fields (UFLX, VFLX, FLXDIV, PVTF, PHIVB) are brought up to date
+ * by this call. */
 int dycore_field_ptr(dycore_t *h, const char *name, void **dev,
                      int64_t *pitch, int64_t *rows, int64_t *levels);
 /* dst <- src, whole field: misc_gpu_functions.py:35-40 (set_equal) and the slice

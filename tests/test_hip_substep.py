@@ -19,13 +19,16 @@ sys.path.insert(0, %r)
 import numpy as np
 from climate_model_amd import Namelist, Grid, ModelFields, HipDycore
 from climate_model_amd.synthetic import initialize_fields
-nx, ny, nz, steps, moist, f32, out = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5]), int(sys.argv[6]), sys.argv[7]
+nx, ny, nz, steps, moist, f32, out, rad = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5]), int(sys.argv[6]), sys.argv[7], int(sys.argv[8])
 dtype = np.float32 if f32 else np.float64
 GR = Grid(Namelist(nz=nz, dlat_deg=180.0 / ny, dlon_deg=360.0 / nx, dt=1.0, i_moist_main_switch=moist, working_precision='float32' if f32 else 'float64'))
 assert (GR.nx, GR.ny) == (nx, ny)
-core = HipDycore(GR.nx, GR.ny, GR.nz, i_moist=moist, dtype=dtype)
+core = HipDycore(GR.nx, GR.ny, GR.nz, i_moist=moist, i_radiation=rad, dtype=dtype)
 core.set_grid(GR.GRF['HIP'])
 F = ModelFields(GR, core); initialize_fields(GR, F); F.copy_host_to_device()
+if rad:      # a heating rate field as the radiation scheme would leave it (K / s, smooth, both signs)
+    ii, jj, kk = np.meshgrid(np.arange(GR.nx + 2), np.arange(GR.ny + 2), np.arange(GR.nz), indexing='ij')
+    core.upload('dPOTTdt_RAD', (2e-5 * np.sin(0.3 * ii + 0.2 * jj) * np.cos(0.5 * kk)).astype(dtype))
 core.primary_diag()
 ptr0 = {n: core.field_ptr(n)[0] for n in ('PHI', 'PVTFVB')}
 core.step_matsuno(GR.dt, steps); core.sync()
@@ -37,26 +40,27 @@ print(json.dumps({'same_ptr': ptr0 == ptr1}))
 ''' % ROOT
 
 
-def _run(tmp_path, tag, nx, ny, nz, steps, moist, f32, fused):
+def _run(tmp_path, tag, nx, ny, nz, steps, moist, f32, fused, rad=0):
     e = dict(os.environ, DYCORE_STEP_FUSED=str(fused))
     out = str(tmp_path / (tag + '.npz'))
-    r = subprocess.run([sys.executable, '-c', WORKER, str(nx), str(ny), str(nz), str(steps), str(moist), str(f32), out],
+    r = subprocess.run([sys.executable, '-c', WORKER, str(nx), str(ny), str(nz), str(steps), str(moist), str(f32), out, str(rad)],
                        env=e, check=True, capture_output=True, text=True)
     import json
     return np.load(out), json.loads(r.stdout.strip().splitlines()[-1])
 
 
-@pytest.mark.parametrize('nx,ny,nz,steps,moist,f32', [
-    (90, 45, 8, 3, 0, 0),            # BASELINE config 0's grid
-    (130, 33, 16, 2, 0, 0),          # ragged: three tile columns, the last one 2 wide; 33 rows = 8 tile rows + 1
-    (64, 6, 8, 2, 0, 0),             # one tile column, two tile rows
-    (200, 50, 32, 2, 1, 0),          # with moisture (k_moist follows the fused launch)
-    (360, 180, 64, 2, 0, 0),         # BASELINE config 1's resolution at 64 levels
-    (130, 33, 16, 2, 0, 1),          # the float build (DYCORE_STEP_FUSED=1 asks for it; off by default there)
+@pytest.mark.parametrize('nx,ny,nz,steps,moist,f32,rad', [
+    (90, 45, 8, 3, 0, 0, 0),         # BASELINE config 0's grid
+    (130, 33, 16, 2, 0, 0, 0),       # ragged: three tile columns, the last one 2 wide; 33 rows = 8 tile rows + 1
+    (64, 6, 8, 2, 0, 0, 0),          # one tile column, two tile rows
+    (200, 50, 32, 2, 1, 0, 0),       # with moisture (k_moist follows the fused launch)
+    (200, 50, 32, 2, 1, 0, 1),       # BASELINE config 5's ingredients: moisture + a radiative heating rate (staged as one more own-cell tile)
+    (360, 180, 64, 2, 0, 0, 0),      # BASELINE config 1's resolution at 64 levels
+    (130, 33, 16, 2, 0, 1, 0),       # the float build (DYCORE_STEP_FUSED=1 asks for it; off by default there)
 ])
-def test_fused_substep_equals_separate_kernels(tmp_path, nx, ny, nz, steps, moist, f32):
-    ref, _ = _run(tmp_path, 'separate', nx, ny, nz, steps, moist, f32, 0)
-    got, info = _run(tmp_path, 'fused', nx, ny, nz, steps, moist, f32, 1)
+def test_fused_substep_equals_separate_kernels(tmp_path, nx, ny, nz, steps, moist, f32, rad):
+    ref, _ = _run(tmp_path, 'separate', nx, ny, nz, steps, moist, f32, 0, rad)
+    got, info = _run(tmp_path, 'fused', nx, ny, nz, steps, moist, f32, 1, rad)
     for n in ref.files:
         assert np.array_equal(ref[n], got[n], equal_nan=True), n
     # two substeps swap the alternate buffers twice: pointers handed out before a step are still the fields' after it

@@ -1,0 +1,54 @@
+"""The optional PHI-in-the-thread path (DYCORE_LAZY_PHI=1: the LDS-DMA momentum kernel carries PHI up the column from
+the surface geopotential, k_pott_fused stores PHIVB at every 4th interface instead of PHI, everybody else gets PHI and
+PHIVB on demand from k_derive_phi) against the default path: the same step to rounding level -- NOT bit for bit (a level
+chunk starts from a stored PHIVB, an unchunked column carries its own), which is why it is not the default -- and the
+derived PHI / PHIVB a caller downloads are the default path's stored ones."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+WORKER = r'''
+import sys
+sys.path.insert(0, %r)
+import numpy as np
+from climate_model_amd import Namelist, Grid, ModelFields, HipDycore
+from climate_model_amd.synthetic import initialize_fields
+nx, ny, nz, steps, out = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), sys.argv[5]
+GR = Grid(Namelist(nz=nz, dlat_deg=180.0 / ny, dlon_deg=360.0 / nx, dt=1.0))
+core = HipDycore(GR.nx, GR.ny, GR.nz)
+core.set_grid(GR.GRF['HIP'])
+F = ModelFields(GR, core); initialize_fields(GR, F); F.copy_host_to_device()
+core.primary_diag(); core.step_matsuno(GR.dt, steps); core.sync()
+np.savez(out, **{n: core.download(n) for n in ('COLP', 'UWIND', 'VWIND', 'POTT', 'PHI', 'PHIVB', 'PVTF', 'PVTFVB', 'POTTVB')})
+''' % ROOT
+
+
+def _run(tmp_path, tag, nx, ny, nz, steps, **env):
+    e = dict(os.environ)
+    e.update({k: str(v) for k, v in env.items()})
+    out = str(tmp_path / (tag + '.npz'))
+    subprocess.run([sys.executable, '-c', WORKER, str(nx), str(ny), str(nz), str(steps), out], env=e, check=True)
+    return np.load(out)
+
+
+@pytest.mark.parametrize('nx,ny,nz,steps', [(90, 45, 8, 3), (360, 180, 32, 2), (720, 360, 64, 2)])
+def test_phi_in_thread_equals_stored_phi_to_rounding(tmp_path, nx, ny, nz, steps):
+    # both on the two-kernel step: the whole-substep kernel reads the stored PHI by construction
+    ref = _run(tmp_path, 'stored', nx, ny, nz, steps, DYCORE_STEP_FUSED=0)
+    got = _run(tmp_path, 'local', nx, ny, nz, steps, DYCORE_STEP_FUSED=0, DYCORE_LAZY_PHI=1)
+    for n in ref.files:
+        a, b = ref[n], got[n]
+        m = np.isfinite(a)
+        assert np.array_equal(m, np.isfinite(b)), n
+        scale = np.max(np.abs(a[m]))
+        err = np.max(np.abs(a[m] - b[m])) / scale
+        # the thread's PVTF differs from the stored one by the rounding of p[k+1] - p[k] (4e-15), PHI by cp POTT times that
+        # (1e-9 m2/s2), and the pressure-gradient term takes horizontal DIFFERENCES of PHI: observed 2e-12 on the winds
+        # at 0.5 deg x 64 after two steps, less elsewhere
+        assert err <= 1e-11, (n, err)

@@ -161,7 +161,8 @@ struct dycore {
 #else
     bool step_fused = true;
 #endif
-    real *pvb_alt = nullptr, *phi_alt = nullptr;       // the buffers that launch writes the new PVTFVB / PHI into (swapped in afterwards)
+    real *pvb_alt = nullptr, *phi_alt = nullptr;
+    long long *trace_buf = nullptr;                    // (-DDYC_TRACE experiment builds)       // the buffers that launch writes the new PVTFVB / PHI into (swapped in afterwards)
     int mom_tj = 4;                 // tile rows of the LDS-DMA momentum kernel (8: one workgroup per CU; 4: two, each with its own barrier)
     int cell_lin = -1;              // DYCORE_CELL_LINEAR: column-kernel launch, bit 0 = cell runs, bit 1 = XCD-aware order (default 3 or 2)
     int mom_ks = 0;                 // DYCORE_MOM_KS: force the level chunks per momentum tile (1 .. 16)
@@ -595,7 +596,7 @@ int do_momentum_fused(dycore *h, const Ptrs &p, const real *u_old, const real *v
         const bool cur = (u_old == p.UWIND);
         const bool fw = flux_from_winds(h) && (h->fw_mask & 2);
         // ring depth: two levels in flight for the production (dry / moist, fluxes from the winds) instances
-#define MOM_LAUNCH_P(CUR_, TJ_, FW_, TB_, DP_, PL_) hipLaunchKernelGGL((k_momentum_dma<CUR_, TJ_, FW_, TB_, DP_, PL_>), gr2, blk, dma_lds_bytes(TJ_, FW_, CUR_, DP_, PL_), h->stream, h->g, p, gbx, plan, jv_lo, u_old, v_old, u_out, v_out, dt, TempArgs{nullptr, nullptr, nullptr, nullptr})
+#define MOM_LAUNCH_P(CUR_, TJ_, FW_, TB_, DP_, PL_) hipLaunchKernelGGL((k_momentum_dma<CUR_, TJ_, FW_, TB_, DP_, PL_>), gr2, blk, dma_lds_bytes(TJ_, FW_, CUR_, DP_, PL_), h->stream, h->g, p, gbx, plan, jv_lo, u_old, v_old, u_out, v_out, dt, TempArgs{nullptr, nullptr, nullptr, nullptr, nullptr})
 #define MOM_LAUNCH_T(CUR_, TJ_, FW_, TB_, DP_) MOM_LAUNCH_P(CUR_, TJ_, FW_, TB_, DP_, false)
 #define MOM_LAUNCH(CUR_, FW_, TB_, DP_) MOM_LAUNCH_T(CUR_, FTJ, FW_, TB_, DP_)
         const bool pl = phi_on_demand(h);
@@ -628,7 +629,14 @@ int do_substep_fused(dycore *h, const Ptrs &p, const real *u_old, const real *v_
     MomPlan plan = {{0, gby, gby, 0}, 1, 8 * ((gbx * gby + 7) / 8), {0, 0, 0, 0}, 1, h->mom_patch};
     const dim3 gr(plan.nblk_a), blk(FTI, 2 * tj);
     const bool cur = (u_old == p.UWIND);
-    const TempArgs ta = {pott_old, pott_out, h->pvb_alt, h->phi_alt};
+#ifdef DYC_TRACE
+    static long long *trace_buf = nullptr;
+    if (!trace_buf && hipMalloc((void **)&trace_buf, 8 * 256 * 4 * sizeof(long long)) == hipSuccess) (void)hipMemset(trace_buf, 0, 8 * 256 * 4 * sizeof(long long));
+    const TempArgs ta = {pott_old, pott_out, h->pvb_alt, h->phi_alt, trace_buf};
+    h->trace_buf = trace_buf;
+#else
+    const TempArgs ta = {pott_old, pott_out, h->pvb_alt, h->phi_alt, nullptr};
+#endif
     const int jv_lo = 2;        // pole_s
     if (cur) hipLaunchKernelGGL((k_momentum_dma<true, tj, true, false, 2, false, true>), gr, blk, dma_lds_bytes(tj, true, true, 2, false, true), h->stream,
                                 h->g, p, gbx, plan, jv_lo, u_old, v_old, u_out, v_out, dt, ta);
@@ -1081,6 +1089,15 @@ int dycore_use_stream(dycore_t *h, void *stream)
 void *dycore_get_stream(dycore_t *h) { return h ? (void *)h->home : nullptr; }
 int dycore_overlap_parts(dycore_t *h) { return h && fused_path(h) && flux_from_winds(h) ? 1 : 0; }
 int dycore_flux_from_winds(dycore_t *h) { return h && fused_path(h) && flux_from_winds(h) ? 1 : 0; }
+#ifdef DYC_TRACE
+extern "C" int dycore_debug_trace(dycore_t *h, long long *host)      // 8 waves x 256 levels x 4 points
+{
+    if (!h || !h->trace_buf) return fail(DYCORE_ESTATE, "no trace");
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    HIP_TRY(hipMemcpy(host, h->trace_buf, 8 * 256 * 4 * sizeof(long long), hipMemcpyDeviceToHost));
+    return 0;
+}
+#endif
 int dycore_sync(dycore_t *h)
 {
     if (!h) return fail(DYCORE_EINVAL, "null handle");

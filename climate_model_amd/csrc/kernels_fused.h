@@ -498,7 +498,15 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 // alternate buffers (the momentum wavefronts of neighbouring tiles still read the old ones), which the library swaps in
 // after the launch.  Whole columns only (the diagnostics integrate from the surface): no level chunks, so a latitude
 // band, whose few tiles need them to fill the chip, keeps the two separate kernels.
-struct TempArgs { const real *pott_old; real *pott_out, *pvb_out, *phi_out; };
+struct TempArgs { const real *pott_old; real *pott_out, *pvb_out, *phi_out; long long *trace; };
+// -DDYC_TRACE (experiment builds only): the wavefronts of ONE workgroup of the whole-substep kernel write their cycle counter at
+// four points of every level: [wave][level][point], point 0 = top of the iteration, 1 = stores and DMA issued, 2 = arithmetic
+// done, 3 = own DMA landed / flux entries formed (the barrier follows)
+#ifdef DYC_TRACE
+#define TRACE_PT(k_, pt_) do { if (ta.trace && blockIdx.x == DYC_TRACE && lane == 0) ta.trace[((size_t)wave * 256 + (k_)) * 4 + (pt_)] = (long long)__builtin_readcyclecounter(); } while (0)
+#else
+#define TRACE_PT(k_, pt_) do { } while (0)
+#endif
 template <bool OLD_IS_CUR, int TJ, bool FROM_WINDS, bool TURB = false, int DEPTH = 1, bool PHI_LOCAL = false, bool WITH_TEMP = false>
 __global__ __launch_bounds__(FTI *TJ *(WITH_TEMP ? 2 : 1), ((TJ <= 4 && !WITH_TEMP) ? 2 : 1)) void k_momentum_dma(Geo g, Ptrs p, int gbx, MomPlan plan, int jv_lo,
                                                       const real *u_old, const real *v_old,
@@ -710,6 +718,7 @@ __global__ __launch_bounds__(FTI *TJ *(WITH_TEMP ? 2 : 1), ((TJ <= 4 && !WITH_TE
         for (int k = nz - 1; k >= 0; k--) {
             int slot1 = slot + 1;
             if (slot1 == NS) slot1 = 0;
+            TRACE_PT(k, 0);
             // ---- the outputs of level k+1 ----
             if (active && k + 1 < nz) {
                 const size_t q1 = c + (size_t)(k + 1) * pl;
@@ -723,6 +732,7 @@ __global__ __launch_bounds__(FTI *TJ *(WITH_TEMP ? 2 : 1), ((TJ <= 4 && !WITH_TE
             }
             asm volatile("" ::: "memory");      // the stores above stay above the DMA below
             if (k - 2 >= 0 && DYC_MOM_MODE != 2) issue(k - 2, (slot + 2) % NS);
+            TRACE_PT(k, 1);
             const real *db = dsm + slot * DSLOT;
             const real *fb = dsm + NS * DSLOT + (k & 1) * FSLOT;
             if (active && DYC_MOM_MODE != 1 && DYC_WT_SKIP != 1) {
@@ -752,7 +762,9 @@ __global__ __launch_bounds__(FTI *TJ *(WITH_TEMP ? 2 : 1), ((TJ <= 4 && !WITH_TE
                 pottn_kp1 = pott; pvtf_kp1 = dl.pvtf;
                 w_kp1 = w_k; pvbo_kp1 = pvbo_k;
             }
+            TRACE_PT(k, 2);
             if (k - 1 >= 0 && DYC_MOM_MODE != 2) wait_vmcnt(k - 2 >= 0 ? n_issue : 0);      // level k-1 has landed
+            TRACE_PT(k, 3);
             lds_barrier();
             slot = slot1;
         }
@@ -903,6 +915,7 @@ __global__ __launch_bounds__(FTI *TJ *(WITH_TEMP ? 2 : 1), ((TJ <= 4 && !WITH_TE
         // (below), so that every older vector-memory operation of the wave precedes it and `vmcnt(n_issue)` at the
         // end of the iteration means exactly "level k-1 has landed"
         if (DEPTH == 1 && k - 1 >= k0 && DYC_MOM_MODE != 2) issue(k - 1, slot1);
+        if (WITH_TEMP) TRACE_PT(k, 0);
         const real tbu = tbu_nx, tbv = tbv_nx;
         if (TURB && k - 1 >= k0) { tbu_nx = p.TURB_U[c + (size_t)(k - 1) * g.plane]; tbv_nx = v_on ? p.TURB_V[c + (size_t)(k - 1) * g.plane] : 0.0; }
         const real *db = dsm + slot * DSLOT;
@@ -945,6 +958,7 @@ __global__ __launch_bounds__(FTI *TJ *(WITH_TEMP ? 2 : 1), ((TJ <= 4 && !WITH_TE
             asm volatile("" ::: "memory");      // the stores above stay above the DMA below
             if (k - AHEAD >= k0 && DYC_MOM_MODE != 2) issue(k - AHEAD, (slot + AHEAD) % NS);
         }
+        if (WITH_TEMP) TRACE_PT(k, 1);
         if (DYC_MOM_MODE != 1 && active && !(WITH_TEMP && DYC_WT_SKIP == 2)) {
             real uf[3][4], vf[4][3], uw[3][3], vw[3][3];
 #pragma unroll
@@ -1082,11 +1096,13 @@ __global__ __launch_bounds__(FTI *TJ *(WITH_TEMP ? 2 : 1), ((TJ <= 4 && !WITH_TE
             su_kp1 = su_k; sv_kp1 = sv_k;
             pvb_kp1 = pvb_k; pvb_im1_kp1 = pvb_im1_k; pvb_jm1_kp1 = pvb_jm1_k;
         }
+        if (WITH_TEMP) TRACE_PT(k, 2);
         // this wave's part of level k-1 has landed (the deeper prefetch stays in flight); form its flux entries
         if (k - 1 >= k0 && DYC_MOM_MODE != 2) {
             wait_vmcnt((DEPTH == 2 && k - AHEAD >= k0) ? n_issue : 0);        // level k - AHEAD + 1 has landed
             flux_own(slot1, (k - 1) & 1);
         }
+        if (WITH_TEMP) TRACE_PT(k, 3);
         lds_barrier();         // level k-1 is in LDS for every wave; slot `slot` is free again
         slot = slot1;
     }

@@ -687,8 +687,8 @@ __global__ __launch_bounds__(FTI *TJ *(WITH_TEMP ? 2 : 1), ((TJ <= 4 && !WITH_TE
     // =====================================================================================================
     // temperature wavefronts (WITH_TEMP): k_pott_fused's bottom-up sweep of one column on the tiles the momentum
     // wavefronts stage -- same helper functions, same bits.  They move the own-cell tiles and keep step with the
-    // momentum wavefronts' barriers; the four outputs of a level are stored at the start of the next iteration,
-    // in front of that iteration's DMA, like the momentum wavefronts' (counted vmcnt, above).
+    // momentum wavefronts' barriers; the outputs of a level and the DMA of their own tiles go out at the END of the level
+    // (below), away from the momentum wavefronts' burst at the top of it.
     if (WITH_TEMP && role_t) {
         const size_t c = at2(g, active ? i : 1, active ? j : 1);
         const real cnew = p.COLP_NEW[c];
@@ -703,7 +703,7 @@ __global__ __launch_bounds__(FTI *TJ *(WITH_TEMP ? 2 : 1), ((TJ <= 4 && !WITH_TE
         real pottn_kp1 = 0.0, pvtf_kp1 = 0.0, pottvb_first = 0.0;
         real p_up = interface_pressure(g.pair_top, c_sig[nz - 1], cnew), pvb_up = exner_vb(p_up);
         if (active) ta.pvb_out[c + (size_t)nz * pl] = pvb_kp1;
-        real o_pott = 0.0, o_pvb = 0.0, o_phi = 0.0, o_vb = 0.0, o_sfc = 0.0;       // outputs of level k+1, stored one iteration late
+        real o_pott = 0.0, o_pvb = 0.0, o_phi = 0.0, o_vb = 0.0, o_sfc = 0.0;       // outputs of the level, stored at its end
         {   // every value loaded above is complete before the level loop starts (see the momentum wavefronts)
             asm volatile("" : "+v"(colp), "+v"(cold), "+v"(c_im1), "+v"(c_ip1), "+v"(c_jm1), "+v"(c_jp1), "+v"(hr_area), "+v"(r_cnew), "+v"(phivb_kp1), "+v"(w_kp1), "+v"(pvbo_kp1), "+v"(pvb_up));
         }
@@ -719,19 +719,6 @@ __global__ __launch_bounds__(FTI *TJ *(WITH_TEMP ? 2 : 1), ((TJ <= 4 && !WITH_TE
             int slot1 = slot + 1;
             if (slot1 == NS) slot1 = 0;
             TRACE_PT(k, 0);
-            // ---- the outputs of level k+1 ----
-            if (active && k + 1 < nz) {
-                const size_t q1 = c + (size_t)(k + 1) * pl;
-                __builtin_nontemporal_store(o_pott, ta.pott_out + q1);
-                __builtin_nontemporal_store(o_pvb, ta.pvb_out + q1);
-                __builtin_nontemporal_store(o_phi, ta.phi_out + q1);
-                if (k + 1 < nz - 1) {
-                    __builtin_nontemporal_store(o_vb, p.POTTVB + q1 + pl);
-                    if (k + 1 == nz - 2 && nz > 2) __builtin_nontemporal_store(o_sfc, p.POTTVB + c + (size_t)nz * pl);   // surface extrapolation
-                }
-            }
-            asm volatile("" ::: "memory");      // the stores above stay above the DMA below
-            if (k - 2 >= 0 && DYC_MOM_MODE != 2) issue(k - 2, (slot + 2) % NS);
             TRACE_PT(k, 1);
             const real *db = dsm + slot * DSLOT;
             const real *fb = dsm + NS * DSLOT + (k & 1) * FSLOT;
@@ -763,20 +750,30 @@ __global__ __launch_bounds__(FTI *TJ *(WITH_TEMP ? 2 : 1), ((TJ <= 4 && !WITH_TE
                 w_kp1 = w_k; pvbo_kp1 = pvbo_k;
             }
             TRACE_PT(k, 2);
-            if (k - 1 >= 0 && DYC_MOM_MODE != 2) wait_vmcnt(k - 2 >= 0 ? n_issue : 0);      // level k-1 has landed
+            // Everything this wavefront sends to memory goes out HERE, at the end of the level: the momentum wavefronts' burst
+            // of DMA and stores at the top of a level fills the queues, and a vector-memory instruction that finds them full
+            // blocks its wavefront (timeline in profiles/r02_notes.md: 750 ticks per level with the stores and the DMA at the
+            // top, 80 now).  Its own-cell tiles of level k-1 went out one level ago, behind that level's stores: vmcnt(0).
+            if (k - 1 >= 0 && DYC_MOM_MODE != 2) wait_vmcnt(0);
+            // ---- the outputs of level k: a whole level to retire before the next wait ----
+            asm volatile("" ::: "memory");
+            if (active) {
+                const size_t q0 = c + (size_t)k * pl;
+                __builtin_nontemporal_store(o_pott, ta.pott_out + q0);
+                __builtin_nontemporal_store(o_pvb, ta.pvb_out + q0);
+                __builtin_nontemporal_store(o_phi, ta.phi_out + q0);
+                if (k < nz - 1) {
+                    __builtin_nontemporal_store(o_vb, p.POTTVB + q0 + pl);
+                    if (k == nz - 2 && nz > 2) __builtin_nontemporal_store(o_sfc, p.POTTVB + c + (size_t)nz * pl);   // surface extrapolation
+                }
+            }
+            asm volatile("" ::: "memory");
+            if (k - 2 >= 0 && DYC_MOM_MODE != 2) issue(k - 2, (slot + 2) % NS);        // its own-cell tiles of level k-2
             TRACE_PT(k, 3);
             lds_barrier();
             slot = slot1;
         }
-        if (active) {       // level 0 and the model top
-            __builtin_nontemporal_store(o_pott, ta.pott_out + c);
-            __builtin_nontemporal_store(o_pvb, ta.pvb_out + c);
-            __builtin_nontemporal_store(o_phi, ta.phi_out + c);
-            if (nz >= 2) {
-                __builtin_nontemporal_store(o_vb, p.POTTVB + c + pl);
-                __builtin_nontemporal_store(pottn_kp1 - (pottvb_first - pottn_kp1), p.POTTVB + c);
-            }
-        }
+        if (active && nz >= 2) __builtin_nontemporal_store(pottn_kp1 - (pottvb_first - pottn_kp1), p.POTTVB + c);      // the model top
         return;
     }
     // =====================================================================================================

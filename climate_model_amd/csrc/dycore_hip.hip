@@ -631,7 +631,7 @@ int do_substep_fused(dycore *h, const Ptrs &p, const real *u_old, const real *v_
     const bool cur = (u_old == p.UWIND);
 #ifdef DYC_TRACE
     static long long *trace_buf = nullptr;
-    if (!trace_buf && hipMalloc((void **)&trace_buf, 8 * 256 * 4 * sizeof(long long)) == hipSuccess) (void)hipMemset(trace_buf, 0, 8 * 256 * 4 * sizeof(long long));
+    if (!trace_buf && hipMalloc((void **)&trace_buf, 8 * 256 * 8 * sizeof(long long)) == hipSuccess) (void)hipMemset(trace_buf, 0, 8 * 256 * 8 * sizeof(long long));
     const TempArgs ta = {pott_old, pott_out, h->pvb_alt, h->phi_alt, trace_buf};
     h->trace_buf = trace_buf;
 #else
@@ -1090,11 +1090,11 @@ void *dycore_get_stream(dycore_t *h) { return h ? (void *)h->home : nullptr; }
 int dycore_overlap_parts(dycore_t *h) { return h && fused_path(h) && flux_from_winds(h) ? 1 : 0; }
 int dycore_flux_from_winds(dycore_t *h) { return h && fused_path(h) && flux_from_winds(h) ? 1 : 0; }
 #ifdef DYC_TRACE
-extern "C" int dycore_debug_trace(dycore_t *h, long long *host)      // 8 waves x 256 levels x 4 points
+extern "C" int dycore_debug_trace(dycore_t *h, long long *host)      // 8 waves x 256 levels x 8 points
 {
     if (!h || !h->trace_buf) return fail(DYCORE_ESTATE, "no trace");
     HIP_TRY(hipStreamSynchronize(h->stream));
-    HIP_TRY(hipMemcpy(host, h->trace_buf, 8 * 256 * 4 * sizeof(long long), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(host, h->trace_buf, 8 * 256 * 8 * sizeof(long long), hipMemcpyDeviceToHost));
     return 0;
 }
 #endif

@@ -503,7 +503,7 @@ struct TempArgs { const real *pott_old; real *pott_out, *pvb_out, *phi_out; long
 // four points of every level: [wave][level][point], point 0 = top of the iteration, 1 = stores and DMA issued, 2 = arithmetic
 // done, 3 = own DMA landed / flux entries formed (the barrier follows)
 #ifdef DYC_TRACE
-#define TRACE_PT(k_, pt_) do { if (ta.trace && blockIdx.x == DYC_TRACE && lane == 0) ta.trace[((size_t)wave * 256 + (k_)) * 4 + (pt_)] = (long long)__builtin_readcyclecounter(); } while (0)
+#define TRACE_PT(k_, pt_) do { if (ta.trace && blockIdx.x == DYC_TRACE && lane == 0) ta.trace[((size_t)wave * 256 + (k_)) * 8 + (pt_)] = (long long)__builtin_readcyclecounter(); } while (0)
 #else
 #define TRACE_PT(k_, pt_) do { } while (0)
 #endif
@@ -755,6 +755,7 @@ __global__ __launch_bounds__(FTI *TJ *(WITH_TEMP ? 2 : 1), ((TJ <= 4 && !WITH_TE
             // blocks its wavefront (timeline in profiles/r02_notes.md: 750 ticks per level with the stores and the DMA at the
             // top, 80 now).  Its own-cell tiles of level k-1 went out one level ago, behind that level's stores: vmcnt(0).
             if (k - 1 >= 0 && DYC_MOM_MODE != 2) wait_vmcnt(0);
+            TRACE_PT(k, 5);
             // ---- the outputs of level k: a whole level to retire before the next wait ----
             asm volatile("" ::: "memory");
             if (active) {
@@ -951,6 +952,7 @@ __global__ __launch_bounds__(FTI *TJ *(WITH_TEMP ? 2 : 1), ((TJ <= 4 && !WITH_TE
                 wu_b = wu_t; wv_b = wv_t;
             }
         }
+        if (WITH_TEMP) TRACE_PT(k, 4);
         if (DEPTH == 2) {
             asm volatile("" ::: "memory");      // the stores above stay above the DMA below
             if (k - AHEAD >= k0 && DYC_MOM_MODE != 2) issue(k - AHEAD, (slot + AHEAD) % NS);
@@ -1097,6 +1099,7 @@ __global__ __launch_bounds__(FTI *TJ *(WITH_TEMP ? 2 : 1), ((TJ <= 4 && !WITH_TE
         // this wave's part of level k-1 has landed (the deeper prefetch stays in flight); form its flux entries
         if (k - 1 >= k0 && DYC_MOM_MODE != 2) {
             wait_vmcnt((DEPTH == 2 && k - AHEAD >= k0) ? n_issue : 0);        // level k - AHEAD + 1 has landed
+            if (WITH_TEMP) TRACE_PT(k, 5);
             flux_own(slot1, (k - 1) & 1);
         }
         if (WITH_TEMP) TRACE_PT(k, 3);

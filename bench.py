@@ -69,6 +69,16 @@ def self_launch(args):
     env = dict(os.environ)
     env.setdefault('OMP_NUM_THREADS', '1')
     proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    if proc.returncode != 0 and env.get('DYCORE_BANDS_NATIVE', '1') != '0' and env.get('DYCORE_BANDS_BACKEND', 'nccl') == 'nccl' \
+            and not any(l.startswith('{') for l in proc.stdout.splitlines()):
+        # the in-library RCCL transport could not be brought up (its watchdog exits 86; a rank that dies takes the job
+        # down): ONE more attempt, in a fresh set of child processes, on the torch.distributed transport
+        sys.stderr.write('bench.py: the ranks exited with code %d; retrying once with DYCORE_BANDS_NATIVE=0\n' % proc.returncode)
+        with socket.socket() as so:
+            so.bind(('127.0.0.1', 0))
+            cmd[cmd.index('--master-port') + 1] = str(so.getsockname()[1])
+        env['DYCORE_BANDS_NATIVE'] = '0'
+        proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
     sys.stdout.write(proc.stdout)
     sys.stdout.flush()
     return proc.returncode
@@ -331,7 +341,10 @@ def main():
                                'dt=%.4g s' % (args.dlat, GR.nx, GR.ny, GR.nz, GR.dt),
                    'cells': cells, 'parallelism': 'latitude bands x%d' % world if world > 1 else 'single GPU',
                    'exchange': (('overlapped, 2 per substep' if bands.overlap else 'plain, 2 per substep') +
-                                (', RCCL send/recv issued by the library' if getattr(bands, 'native', None) is not None else ', torch.distributed P2P')) if bands is not None else None},
+                                (', RCCL send/recv issued by the library' if getattr(bands, 'native', None) is not None else
+                                 ', torch.distributed P2P (%s)' % backend) +
+                                ((' -- in-library transport refused: %s' % bands.native_error) if getattr(bands, 'native_error', None) else ''))
+                               if bands is not None else None},
         'roofline': roof,
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.moist and not args.radiation and not args.f32:

@@ -273,6 +273,131 @@ def _overlapped_step(cores, streams, deliver, dt, nsteps, with_rho):
     streams.wait('B2')
 
 
+def _all_agree(dist, group, device, ok):
+    """True when `ok` holds on every rank of the group (one all_reduce(MIN) on the group's own backend)."""
+    import torch
+    t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=device if dist.get_backend(group) == 'nccl' else 'cpu')
+    dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
+    return bool(int(t.item()))
+
+
+class _Watchdog:
+    """Bounds a call that may block for ever inside a communication library (ncclCommInitRank and the first
+    send / recv of a connection have no timeout of their own): if the block is still running after `seconds`, the
+    process prints why and exits with code 86 -- a failed run the launcher sees, not a hung one.  Nothing is
+    re-executed: a fresh attempt is a fresh child of whoever launched this process (bench.py's own launcher retries
+    once with DYCORE_BANDS_NATIVE=0)."""
+
+    def __init__(self, seconds, what):
+        import threading
+        self.what, self.seconds = what, seconds
+        self.timer = threading.Timer(seconds, self._fire)
+        self.timer.daemon = True
+
+    def _fire(self):
+        import os
+        import sys
+        sys.stderr.write('climate_model_amd.bands: %s did not return within %g s; giving up (exit 86). '
+                         'DYCORE_BANDS_NATIVE=0 selects the torch.distributed transport.\n' % (self.what, self.seconds))
+        sys.stderr.flush()
+        os._exit(86)
+
+    def __enter__(self):
+        self.timer.start()
+        return self
+
+    def __exit__(self, *exc):
+        self.timer.cancel()
+        return False
+
+
+def _probe_native(unique_id, rank, nranks, south, north, device_index, dtype, timeout):
+    """First contact of the in-library RCCL transport between THESE peers, in a child process: a small band per rank,
+    communicator, connect, two steps (python -m climate_model_amd.bands_probe).  A child that fails, or is still
+    running after `timeout` seconds and is killed, costs this process nothing: it reports False and every rank then
+    agrees on the torch.distributed transport."""
+    import os
+    import subprocess
+    import sys
+    cmd = [sys.executable, '-m', 'climate_model_amd.bands_probe', bytes(unique_id).hex(), str(rank), str(nranks),
+           str(-1 if south is None else south), str(-1 if north is None else north), str(device_index), str(dtype)]
+    env = dict(os.environ)
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT', 'TORCHELASTIC_RUN_ID'):
+        env.pop(k, None)         # the child is not a rank of this job's process group
+    env['PYTHONPATH'] = os.path.dirname(os.path.dirname(os.path.abspath(__file__))) + os.pathsep + env.get('PYTHONPATH', '')
+    try:
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout)
+    except subprocess.TimeoutExpired:
+        return False, 'probe still running after %g s (killed)' % timeout
+    except OSError as e:
+        return False, 'probe could not be started: %r' % (e,)
+    if r.returncode == 0 and 'BANDS_PROBE_OK' in r.stdout:
+        return True, None
+    return False, 'probe failed (exit %d): %s' % (r.returncode, (r.stderr or r.stdout)[-400:].strip())
+
+
+def _negotiate_native(core, layout, rank, device, group):
+    """Bring the in-library RCCL transport up on every rank, or on none.  Each step that can fail on one rank alone is
+    followed by ONE all_reduce(MIN) of a success flag on the process group that already exists, so that the ranks
+    always take the same branch:
+      1. librccl resolves and hands out an id (on every rank: the same dlopen the communicator needs);
+      2. the group's first rank broadcasts its id;
+      3. probe (DYCORE_BANDS_PROBE=0 to skip): a child process per rank runs the whole first contact -- communicator,
+         peer connections, two band steps -- between the same devices, bounded by a timeout;
+      4. the real communicator + connect, under a watchdog that turns a hang into exit code 86.
+    Returns (NativeBands or None, reason it is None)."""
+    import os
+    import sys
+    import torch.distributed as dist
+    from .hip_backend import NativeBands, bands_unique_id, DycoreError
+    dtype = getattr(core, 'dtype', 'float64')
+
+    first = dist.get_global_rank(group, 0) if group is not None else 0
+
+    def say(msg):
+        if rank == first:
+            print('climate_model_amd.bands: in-library RCCL transport not used (%s); all ranks use torch.distributed P2P' % msg,
+                  file=sys.stderr, flush=True)
+
+    my_id, err = None, None
+    try:
+        my_id = bands_unique_id(dtype)
+    except DycoreError as e:
+        err = str(e)
+    if not _all_agree(dist, group, device, my_id is not None):
+        say(err or 'librccl unavailable on another rank')
+        return None, err or 'librccl unavailable on another rank'
+    src = first
+    ids = [my_id]
+    dist.broadcast_object_list(ids, src=src, group=group)
+    south, north = layout.south(rank), layout.north(rank)
+    timeout = float(os.environ.get('DYCORE_BANDS_TIMEOUT', '240'))
+    if os.environ.get('DYCORE_BANDS_PROBE', '1') != '0':
+        # the probe needs an id of its own (a communicator consumes one): the first rank draws a second one
+        pid = [bands_unique_id(dtype) if rank == src else None]
+        dist.broadcast_object_list(pid, src=src, group=group)
+        dev_index = device.index if getattr(device, 'index', None) is not None else 0
+        ok, why = _probe_native(pid[0], rank, layout.nbands, south, north, dev_index, dtype, timeout)
+        if not _all_agree(dist, group, device, ok):
+            say(why or 'the probe failed on another rank')
+            return None, why or 'the probe failed on another rank'
+    nb, why = None, None
+    with _Watchdog(timeout, 'ncclCommInitRank / first exchange of the band transport'):
+        try:
+            nb = NativeBands.rccl(core, ids[0], rank, layout.nbands, south, north)
+            nb.connect()
+            core.sync()
+        except DycoreError as e:
+            why = str(e)
+            nb = None
+    if not _all_agree(dist, group, device, nb is not None):
+        if nb is not None:
+            nb.close()
+        say(why or 'communicator or connect failed on another rank')
+        return None, why or 'communicator or connect failed on another rank'
+    return nb, None
+
+
 class DistributedBands:
     """One process = one band.  Drives the Matsuno step in parts with neighbour exchanges
     through torch.distributed (RCCL when the process group's backend is nccl).  With
@@ -288,25 +413,16 @@ class DistributedBands:
         self.south, self.north = layout.south(rank), layout.north(rank)
         # RCCL process group + a handle on the fused step: the whole band step runs inside the library
         # (hip_backend.NativeBands: ncclSend / ncclRecv issued by the library itself on its comm stream, one call per
-        # step sequence); the torch.distributed transport below remains for gloo (tests, one-GPU rehearsals), for
-        # the turbulence-coupled step and behind DYCORE_BANDS_NATIVE=0
-        self.native = None
+        # step sequence; dry, moist and turbulence-coupled handles alike).  The torch.distributed transport below
+        # remains for gloo (tests, one-GPU rehearsals), behind DYCORE_BANDS_NATIVE=0, and as the fallback ALL ranks
+        # take together when the in-library transport cannot be brought up on any one of them (_negotiate_native).
+        self.native, self.native_error = None, None
         if native is None:
             import os
             native = os.environ.get('DYCORE_BANDS_NATIVE', '1') != '0'
         if (native and str(device) != 'cpu' and dist.get_backend(group) == 'nccl' and getattr(core, 'overlap_parts', False)
                 and getattr(core, 'flux_from_winds', False) and layout.nbands > 1):
-            from .hip_backend import NativeBands, bands_unique_id, DycoreError
-            ids = [None]
-            if rank == 0:
-                try:
-                    ids = [bands_unique_id()]
-                except DycoreError as e:        # no usable librccl: every rank falls back together
-                    import sys
-                    print('climate_model_amd.bands: in-library RCCL transport unavailable (%s); using torch.distributed' % e, file=sys.stderr)
-            dist.broadcast_object_list(ids, src=0, group=group)
-            if ids[0] is not None:
-                self.native = NativeBands.rccl(core, ids[0], rank, layout.nbands, self.south, self.north)
+            self.native, self.native_error = _negotiate_native(core, layout, rank, device, group)
         self.halo = BandHalo(core, layout.ny(rank), self.south is not None, self.north is not None)
         self.bufs = _TorchBuffers(self.halo, device)
         on_gpu = str(device) != 'cpu'

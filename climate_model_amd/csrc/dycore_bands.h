@@ -17,9 +17,23 @@
 // one process (the single-GPU rehearsal of the same schedule, and its bit-for-bit test).
 #pragma once
 #include <dlfcn.h>
+// Every RCCL entry point is resolved with dlsym, so only a handful of types are needed at compile time: the RCCL
+// development header when the ROCm install has it, otherwise the same declarations spelt out (the NCCL ABI: an opaque
+// communicator, a 128-byte id, result 0 = success, the datatype codes) -- a ROCm without rccl-dev still builds the library.
+#if __has_include(<rccl/rccl.h>)
 #include <rccl/rccl.h>
+#else
+typedef struct ncclComm *ncclComm_t;
+typedef struct { char internal[128]; } ncclUniqueId;
+typedef enum { ncclSuccess = 0 } ncclResult_t;
+typedef enum { ncclInt8 = 0, ncclChar = 0, ncclUint8 = 1, ncclInt32 = 2, ncclInt = 2, ncclUint32 = 3, ncclInt64 = 4, ncclUint64 = 5,
+               ncclFloat16 = 6, ncclHalf = 6, ncclFloat32 = 7, ncclFloat = 7, ncclFloat64 = 8, ncclDouble = 8 } ncclDataType_t;
+#endif
 
 namespace {
+
+// message elements have the working precision of the build (counts and buffers are in `real`)
+constexpr ncclDataType_t kNcclReal = sizeof(real) == 4 ? ncclFloat : ncclDouble;
 
 struct RcclApi {
     void *lib = nullptr;
@@ -73,7 +87,7 @@ struct MsgItem { real *Ptrs::*plain; real *Ptrs::*est; int row, nk; };
 
 struct Msg {
     std::vector<MsgItem> send_s, send_n, recv_s, recv_n;
-    size_t ss = 0, sn = 0, rs = 0, rn = 0;      // doubles
+    size_t ss = 0, sn = 0, rs = 0, rn = 0;      // elements (`real`)
     real *send = nullptr, *recv = nullptr;    // [south part | north part]
 };
 
@@ -195,10 +209,10 @@ int bands_transport(dycore_bands *B, int ph)
         // order inside the group: to the south, from the north, to the north, from the south -- any order is right
         // between distinct peers; it also pairs the messages of a band that is its own neighbour on both sides
         NCCL_TRY(B, B->rccl->GroupStart());
-        if (B->south >= 0) NCCL_TRY(B, B->rccl->Send(m.send, m.ss, ncclDouble, B->south, B->nccl, B->comm));
-        if (B->north >= 0) NCCL_TRY(B, B->rccl->Recv(m.recv + m.rs, m.rn, ncclDouble, B->north, B->nccl, B->comm));
-        if (B->north >= 0) NCCL_TRY(B, B->rccl->Send(m.send + m.ss, m.sn, ncclDouble, B->north, B->nccl, B->comm));
-        if (B->south >= 0) NCCL_TRY(B, B->rccl->Recv(m.recv, m.rs, ncclDouble, B->south, B->nccl, B->comm));
+        if (B->south >= 0) NCCL_TRY(B, B->rccl->Send(m.send, m.ss, kNcclReal, B->south, B->nccl, B->comm));
+        if (B->north >= 0) NCCL_TRY(B, B->rccl->Recv(m.recv + m.rs, m.rn, kNcclReal, B->north, B->nccl, B->comm));
+        if (B->north >= 0) NCCL_TRY(B, B->rccl->Send(m.send + m.ss, m.sn, kNcclReal, B->north, B->nccl, B->comm));
+        if (B->south >= 0) NCCL_TRY(B, B->rccl->Recv(m.recv, m.rs, kNcclReal, B->south, B->nccl, B->comm));
         NCCL_TRY(B, B->rccl->GroupEnd());
         return 0;
     }
@@ -260,7 +274,9 @@ int bands_finish_create(dycore_bands *B)
     // every member: the fused step with split parts and fluxes re-formed from the winds (the message plan above)
     for (BandMember &b : B->m) {
         if (!fused_path(b.h) || !flux_from_winds(b.h))
-            return fail(DYCORE_ESTATE, "the in-library band step needs the fused step (dycore_overlap_parts, dycore_flux_from_winds)");
+            return fail(DYCORE_ESTATE, "the in-library band step needs the fused step (dycore_overlap_parts, dycore_flux_from_winds): %s",
+                        !b.h->zonal ? "lat_rad / lat_is_rad / corf / corf_is vary along a row, so this handle steps on the stage kernels"
+                        : !b.h->fused ? "DYCORE_FUSED=0" : "the level count or a DYCORE_* switch selects kernels that store the mass fluxes");
         if (b.h->home != B->main) return fail(DYCORE_EINVAL, "all bands of one process must launch on the same stream");
         build_plan(b);
     }

@@ -137,6 +137,7 @@ struct dycore {
     size_t stage_elems = 0;
     int grid_set = 0;
     bool zonal = true;              // lat_rad, lat_is_rad, corf, corf_is do not vary along a row (the fused momentum kernel keeps them per wavefront)
+    int nonzonal = 0;               // ... which of the four do (bits 1, 2, 4, 8), as of their last dycore_set_grid
     bool fused = true;              // production kernels in dycore_step_matsuno (DYCORE_FUSED=0: stage kernels)
     bool lazy = true;               // fused step leaves FLXDIV / PHIVB to be derived on demand (DYCORE_LAZY=0: store them)
     bool fused_turb = true;         // DYCORE_FUSED_TURB=0: a turbulence-coupled handle steps on the stage kernels
@@ -1155,10 +1156,21 @@ int dycore_set_grid(dycore_t *h, const char *name, const real *host, int32_t n0,
         const size_t n = (size_t)n0 * n1;
         if (d.member == &Ptrs::lat_rad || d.member == &Ptrs::lat_is_rad || d.member == &Ptrs::corf || d.member == &Ptrs::corf_is) {
             // a latitude-longitude grid: these depend on the row only (main_grid.py:132-189, 229-240).  The fused
-            // momentum kernel relies on it; anything else steps on the stage kernels
-            for (int j = 1; j <= g.ny && h->zonal; j++)
-                for (int i = 2; i <= g.nx + d.stgx; i++)
-                    if (host[(size_t)i * n1 + j] != host[(size_t)1 * n1 + j]) { h->zonal = false; break; }
+            // momentum kernel relies on it (a wavefront keeps them in scalar registers); anything else steps on the
+            // stage kernels.  Every row the fused kernels read is checked -- they take corf and lat_rad at j-1 = 0 too
+            // (a pole's halo row, which the reference leaves NaN: NaN along the whole row counts as constant) --, and
+            // the verdict is taken anew from all four arrays whenever one of them is set again.
+            bool ok = true;
+            for (int j = 0; j < n1 && ok; j++) {
+                const real r0 = host[(size_t)1 * n1 + j];
+                for (int i = 2; i <= g.nx + d.stgx; i++) {
+                    const real v = host[(size_t)i * n1 + j];
+                    if (v != r0 && !(v != v && r0 != r0)) { ok = false; break; }
+                }
+            }
+            const int bit = d.member == &Ptrs::lat_rad ? 1 : d.member == &Ptrs::lat_is_rad ? 2 : d.member == &Ptrs::corf ? 4 : 8;
+            h->nonzonal = ok ? (h->nonzonal & ~bit) : (h->nonzonal | bit);
+            h->zonal = h->nonzonal == 0;
         }
         HIP_TRY(hipMemcpyAsync(h->stage, host, n * sizeof(real), hipMemcpyHostToDevice, h->stream));
         hipLaunchKernelGGL(k_to_device, dim3((n0 + 31) / 32, 1, n1), dim3(32, 8), 0, h->stream, g, h->stage, dev, n0, n1, 1);

@@ -379,9 +379,10 @@ class HipDycore:
 UNIQUE_ID_BYTES = 128       # sizeof(ncclUniqueId)
 
 
-def bands_unique_id():
-    """The 128-byte RCCL rendezvous id (rank 0 obtains it, every rank passes it to NativeBands.rccl)."""
-    lib = load_library()
+def bands_unique_id(dtype=np.float64):
+    """The 128-byte RCCL rendezvous id (rank 0 obtains it, every rank passes it to NativeBands.rccl).
+    `dtype`: the build to ask (either one resolves the same librccl of the process)."""
+    lib = load_library(dtype=dtype)
     buf = C.create_string_buffer(UNIQUE_ID_BYTES)
     rc = lib.dycore_bands_unique_id(buf, UNIQUE_ID_BYTES)
     if rc != 0:

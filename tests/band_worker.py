@@ -18,9 +18,13 @@ from test_hip_bands import _initial_state
 
 def main():
     rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
-    dist.init_process_group(os.environ.get('DYCORE_BANDS_BACKEND', 'gloo'))
+    backend = os.environ.get('DYCORE_BANDS_BACKEND', 'gloo')
     dev = 0 if os.environ.get('DYCORE_BANDS_ONE_GPU') else int(os.environ.get('LOCAL_RANK', 0))
     torch.cuda.set_device(dev)
+    if backend == 'nccl':
+        dist.init_process_group('nccl', device_id=torch.device('cuda', dev))
+    else:
+        dist.init_process_group(backend)
     stream = torch.cuda.Stream()
     torch.cuda.set_stream(stream)
     GR, state = _initial_state(4, 8, 0)
@@ -32,6 +36,8 @@ def main():
         core.upload(n, L.slice_rows(a, rank, FIELD_TABLE[n][1]))
     core.primary_diag()
     bands = DistributedBands(core, L, rank, torch.device('cuda', dev))
+    if os.environ.get('DYCORE_EXPECT_NATIVE'):      # distinct devices + nccl: the in-library RCCL transport must be the one that runs
+        assert bands.native is not None, 'in-library transport not used: %s' % bands.native_error
     bands.connect()             # as bench.py does: must leave every field untouched
     bands.step_matsuno(GR.dt, 3)
     core.sync()

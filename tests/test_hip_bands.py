@@ -108,6 +108,48 @@ def test_multi_process_gloo_bands_equal_single(tmp_path, nproc):
         np.testing.assert_array_equal(z[n], ref[n], err_msg=n)
 
 
+def _n_devices():
+    import torch
+    return torch.cuda.device_count()        # (counting devices does not initialise the GPU)
+
+
+@pytest.mark.parametrize('nproc,probe', [(2, '1'), (2, '0'), (4, '1')])
+def test_rccl_bands_between_distinct_devices(tmp_path, nproc, probe):
+    """The multi-GPU path proper, run wherever the box has the devices: one rank per GPU, process group on nccl (= RCCL),
+    DistributedBands brings up the in-library transport (probe child first, then ncclCommInitRank next to torch's own
+    communicator), three Matsuno steps through ncclSend / ncclRecv between real peers -- bitwise equal to the
+    single-domain run.  Skipped on a one-GPU box (RCCL refuses two ranks on one device); there the same schedule is
+    covered by the self-neighbour RCCL test above and the gloo runs."""
+    if _n_devices() < nproc:
+        pytest.skip('needs %d GPUs, %d visible' % (nproc, _n_devices()))
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+    out = tmp_path / 'bands.npz'
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0', DYCORE_BANDS_BACKEND='nccl', DYCORE_EXPECT_NATIVE='1',
+               DYCORE_BANDS_PROBE=probe)
+    env.pop('DYCORE_BANDS_ONE_GPU', None)
+    env.pop('DYCORE_BANDS_NATIVE', None)
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(nproc),
+           '--master-addr', '127.0.0.1', '--master-port', str(port),
+           os.path.join(ROOT, 'tests', 'band_worker.py'), str(out)]
+    r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    GR, state = _initial_state(4, 8, 0)
+    ref = _single(GR, state, 0, 3)
+    z = np.load(out)
+    for n in ('COLP', 'UWIND', 'VWIND', 'POTT'):
+        np.testing.assert_array_equal(z[n], ref[n], err_msg=n)
+
+
+def test_bands_probe_child_on_one_gpu():
+    """python -m climate_model_amd.bands_probe, the child every rank starts before it commits to the in-library
+    transport: here as a single rank that is its own neighbour on both sides (two ranks cannot share a GPU under RCCL)."""
+    from climate_model_amd.hip_backend import bands_unique_id
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0', PYTHONPATH=ROOT + os.pathsep + os.environ.get('PYTHONPATH', ''))
+    cmd = [sys.executable, '-m', 'climate_model_amd.bands_probe', bands_unique_id().hex(), '0', '1', '0', '0', '0', 'float64']
+    r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and 'BANDS_PROBE_OK' in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
+
+
 def test_bench_two_ranks_rehearsal():
     """The bare command the round driver runs, `python bench.py --gpus 2 ...` with no launcher and no
     WORLD_SIZE: bench.py starts torch.distributed.run as a child before it touches the GPU, relays the
@@ -139,12 +181,13 @@ def test_bench_self_launch_propagates_failure():
     assert r.returncode != 0
 
 
-@pytest.mark.parametrize('i_moist', [0, 1])
-def test_native_band_step_over_rccl(i_moist):
+@pytest.mark.parametrize('i_moist,prec', [(0, 'f64'), (1, 'f64'), (0, 'f32'), (1, 'f32')])
+def test_native_band_step_over_rccl(i_moist, prec):
     """dycore_bands_create_rccl / dycore_bands_step_matsuno: ncclSend / ncclRecv issued by the library on its comm
-    stream (tests/native_rccl_worker.py: a band that is its own neighbour, against the device-copy transport)."""
+    stream (tests/native_rccl_worker.py: a band that is its own neighbour, against the device-copy transport).
+    'f32': libdycore_hip_f32.so -- message counts are in elements of the build's `real`, the RCCL datatype must follow."""
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
-    r = subprocess.run([sys.executable, os.path.join(ROOT, 'tests', 'native_rccl_worker.py'), str(i_moist)], env=env, cwd=ROOT,
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'tests', 'native_rccl_worker.py'), str(i_moist), prec], env=env, cwd=ROOT,
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and 'NATIVE_RCCL_OK' in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
 

@@ -720,18 +720,72 @@ __global__ __launch_bounds__(TI *TJ) void k_euler_forward(Geo g, Ptrs p, real dt
 }
 
 // ------------------------------------------------------------------------------------
-// (p / 1e5) ** kappa of dyn_diagnostics.py:146-153.  DYC_POW_VARIANT 0: pow() as written in the
-// reference; 1: exp(kappa * (log(p) - log(1e5))), the same value to ~2 ulp at less than half
-// the instruction count (k_pott_fused is bound by fp64 instruction issue, not by HBM).
-#ifndef DYC_POW_VARIANT
-#define DYC_POW_VARIANT 0
-#endif
+// (p / 1e5) ** kappa of dyn_diagnostics.py:146-153: the Exner function at an interface.
+// The generic pow() of the device library costs 226 vector instructions per call -- 70 % of the temperature sweep's
+// arithmetic per level, the largest single item of the whole substep (profiles/r03_notes.md).  Its argument here lives in
+// a narrow domain (0.05 < p / 1e5 < 1.3, kappa a constant), so it is evaluated directly, ~85 instructions, every rounding
+// written out (fma / contract off: all kernels that call it produce the same bits, which the band decomposition relies on):
+//   x = p * 1e-5 as a double-double (no division);  x = 2^e m, m in [sqrt(1/2), sqrt(2));
+//   log m = 2 atanh(s), s = (m - 1) / (m + 1) as a double-double quotient, odd series up to s^21 (|s| <= 0.172);
+//   y = kappa (e ln 2 + log m) as a double-double (relative error of the logarithm < 2^-58);
+//   exp(y) = 2^n exp(r), r = y - n ln 2 exact in its high part, Taylor polynomial of degree 13, the last sum compensated.
+// Error <= 0.8 ulp against the exact power (mean 0.26; glibc's pow: 0.51, ocml's: ~1; exp(kappa log p): 3.3) on 4e6
+// random arguments of the domain (prototype against quad precision; the device instruction sequence is the same).
+// -DDYC_EXNER_OCML (experiment builds): the library's pow, as in rounds 1-2.
+__device__ __forceinline__ double exner_pow(double p)
+{
+#pragma clang fp contract(off)
+    constexpr double C_HI = 0x1.4f8b588e368f1p-17, C_LO = -0x1.ee78183f91e64p-71;        // 1e-5
+    constexpr double LN2_HI = 0x1.62e42fefa38p-1, LN2_LO = 0x1.ef35793c7673p-45;           // ln 2, the high part with 11 trailing zero bits
+    constexpr double LOG2E = 0x1.71547652b82fep+0;
+    constexpr double KAP = (double)CON_KAPPA;               // (the float build's kappa is the float one, as in the reference's float32 mode)
+    const double xh = p * C_HI;
+    const double xl = fma(p, C_LO, fma(p, C_HI, -xh));
+    double m = __builtin_amdgcn_frexp_mant(xh);             // [0.5, 1)
+    int e = __builtin_amdgcn_frexp_exp(xh);
+    const bool low = m < 0.70710678118654752;
+    m = m * (low ? 2.0 : 1.0);
+    e = low ? e - 1 : e;
+    const double corr = xl * __builtin_amdgcn_rcp(xh);      // log(xh + xl) - log(xh)
+    const double f = m - 1.0, g = m + 1.0, gl = m - (g - 1.0);        // m - 1 and g - 1 are exact; gl = rounding error of m + 1
+    double r = __builtin_amdgcn_rcp(g);
+    r = fma(r, fma(-g, r, 1.0), r);
+    r = fma(r, fma(-g, r, 1.0), r);
+    const double s = f * r;
+    const double sl = fma(-s, gl, fma(-s, g, f)) * r;       // s + sl = (m - 1) / (m + 1)
+    const double s2 = s * s;
+    double P = 1.0 / 21.0;
+    P = fma(P, s2, 1.0 / 19.0); P = fma(P, s2, 1.0 / 17.0); P = fma(P, s2, 1.0 / 15.0); P = fma(P, s2, 1.0 / 13.0);
+    P = fma(P, s2, 1.0 / 11.0); P = fma(P, s2, 1.0 / 9.0); P = fma(P, s2, 1.0 / 7.0); P = fma(P, s2, 1.0 / 5.0);
+    P = fma(P, s2, 1.0 / 3.0);
+    P = P * s2;
+    const double lh = 2.0 * s;
+    const double ll = fma(lh, P, 2.0 * sl) + corr;          // log m = lh + ll
+    const double E = (double)e;
+    const double A = E * LN2_HI;                            // exact
+    double th = A + lh;
+    double tl = ((A - th) + lh) + fma(E, LN2_LO, ll);       // |A| >= |lh| or A = 0
+    { const double t2 = th + tl; tl = (th - t2) + tl; th = t2; }
+    const double yh = KAP * th;
+    const double yl = fma(KAP, tl, fma(KAP, th, -yh));
+    const double n = __builtin_rint(yh * LOG2E);
+    const double rh = fma(-n, LN2_HI, yh);                  // exact
+    const double rl = fma(-n, LN2_LO, yl);
+    double q = 1.0 / 6227020800.0;
+    q = fma(q, rh, 1.0 / 479001600.0); q = fma(q, rh, 1.0 / 39916800.0); q = fma(q, rh, 1.0 / 3628800.0); q = fma(q, rh, 1.0 / 362880.0);
+    q = fma(q, rh, 1.0 / 40320.0); q = fma(q, rh, 1.0 / 5040.0); q = fma(q, rh, 1.0 / 720.0); q = fma(q, rh, 1.0 / 120.0);
+    q = fma(q, rh, 1.0 / 24.0); q = fma(q, rh, 1.0 / 6.0); q = fma(q, rh, 0.5);
+    const double t = (rh * rh) * q;
+    const double u = 1.0 + rh, ul = (1.0 - u) + rh;
+    const double res = u + fma(rl, u + t, ul + t);
+    return __builtin_amdgcn_ldexp(res, (int)n);
+}
 __device__ __forceinline__ real exner_vb(real p)
 {
-#if DYC_POW_VARIANT == 1
-    return exp(CON_KAPPA * (log(p) - 11.512925464970229));   // log(100000)
-#else
+#ifdef DYC_EXNER_OCML
     return pow(p / 100000.0, CON_KAPPA);
+#else
+    return (real)exner_pow((double)p);
 #endif
 }
 

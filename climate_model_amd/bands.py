@@ -116,8 +116,11 @@ class BandHalo:
         # the second v-row beyond its northern edge with the winds
         fw = bool(getattr(core, 'flux_from_winds', False))
         swap = {'UFLX': 'UCOL', 'VFLX': 'VCOL'} if fw else {}
+        # ... and with the scalar state the diagnostics of that state as their OWNER computed them (PVTFVB, and PHIVB / PHI /
+        # POTTVB / PVTF depending on what the handle's step stores): a band does not re-diagnose rows it receives
+        diag = [(n, None) for n in getattr(core, 'band_diag_fields', ())]
         for ph in PHASES:
-            extra = [('QV', None), ('QC', None)] if (moist and ph in ('B', 'B2', 'AB2')) else []
+            extra = ([('QV', None), ('QC', None)] if moist else []) + diag if ph in ('B', 'B2', 'AB2') else []
             north = [(swap.get(f, f), r) for f, r in SEND_NORTH[ph]]
             south = [(swap.get(f, f), r) for f, r in SEND_SOUTH[ph]]
             rs, rn = list(RECV_FROM_SOUTH[ph]), list(RECV_FROM_NORTH[ph])
@@ -218,8 +221,7 @@ def _overlapped_step(cores, streams, deliver, dt, nsteps, with_rho):
         |AB2  momentum, edge tiles                pack B1  (new winds)
               temperature (+ moisture), halos
 
-    and on the comm stream, behind each pack: transport, unpack (after AB2: primary diagnostics
-    of the received rows).  AB2 travels behind the inner momentum tiles, B1 behind the temperature
+    and on the comm stream, behind each pack: transport, unpack.  AB2 travels behind the inner momentum tiles, B1 behind the temperature
     kernel and the continuity kernel of the next substep's start.  The POTT rows written by the
     last substep of a call go out alone ('B2') before it returns.
     deliver(ph, sub) issues transport + unpack on the current stream."""
@@ -235,9 +237,6 @@ def _overlapped_step(cores, streams, deliver, dt, nsteps, with_rho):
                 c.use_stream(streams.comm.cuda_stream)
             try:
                 deliver(ph, sub)
-                if ph in ('AB2', 'B2'):     # diagnostics of the received POTT rows: the substep that wrote them
-                    for c in cores:
-                        c.substep_part(dt, 1 - sub if ph == 'AB2' else sub, 2)
             finally:
                 for c in cores:
                     c.use_stream(None)

@@ -5,10 +5,12 @@
 // each time behind a kernel that does not need the rows:
 //
 //   main:  |B1  continuity ---- momentum inner tiles - |AB2 - momentum edge tiles ---- temperature(+moisture)
-//   comm:                  AB2: pack, transport, unpack, diag rows                   B1: pack, transport, unpack
+//   comm:                  AB2: pack, transport, unpack                              B1: pack, transport, unpack
 //
 //   AB2 = 2-D column pressures at the u- / v-points, WWIND, COLP_NEW of this substep + the POTT (QV, QC) rows of the
-//         state it evaluates on;  B1 = the new winds;  B2 = the POTT (QV, QC) rows of the last substep of a call.
+//         state it evaluates on and the rows of that state's diagnostics as their owner computed them (PVTFVB and the
+//         PHIVB planes the momentum kernel's level chunks start from; dycore_band_row_fields);
+//         B1 = the new winds;  B2 = the scalar rows of the last substep of a call.
 //
 // The schedule, the message plans, the pack / unpack launches and the stream / event choreography of one step are
 // issued by ONE call (dycore_bands_step_matsuno): the host cost of a band's step is a few dozen HIP calls.
@@ -83,7 +85,7 @@ enum { PH_AB2 = 0, PH_B1 = 1, PH_B2 = 2, PH_COUNT = 3 };
 
 // one row of one field inside a message; `est` != nullptr marks a state field (UWIND, VWIND, POTT, QV, QC), which the
 // fused step keeps in its *_EST scratch buffer after the predictor
-struct MsgItem { real *Ptrs::*plain; real *Ptrs::*est; int row, nk; };
+struct MsgItem { real *Ptrs::*plain; real *Ptrs::*est; int row, nk, k0 = 0, kstep = 1; };
 
 struct Msg {
     std::vector<MsgItem> send_s, send_n, recv_s, recv_n;
@@ -128,9 +130,22 @@ void build_plan(BandMember &b)
     const int N = h->g.ny, nz = h->g.nz;
     const bool moist = h->g.i_moist;
 #define ST(n_) &Ptrs::n_, &Ptrs::n_##_EST
+    // the scalar state and, with it, the diagnostics of that state the owner computed (dycore_band_row_fields): a band
+    // does not re-diagnose the rows it receives
+    std::vector<const char *> diag;
+    band_row_fields(h, diag);
     auto scalars = [&](std::vector<MsgItem> &v, int row) {
         v.push_back({ST(POTT), row, nz});
         if (moist) { v.push_back({ST(QV), row, nz}); v.push_back({ST(QC), row, nz}); }
+        const bool planes = !h->g.i_turb && phi_on_demand(h);
+        for (const char *n : diag) {
+            const FieldDesc &d = kFields[h->field_idx.at(n)];
+            if (planes && d.member == &Ptrs::PHIVB) {       // the planes PHIVB_STRIDE, 2 PHIVB_STRIDE, ... below the surface interface
+                const int np = (nz - 1) / PHIVB_STRIDE;
+                if (np > 0) { MsgItem it{d.member, nullptr, row, np}; it.k0 = PHIVB_STRIDE; it.kstep = PHIVB_STRIDE; v.push_back(it); }
+            } else
+                v.push_back({d.member, nullptr, row, h->nk_of(d.nk)});
+        }
     };
     {   // AB2
         Msg &m = b.msg[PH_AB2];
@@ -185,7 +200,7 @@ int rows_move(dycore *h, const std::vector<MsgItem> &south, bool with_s, const s
         for (const MsgItem &it : (part == 0 ? south : north)) {
             const int e = rl.n++;
             rl.base[e] = h->p.*((src == 0 && it.est) ? it.est : it.plain);
-            rl.row[e] = it.row; rl.nk[e] = it.nk; rl.off[e] = off;
+            rl.row[e] = it.row; rl.nk[e] = it.nk; rl.k0[e] = it.k0; rl.kstep[e] = it.kstep; rl.off[e] = off;
             off += (long long)it.nk * (h->g.nx + 3);
             if (it.nk > maxk) maxk = it.nk;
             if (rl.n == ROWLIST_MAX) { int rc = flush(); if (rc) return rc; }
@@ -231,8 +246,7 @@ int bands_transport(dycore_bands *B, int ph)
     return 0;
 }
 
-// pack on the main stream, then on the comm stream: transport, unpack (+ the primary diagnostics of received POTT
-// rows); one event per phase marks "halo rows of this phase are in place"
+// on the comm stream: pack, transport, unpack; one event per phase marks "halo rows of this phase are in place"
 int bands_exchange(dycore_bands *B, int ph, int sub, real dt)
 {
     int rc = 0;
@@ -250,10 +264,8 @@ int bands_exchange(dycore_bands *B, int ph, int sub, real dt)
         for (BandMember &b : B->m) b.h->stream = b.h->home;
         return rc;
     }
-    for (BandMember &b : B->m) {
+    for (BandMember &b : B->m)
         if ((rc = rows_move(b.h, b.msg[ph].recv_s, b.has_s, b.msg[ph].recv_n, b.has_n, src, b.msg[ph].recv, 1))) break;
-        if (ph != PH_B1 && (rc = substep_part(b.h, dt, src, 2))) break;      // diagnostics of the received POTT rows
-    }
     for (BandMember &b : B->m) b.h->stream = b.h->home;
     if (rc) return rc;
     HIP_TRY(hipEventRecord(B->done[ph], B->comm));

@@ -106,12 +106,12 @@ constexpr int kNGrid = sizeof(kGrid) / sizeof(kGrid[0]);
 
 // kernels tracked by the profiler
 enum KernelId {
-    K_CONTINUITY = 0, K_PREPARE, K_UFLX, K_VFLX, K_POTT, K_EULER, K_DIAG, K_RHO, K_EXCHANGE, K_COPY, K_HALO, K_MOM_FUSED, K_POTT_FUSED, K_DIAG_ROWS, K_HALO_MULTI, K_CONT_REG, K_DERIVE, K_MOIST, K_SECONDARY, K_TURB, K_RAD, K_TURB_TEND, K_MOM_DMA, K_SUBSTEP,
+    K_CONTINUITY = 0, K_PREPARE, K_UFLX, K_VFLX, K_POTT, K_EULER, K_DIAG, K_RHO, K_EXCHANGE, K_COPY, K_HALO, K_MOM_FUSED, K_POTT_FUSED, K_TEMP_CANON, K_HALO_MULTI, K_CONT_REG, K_DERIVE, K_MOIST, K_SECONDARY, K_TURB, K_RAD, K_TURB_TEND, K_MOM_DMA, K_SUBSTEP,
     K_COUNT
 };
 const char *kKernelNames[K_COUNT] = {
     "k_continuity", "k_prepare", "k_uflx_tendency", "k_vflx_tendency", "k_pott_tendency",
-    "k_euler_forward", "k_primary_diag", "k_diag_rho", "k_exchange_bc", "copy_field", "k_rows", "k_momentum_fused", "k_pott_fused", "k_primary_diag_rows", "k_halo_multi", "k_continuity_reg", "k_derive", "k_moist", "k_diag_secondary", "k_turbulence", "k_radiation", "k_turb_tendencies", "k_momentum_dma", "k_substep_fused",
+    "k_euler_forward", "k_primary_diag", "k_diag_rho", "k_exchange_bc", "copy_field", "k_rows", "k_momentum_fused", "k_pott_fused", "k_temp_canon", "k_halo_multi", "k_continuity_reg", "k_derive", "k_moist", "k_diag_secondary", "k_turbulence", "k_radiation", "k_turb_tendencies", "k_momentum_dma", "k_substep_fused",
 };
 
 struct ProfRec { int kid; hipEvent_t a, b; };
@@ -125,9 +125,6 @@ struct dycore {
     hipStream_t stream = nullptr;   // where launches go (dycore_use_stream can redirect them)
     hipStream_t home = nullptr;     // the handle's own stream (DycoreConfig.stream or created here)
     bool own_stream = false;
-    hipStream_t side = nullptr;     // halo-row diagnostics of a band overlap the next continuity
-    hipEvent_t ev_main = nullptr, ev_side = nullptr;
-    bool side_pending = false;
     std::unordered_map<std::string, int> field_idx, grid_idx;
     std::vector<real *> allocs;
     double *rad_ws = nullptr;     // workspace of the radiation columns, [element][column] (the column solves run in double in either precision)
@@ -143,12 +140,13 @@ struct dycore {
     bool fused_turb = true;         // DYCORE_FUSED_TURB=0: a turbulence-coupled handle steps on the stage kernels
     int fw_mask = 7;                // DYCORE_FW_MASK (debug): 1 continuity stores no fluxes, 2 momentum, 4 temperature/moisture re-form them
     bool lazy_flx = true;           // ... nor UFLX / VFLX: consumers re-form them from the winds (DYCORE_LAZY_FLX=0: store them)
-    bool stale_flxdiv = false, stale_phivb = false, stale_uvflx = false, stale_pvtf = false, stale_phi = false;
-    // ... nor PHI (DYCORE_LAZY_PHI=1; off by default): the LDS-DMA momentum kernel carries it up the column from the surface
-    // geopotential and k_pott_fused stores PHIVB at every 4th interface only.  -2.3 % per step, but a level chunk then
-    // starts from a stored PHIVB while an unchunked column carries its own (1 ulp apart): results depend on the work
-    // list and on the band decomposition at rounding level, which the default does not (profiles/r02_notes.md)
-    bool lazy_phi = false;
+    bool stale_flxdiv = false, stale_phivb = false, stale_uvflx = false, stale_pvtf = false, stale_phi = false, stale_pottvb = false;
+    // ... nor PHI and POTTVB (DYCORE_LAZY_PHI=0: store them): the LDS-DMA momentum kernel carries the hydrostatic integration up
+    // the column in its threads and the temperature kernel forms the interface values of POTT it needs from POTT and PVTFVB;
+    // the temperature kernel stores PHIVB at every 4th interface for the level chunks of the momentum kernel, evaluated with
+    // the same canonical forms (kernels_stage.h), so that results do not depend on the work list or the band decomposition
+    bool lazy_phi = true;
+    bool planes_valid = false;      // the PHIVB planes at every PHIVB_STRIDE-th interface hold the canonical integration of the current state (k_temp_canon keeps them)
     bool lazy_pvtf = true;          // ... nor PVTF (DYCORE_LAZY_PVTF=0: store it); only where the momentum kernel forms its own (flux_from_winds, no i_turb)
     const real *flx_u = nullptr, *flx_v = nullptr;   // winds the last fused continuity evaluated on
     bool winds_bc_dirty = true;     // UWIND / VWIND came from the host: their lateral BC images (column nx+2!) may be unset
@@ -162,7 +160,7 @@ struct dycore {
 #else
     bool step_fused = true;
 #endif
-    real *pvb_alt = nullptr, *phi_alt = nullptr;
+    real *pvb_alt = nullptr;
     long long *trace_buf = nullptr;                    // (-DDYC_TRACE experiment builds)       // the buffers that launch writes the new PVTFVB / PHI into (swapped in afterwards)
     int mom_tj = 4;                 // tile rows of the LDS-DMA momentum kernel (8: one workgroup per CU; 4: two, each with its own barrier)
     int cell_lin = -1;              // DYCORE_CELL_LINEAR: column-kernel launch, bit 0 = cell runs, bit 1 = XCD-aware order (default 3 or 2)
@@ -247,8 +245,7 @@ int check_ready(dycore *h)
     return 0;
 }
 
-int join_side(dycore *h);
-enum { LAZY_FLX = 1, LAZY_FLXDIV = 2, LAZY_PHIVB = 4, LAZY_PVTF = 8, LAZY_PHI = 16, LAZY_ALL = 31 };
+enum { LAZY_FLX = 1, LAZY_FLXDIV = 2, LAZY_PHIVB = 4, LAZY_PVTF = 8, LAZY_PHI = 16, LAZY_POTTVB = 32, LAZY_ALL = 63 };
 int refresh_lazy(dycore *h, int need = LAZY_ALL);
 // stage entry points read what the side stream may still be writing and what the fused step
 // left to be derived (`need`: which of the derived fields the stage reads)
@@ -256,7 +253,7 @@ int ready_join(dycore *h, int need = LAZY_ALL)
 {
     int rc = check_ready(h);
     if (rc) return rc;
-    if ((rc = join_side(h))) return rc;
+    h->planes_valid = false;        // a stage call may rewrite what the stored PHIVB planes were integrated from
     return refresh_lazy(h, need);
 }
 
@@ -362,7 +359,7 @@ int do_diag(dycore *h, const Ptrs &p)
 {
     Scope s(h, K_DIAG);
     hipLaunchKernelGGL(k_primary_diag, grid_for(h->g, h->g.nx + 2, h->g.ny + 2), dim3(TI, TJ), 0, h->stream, h->g, p);
-    if (&p == &h->p || p.PVTF == h->p.PVTF) { h->stale_pvtf = false; h->stale_phivb = false; h->stale_phi = false; }      // it writes all three, whole array
+    if (&p == &h->p || p.PVTF == h->p.PVTF) { h->stale_pvtf = false; h->stale_phivb = false; h->stale_phi = false; h->stale_pottvb = false; }      // it writes all of them, whole array
     return launch_check("k_primary_diag");
 }
 int do_rho(dycore *h, const Ptrs &p)
@@ -458,11 +455,11 @@ int refresh_lazy(dycore *h, int need)
     if ((need & LAZY_PHIVB) && h->stale_phivb && h->stale_phi) need |= LAZY_PHI;      // k_derive_phi writes PHI and PHIVB
     if ((need & LAZY_PHIVB) && h->stale_phivb && !(need & LAZY_PHI)) need |= LAZY_PVTF;      // PHIVB from PHI, POTT, PVTFVB and PVTF
     const bool d_phi = h->stale_phi && (need & LAZY_PHI);
+    const bool d_pottvb = h->stale_pottvb && (need & LAZY_POTTVB);
     const bool d_flx = h->stale_uvflx && (need & LAZY_FLX), d_div = h->stale_flxdiv && (need & LAZY_FLXDIV),
                d_phivb = h->stale_phivb && (need & LAZY_PHIVB) && !d_phi, d_pvtf = h->stale_pvtf && (need & LAZY_PVTF);
-    if (!d_flx && !d_div && !d_phivb && !d_pvtf && !d_phi) return 0;
-    int rc = join_side(h);
-    if (rc) return rc;
+    if (!d_flx && !d_div && !d_phivb && !d_pvtf && !d_phi && !d_pottvb) return 0;
+    int rc;
     Scope s(h, K_DERIVE);
     if (d_flx) {
         hipLaunchKernelGGL(k_derive_uvflx, grid_for(h->g, h->g.nx, h->g.ny), dim3(TI, TJ), 0, h->stream, h->g, h->p, h->flx_u, h->flx_v);
@@ -475,13 +472,20 @@ int refresh_lazy(dycore *h, int need)
         if ((rc = launch_check("k_derive_flxdiv"))) return rc;
         h->stale_flxdiv = false;
     }
+    // (a handle whose step keeps PHI in the momentum kernel's threads derives with the canonical forms that step uses)
+    const int canon = phi_on_demand(h) ? 1 : 0;
     if (d_pvtf) {
-        hipLaunchKernelGGL(k_derive_pvtf, grid_for(h->g, h->g.nx + 2, h->g.ny + 2), dim3(TI, TJ), 0, h->stream, h->g, h->p);
+        hipLaunchKernelGGL(k_derive_pvtf, grid_for(h->g, h->g.nx + 2, h->g.ny + 2), dim3(TI, TJ), 0, h->stream, h->g, h->p, canon);
         if ((rc = launch_check("k_derive_pvtf"))) return rc;
         h->stale_pvtf = false;
     }
+    if (d_pottvb) {
+        hipLaunchKernelGGL(k_derive_pottvb, grid_for(h->g, h->g.nx + 2, h->g.ny + 2), dim3(TI, TJ), 0, h->stream, h->g, h->p);
+        if ((rc = launch_check("k_derive_pottvb"))) return rc;
+        h->stale_pottvb = false;
+    }
     if (d_phi) {
-        hipLaunchKernelGGL(k_derive_phi, grid_for(h->g, h->g.nx + 2, h->g.ny + 2), dim3(TI, TJ), 0, h->stream, h->g, h->p);
+        hipLaunchKernelGGL(k_derive_phi, grid_for(h->g, h->g.nx + 2, h->g.ny + 2), dim3(TI, TJ), 0, h->stream, h->g, h->p, canon);
         if ((rc = launch_check("k_derive_phi"))) return rc;
         h->stale_phi = false;
         h->stale_phivb = false;
@@ -510,6 +514,23 @@ bool row_subset(int n, int dep_s, int dep_n, int mode, RowSet &rs)
     return rs.n > 0;
 }
 
+// The level chunks of the PHI_LOCAL momentum kernel start from stored PHIVB planes.  k_temp_canon keeps them current from
+// substep to substep; after an upload, a stage call or a whole-substep launch nobody has integrated them for the current
+// state: once, with the forms the threads use (whole array, halo rows included: a band's halo rows of POTT, PVTFVB, COLP,
+// HSURF are in place whenever its step starts).  Called when a step begins, i.e. before the band's first exchange of
+// the step packs rows of these planes for its neighbours.
+bool phi_on_demand(const dycore *h);
+int ensure_planes(dycore *h)
+{
+    if (h->planes_valid || !phi_on_demand(h)) return 0;
+    Scope s(h, K_DERIVE);
+    hipLaunchKernelGGL(k_derive_phi, grid_for(h->g, h->g.nx + 2, h->g.ny + 2), dim3(TI, TJ), 0, h->stream, h->g, h->p, 1);
+    int rc = launch_check("k_derive_phi");
+    if (rc) return rc;
+    h->stale_phi = false; h->stale_phivb = false;
+    h->planes_valid = true;
+    return 0;
+}
 // prepare + dUFLXdt + dVFLXdt (+ Euler step of the winds when u_out != nullptr)
 int do_momentum_fused(dycore *h, const Ptrs &p, const real *u_old, const real *v_old,
                       real *u_out, real *v_out, real dt, int mode = ROWS_ALL)
@@ -597,10 +618,11 @@ int do_momentum_fused(dycore *h, const Ptrs &p, const real *u_old, const real *v
         const bool cur = (u_old == p.UWIND);
         const bool fw = flux_from_winds(h) && (h->fw_mask & 2);
         // ring depth: two levels in flight for the production (dry / moist, fluxes from the winds) instances
-#define MOM_LAUNCH_P(CUR_, TJ_, FW_, TB_, DP_, PL_) hipLaunchKernelGGL((k_momentum_dma<CUR_, TJ_, FW_, TB_, DP_, PL_>), gr2, blk, dma_lds_bytes(TJ_, FW_, CUR_, DP_, PL_), h->stream, h->g, p, gbx, plan, jv_lo, u_old, v_old, u_out, v_out, dt, TempArgs{nullptr, nullptr, nullptr, nullptr, nullptr})
+#define MOM_LAUNCH_P(CUR_, TJ_, FW_, TB_, DP_, PL_) hipLaunchKernelGGL((k_momentum_dma<CUR_, TJ_, FW_, TB_, DP_, PL_>), gr2, blk, dma_lds_bytes(TJ_, FW_, CUR_, DP_, PL_), h->stream, h->g, p, gbx, plan, jv_lo, u_old, v_old, u_out, v_out, dt, TempArgs{nullptr, nullptr, nullptr, nullptr})
 #define MOM_LAUNCH_T(CUR_, TJ_, FW_, TB_, DP_) MOM_LAUNCH_P(CUR_, TJ_, FW_, TB_, DP_, false)
 #define MOM_LAUNCH(CUR_, FW_, TB_, DP_) MOM_LAUNCH_T(CUR_, FTJ, FW_, TB_, DP_)
         const bool pl = phi_on_demand(h);
+        if (half && pl) { int rc = ensure_planes(h); if (rc) return rc; }       // (step_begin has done it; a caller of the parts may not have)
         if (half && pl) { if (!cur) MOM_LAUNCH_P(false, 4, true, false, 1, true); else if (h->mom_depth == 2) MOM_LAUNCH_P(true, 4, true, false, 2, true); else MOM_LAUNCH_P(true, 4, true, false, 1, true); }
         else if (half) { if (!cur) MOM_LAUNCH_T(false, 4, true, false, 1); else if (h->mom_depth == 2) MOM_LAUNCH_T(true, 4, true, false, 2); else MOM_LAUNCH_T(true, 4, true, false, 1); }
         else if (h->g.i_turb) { if (cur) MOM_LAUNCH(true, true, true, 1); else MOM_LAUNCH(false, true, true, 1); }
@@ -618,8 +640,7 @@ int do_momentum_fused(dycore *h, const Ptrs &p, const real *u_old, const real *v
 // momentum + temperature in one launch: see k_momentum_dma<..., WITH_TEMP>
 bool substep_fused(const dycore *h)
 {
-    return h->step_fused && h->pvb_alt && h->phi_alt && h->g.pole_s && h->g.pole_n && pvtf_on_demand(h) && !phi_on_demand(h) &&
-           h->mom_tj == 4 && h->g.nz >= 2;
+    return h->step_fused && h->pvb_alt && h->g.pole_s && h->g.pole_n && phi_on_demand(h) && h->g.nz >= 2;
 }
 int do_substep_fused(dycore *h, const Ptrs &p, const real *u_old, const real *v_old, const real *pott_old,
                      real *u_out, real *v_out, real *pott_out, real dt)
@@ -633,27 +654,27 @@ int do_substep_fused(dycore *h, const Ptrs &p, const real *u_old, const real *v_
 #ifdef DYC_TRACE
     static long long *trace_buf = nullptr;
     if (!trace_buf && hipMalloc((void **)&trace_buf, 8 * 256 * 8 * sizeof(long long)) == hipSuccess) (void)hipMemset(trace_buf, 0, 8 * 256 * 8 * sizeof(long long));
-    const TempArgs ta = {pott_old, pott_out, h->pvb_alt, h->phi_alt, trace_buf};
+    const TempArgs ta = {pott_old, pott_out, h->pvb_alt, trace_buf};
     h->trace_buf = trace_buf;
 #else
-    const TempArgs ta = {pott_old, pott_out, h->pvb_alt, h->phi_alt, nullptr};
+    const TempArgs ta = {pott_old, pott_out, h->pvb_alt, nullptr};
 #endif
     const int jv_lo = 2;        // pole_s
-    if (cur) hipLaunchKernelGGL((k_momentum_dma<true, tj, true, false, 2, false, true>), gr, blk, dma_lds_bytes(tj, true, true, 2, false, true), h->stream,
+    // (whole columns: PHI starts from the surface geopotential in every thread, no stored PHIVB plane is read or written)
+    if (cur) hipLaunchKernelGGL((k_momentum_dma<true, tj, true, false, 2, true, true>), gr, blk, dma_lds_bytes(tj, true, true, 2, true, true), h->stream,
                                 h->g, p, gbx, plan, jv_lo, u_old, v_old, u_out, v_out, dt, ta);
-    else hipLaunchKernelGGL((k_momentum_dma<false, tj, true, false, 2, false, true>), gr, blk, dma_lds_bytes(tj, true, false, 2, false, true), h->stream,
+    else hipLaunchKernelGGL((k_momentum_dma<false, tj, true, false, 2, true, true>), gr, blk, dma_lds_bytes(tj, true, false, 2, true, true), h->stream,
                             h->g, p, gbx, plan, jv_lo, u_old, v_old, u_out, v_out, dt, ta);
     int rc = launch_check("k_substep_fused");
     if (rc) return rc;
     std::swap(h->p.PVTFVB, h->pvb_alt);
-    std::swap(h->p.PHI, h->phi_alt);
-    h->stale_pvtf = true;
-    h->stale_phivb = true;
+    h->stale_pvtf = true; h->stale_phi = true; h->stale_phivb = true; h->stale_pottvb = true;
+    h->planes_valid = false;        // whole columns: this launch neither reads nor writes the planes
     return 0;
 }
 int do_pott_fused(dycore *h, const Ptrs &p, const real *pott_old, real *pott_out, real dt)
 {
-    Scope s(h, K_POTT_FUSED);
+    Scope s(h, (!h->g.i_turb && h->lazy && phi_on_demand(h)) ? K_TEMP_CANON : K_POTT_FUSED);
     const dim3 gr = grid_cells(h), bl(TI, TJ);
     const int lin = cells_linear(h);
 #define POTT_LAUNCH_P(W_, F_, T_, V_, P_) hipLaunchKernelGGL((k_pott_fused<W_, F_, T_, V_, P_>), gr, bl, 0, h->stream, h->g, p, pott_old, pott_out, dt, lin)
@@ -661,7 +682,11 @@ int do_pott_fused(dycore *h, const Ptrs &p, const real *pott_old, real *pott_out
     if (h->g.i_turb) {                  // fused turbulence-coupled step: PHIVB is an input of k_turb_tendencies, so it is stored
         POTT_LAUNCH(true, true, true, true);
     } else if (h->lazy) {
-        if (phi_on_demand(h)) { POTT_LAUNCH_P(false, true, false, false, false); h->stale_pvtf = true; h->stale_phi = true; }
+        if (phi_on_demand(h)) {         // production: neither PHI nor POTTVB is stored (k_temp_canon)
+            hipLaunchKernelGGL(k_temp_canon, gr, bl, 0, h->stream, h->g, p, pott_old, pott_out, dt, lin);
+            h->stale_pvtf = true; h->stale_phi = true; h->stale_pottvb = true;
+            h->planes_valid = true;     // ... and of the halo rows once their owner's rows have arrived (a band's exchange)
+        }
         else if (pvtf_on_demand(h)) { POTT_LAUNCH(false, true, false, false); h->stale_pvtf = true; }
         else if (flux_from_winds(h) && (h->fw_mask & 4)) POTT_LAUNCH(false, true, false, true);
         else POTT_LAUNCH(false, false, false, true);
@@ -705,39 +730,6 @@ int do_moist(dycore *h, const Ptrs &p, const real *qv_old, const real *qc_old, r
     return launch_check("k_moist");
 }
 
-// primary diagnostics on the halo rows a band received from its neighbours
-// The two rows are a 64-level serial recursion on ~3000 columns (latency-bound, ~60 us): they
-// run on a side stream behind the unpack of the received POTT rows and are joined again before
-// the next kernel that reads the diagnostics (join_side), i.e. they overlap the continuity
-// kernel and the first exchange of the next substep.
-int join_side(dycore *h)
-{
-    if (!h->side_pending) return 0;
-    HIP_TRY(hipStreamWaitEvent(h->stream, h->ev_side, 0));
-    h->side_pending = false;
-    return 0;
-}
-int do_diag_band_halo(dycore *h, const Ptrs &p)
-{
-    if (h->g.pole_s && h->g.pole_n) return 0;
-    const int row_a = h->g.pole_s ? -1 : 0, row_b = h->g.pole_n ? -1 : h->g.ny + 1;
-    const dim3 gr((h->g.nx + 2 + 63) / 64, 2);
-    const size_t lds = (size_t)(h->g.nz + 1) * 64 * sizeof(real);
-    if (h->prof == 1 || !h->side) { // full profiling brackets every launch on the main stream
-        Scope s(h, K_DIAG_ROWS);
-        hipLaunchKernelGGL(k_primary_diag_rows, gr, dim3(256), lds, h->stream, h->g, p, row_a, row_b);
-        return launch_check("k_primary_diag_rows");
-    }
-    HIP_TRY(hipEventRecord(h->ev_main, h->stream));
-    HIP_TRY(hipStreamWaitEvent(h->side, h->ev_main, 0));
-    hipLaunchKernelGGL(k_primary_diag_rows, gr, dim3(256), lds, h->side, h->g, p, row_a, row_b);
-    int rc = launch_check("k_primary_diag_rows");
-    if (rc) return rc;
-    HIP_TRY(hipEventRecord(h->ev_side, h->side));
-    h->side_pending = true;
-    return 0;
-}
-
 int do_momentum(dycore *h, const Ptrs &p)
 {
     int rc;
@@ -773,8 +765,9 @@ int step_begin(dycore *h, int with_rho)
 {
     int rc;
     Ptrs &p = h->p;
-    if (with_rho && ((rc = join_side(h)) || (rc = refresh_lazy(h, LAZY_PVTF)) || (rc = do_rho(h, p)))) return rc;
+    if (with_rho && ((rc = refresh_lazy(h, LAZY_PVTF | LAZY_POTTVB)) || (rc = do_rho(h, p)))) return rc;
     if (fused_path(h)) {
+        if (!h->g.i_turb && !substep_fused(h) && (rc = ensure_planes(h))) return rc;
         if (h->g.i_turb) {
             // dyn_org_discretizations.py:195-196, 212-216: lateral BC of the K field and the surface momentum
             // fluxes, once per step (they do not change within one).  Whole-field exchange as in the staged
@@ -821,7 +814,6 @@ int substep_part(dycore *h, real dt, int sub, int part)
             if (h->g.i_turb && (rc = do_turb_tendencies(h, q, ROWS_INNER))) return rc;
             return do_momentum_fused(h, q, p.UWIND, p.VWIND, u_out, v_out, dt, ROWS_INNER);
         case DYCORE_PART_MOM_EDGE:  // -> new winds complete: their rows can travel while part TEMP runs
-            if ((rc = join_side(h))) return rc;
             if (h->g.i_turb && (rc = do_turb_tendencies(h, q, ROWS_EDGE))) return rc;
             // the rows that leave now are packed with their periodic images (k_rows); the lateral halo of
             // the new winds is refreshed with everything else at the end of part TEMP
@@ -832,7 +824,6 @@ int substep_part(dycore *h, real dt, int sub, int part)
                 if ((rc = do_substep_fused(h, q, p.UWIND, p.VWIND, p.POTT, u_out, v_out, t_out, dt))) return rc;
             } else {
                 if (part == 1) {
-                    if ((rc = join_side(h))) return rc;
                     if (h->g.i_turb && (rc = do_turb_tendencies(h, q))) return rc;
                     if ((rc = do_momentum_fused(h, q, p.UWIND, p.VWIND, u_out, v_out, dt))) return rc;
                 }
@@ -842,8 +833,8 @@ int substep_part(dycore *h, real dt, int sub, int part)
             if (h->g.i_moist && (rc = do_moist(h, q, p.QV, p.QC, qv_out, qc_out, dt))) return rc;
             const int nz = h->g.nz;
             if (h->g.i_moist && (rc = do_halo(h, {{qv_out, 0, 0, nz}, {qc_out, 0, 0, nz}}))) return rc;
-            std::vector<HaloSpec> hl = {{t_out, 0, 0, nz}, {p.PVTFVB, 0, 0, nz + 1}, {p.POTTVB, 0, 0, nz + 1}};
-            if (!phi_on_demand(h)) hl.push_back({p.PHI, 0, 0, nz});
+            std::vector<HaloSpec> hl = {{t_out, 0, 0, nz}, {p.PVTFVB, 0, 0, nz + 1}};
+            if (!phi_on_demand(h)) { hl.push_back({p.POTTVB, 0, 0, nz + 1}); hl.push_back({p.PHI, 0, 0, nz}); }
             if (!pvtf_on_demand(h)) hl.push_back({p.PVTF, 0, 0, nz});
             if (!h->lazy || h->g.i_turb) hl.push_back({p.PHIVB, 0, 0, nz + 1});
             hl.push_back({u_out, 1, 0, nz});   // owned rows and pole rows only: rows in flight from a neighbour are not touched
@@ -851,11 +842,8 @@ int substep_part(dycore *h, real dt, int sub, int part)
             // + COLP <- COLP_NEW (dyn_matsuno.py:64-67) as a rider of the same launch  -> winds, POTT halo rows
             return do_halo(h, hl, p.COLP, p.COLP_NEW, (size_t)h->g.plane);
         }
-        case 2: {
-            Ptrs d = p;
-            d.POTT = t_out;
-            return do_diag_band_halo(h, d);
-        }
+        case 2:             // nothing: the diagnostics of a band's halo rows arrive from their owner with the POTT rows
+            return 0;       // (dycore_band_row_fields), like the rows themselves -- same bits as the single-domain run
         }
         return fail(DYCORE_EINVAL, "substep part %d out of range", part);
     }
@@ -957,10 +945,10 @@ int dycore_create(const DycoreConfig *cfg, dycore_t **out)
         MOM_ATTR_P(true, 4, true, false, 1, true, ok_pl) MOM_ATTR_P(true, 4, true, false, 2, true, ok_pl) MOM_ATTR_P(false, 4, true, false, 1, true, ok_pl)
         if (!ok_pl) h->lazy_phi = false;
         bool ok_wt = true;
-        if (hipFuncSetAttribute((const void *)k_momentum_dma<true, 4, true, false, 2, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)dma_lds_bytes(4, true, true, 2, false, true)) != hipSuccess) { (void)hipGetLastError(); ok_wt = false; }
-        if (hipFuncSetAttribute((const void *)k_momentum_dma<false, 4, true, false, 2, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)dma_lds_bytes(4, true, false, 2, false, true)) != hipSuccess) { (void)hipGetLastError(); ok_wt = false; }
+        if (hipFuncSetAttribute((const void *)k_momentum_dma<true, 4, true, false, 2, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)dma_lds_bytes(4, true, true, 2, true, true)) != hipSuccess) { (void)hipGetLastError(); ok_wt = false; }
+        if (hipFuncSetAttribute((const void *)k_momentum_dma<false, 4, true, false, 2, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)dma_lds_bytes(4, true, false, 2, true, true)) != hipSuccess) { (void)hipGetLastError(); ok_wt = false; }
         if (!ok_wt) h->step_fused = false;
 #define MOM_ATTR(CUR_, FW_, TB_, DP_, FLAG_) MOM_ATTR_T(CUR_, FTJ, FW_, TB_, DP_, FLAG_)
         MOM_ATTR_T(true, 4, true, false, 1, ok_half) MOM_ATTR_T(true, 4, true, false, 2, ok_half) MOM_ATTR_T(false, 4, true, false, 1, ok_half)
@@ -983,20 +971,6 @@ int dycore_create(const DycoreConfig *cfg, dycore_t **out)
         h->own_stream = true;
     }
     h->home = h->stream;
-    if (!(g.pole_s && g.pole_n)) {      // a band of a decomposed grid
-        if ((size_t)(g.nz + 1) * 64 * sizeof(real) > 65536 &&
-            hipFuncSetAttribute((const void *)k_primary_diag_rows, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((g.nz + 1) * 64 * sizeof(real))) != hipSuccess) {
-            (void)hipGetLastError();
-            delete h;
-            return fail(DYCORE_EINVAL, "too many levels (%d) for the halo-row diagnostics of a latitude band", g.nz);
-        }
-        if (hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking) != hipSuccess ||
-            hipEventCreateWithFlags(&h->ev_main, hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&h->ev_side, hipEventDisableTiming) != hipSuccess) {
-            (void)hipGetLastError();
-            h->side = nullptr;
-        }
-    }
     const real nan = std::numeric_limits<real>::quiet_NaN();
     // Every array is placed so that column i = 1 (the first owned longitude) of every row sits
     // on a 512-B boundary: a wavefront's 64 x 8 B row segment then covers exactly four 128-B
@@ -1052,7 +1026,6 @@ int dycore_create(const DycoreConfig *cfg, dycore_t **out)
     }
     if (!rc && h->step_fused && g.pole_s && g.pole_n && !g.i_turb) {       // (substep_fused: the other conditions can change with the grid)
         rc = alloc(h->field_elems(-1), &h->pvb_alt);         // nz + 1 planes
-        if (!rc) rc = alloc(h->field_elems(0), &h->phi_alt);
     }
     if (!rc) {
         h->stage_elems = (size_t)(g.nx + 3) * (g.ny + 3) * (g.nz + 1);
@@ -1073,9 +1046,6 @@ int dycore_destroy(dycore_t *h)
     for (auto &r : h->recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     for (auto e : h->ev_pool) (void)hipEventDestroy(e);
     for (real *d : h->allocs) (void)hipFree(d);
-    if (h->side) { (void)hipStreamSynchronize(h->side); (void)hipStreamDestroy(h->side); }
-    if (h->ev_main) (void)hipEventDestroy(h->ev_main);
-    if (h->ev_side) (void)hipEventDestroy(h->ev_side);
     if (h->own_stream) (void)hipStreamDestroy(h->home);
     delete h;
     return 0;
@@ -1089,6 +1059,28 @@ int dycore_use_stream(dycore_t *h, void *stream)
 }
 void *dycore_get_stream(dycore_t *h) { return h ? (void *)h->home : nullptr; }
 int dycore_overlap_parts(dycore_t *h) { return h && fused_path(h) && flux_from_winds(h) ? 1 : 0; }
+// Diagnostic fields whose halo rows a latitude band receives from their owner together with the POTT rows (the band does
+// not re-diagnose rows it does not own: the owner's bits travel).  Which ones depends on what the handle's step stores.
+static void band_row_fields(const dycore *h, std::vector<const char *> &out)
+{
+    if (!fused_path(h)) return;                 // the staged step diagnoses the whole band, halo rows included (part 2)
+    out.push_back("PVTFVB");
+    if (!h->g.i_turb && phi_on_demand(h)) { out.push_back("PHIVB"); return; }       // (the planes the level chunks start from)
+    out.push_back("PHI"); out.push_back("POTTVB");
+    if (!pvtf_on_demand(h)) out.push_back("PVTF");
+    if (!h->lazy || h->g.i_turb) out.push_back("PHIVB");
+}
+int dycore_band_row_fields(dycore_t *h, char *buf, int32_t nbytes)
+{
+    if (!h || !buf || nbytes < 1) return fail(DYCORE_EINVAL, "bad argument");
+    std::vector<const char *> v;
+    band_row_fields(h, v);
+    std::string s;
+    for (const char *n : v) { if (!s.empty()) s += ','; s += n; }
+    if ((int)s.size() + 1 > nbytes) return fail(DYCORE_EINVAL, "buffer of %d bytes too small", nbytes);
+    memcpy(buf, s.c_str(), s.size() + 1);
+    return 0;
+}
 int dycore_flux_from_winds(dycore_t *h) { return h && fused_path(h) && flux_from_winds(h) ? 1 : 0; }
 #ifdef DYC_TRACE
 extern "C" int dycore_debug_trace(dycore_t *h, long long *host)      // 8 waves x 256 levels x 8 points
@@ -1102,8 +1094,6 @@ extern "C" int dycore_debug_trace(dycore_t *h, long long *host)      // 8 waves 
 int dycore_sync(dycore_t *h)
 {
     if (!h) return fail(DYCORE_EINVAL, "null handle");
-    int rc = join_side(h);
-    if (rc) return rc;
     HIP_TRY(hipStreamSynchronize(h->stream));
     return 0;
 }
@@ -1179,6 +1169,7 @@ int dycore_set_grid(dycore_t *h, const char *name, const real *host, int32_t n0,
         HIP_TRY(hipStreamSynchronize(h->stream));
     }
     h->grid_set |= 1 << it->second;
+    h->planes_valid = false;
     return 0;
 }
 
@@ -1218,7 +1209,8 @@ int dycore_upload(dycore_t *h, const char *name, const real *host)
     if (rc) return rc;
     if (!host) return fail(DYCORE_EINVAL, "null host pointer");
     if (d->member == &Ptrs::UWIND || d->member == &Ptrs::VWIND) h->winds_bc_dirty = true;
-    if (d->member == &Ptrs::UFLX || d->member == &Ptrs::VFLX || d->member == &Ptrs::FLXDIV || d->member == &Ptrs::PHIVB || d->member == &Ptrs::PVTF || d->member == &Ptrs::PHI)
+    h->planes_valid = false;
+    if (d->member == &Ptrs::UFLX || d->member == &Ptrs::VFLX || d->member == &Ptrs::FLXDIV || d->member == &Ptrs::PHIVB || d->member == &Ptrs::PVTF || d->member == &Ptrs::PHI || d->member == &Ptrs::POTTVB)
         if ((rc = refresh_lazy(h))) return rc;      // a caller's value must not be overwritten by a later derivation
     const Geo &g = h->g;
     const int n0 = g.nx + 2 + d->stgx, n1 = g.ny + 2 + d->stgy, n2 = h->nk_of(d->nk);
@@ -1239,6 +1231,7 @@ static int lazy_need(const FieldDesc *d)
     if (d->member == &Ptrs::PHIVB) return LAZY_PHIVB;
     if (d->member == &Ptrs::PVTF) return LAZY_PVTF;
     if (d->member == &Ptrs::PHI) return LAZY_PHI;
+    if (d->member == &Ptrs::POTTVB) return LAZY_POTTVB;
     return 0;
 }
 
@@ -1248,7 +1241,6 @@ int dycore_download(dycore_t *h, const char *name, real *host)
     int rc = find_field(h, name, &d);
     if (rc) return rc;
     if (!host) return fail(DYCORE_EINVAL, "null host pointer");
-    if ((rc = join_side(h))) return rc;
     if ((rc = refresh_lazy(h, lazy_need(d)))) return rc;
     const Geo &g = h->g;
     const int n0 = g.nx + 2 + d->stgx, n1 = g.ny + 2 + d->stgy, n2 = h->nk_of(d->nk);
@@ -1267,6 +1259,7 @@ int dycore_field_ptr(dycore_t *h, const char *name, void **dev, int64_t *pitch, 
     int rc = find_field(h, name, &d);
     if (rc) return rc;
     if ((rc = refresh_lazy(h, lazy_need(d)))) return rc;
+    h->planes_valid = false;        // the caller may write through the pointer
     if (dev) *dev = h->p.*(d->member);
     if (pitch) *pitch = h->g.P;
     if (rows) *rows = h->g.NJ;
@@ -1281,7 +1274,7 @@ int dycore_copy_field(dycore_t *h, const char *dst, const char *src)
     if ((rc = find_field(h, dst, &a)) || (rc = find_field(h, src, &b))) return rc;
     if (a->stgx != b->stgx || a->stgy != b->stgy || a->nk != b->nk)
         return fail(DYCORE_EINVAL, "copy_field: '%s' and '%s' differ in shape", dst, src);
-    if ((rc = join_side(h))) return rc;
+    h->planes_valid = false;
     if ((rc = refresh_lazy(h, lazy_need(a) | lazy_need(b)))) return rc;
     return do_copy(h, h->p.*(a->member), h->p.*(b->member), h->field_elems(a->nk));
 }
@@ -1309,9 +1302,9 @@ int dycore_moist_tendency(dycore_t *h)
 }
 int dycore_euler_forward(dycore_t *h, double dt) { int rc = ready_join(h); return rc ? rc : do_euler(h, h->p, dt); }
 int dycore_primary_diag(dycore_t *h) { int rc = ready_join(h); return rc ? rc : do_diag(h, h->p); }
-int dycore_secondary_diag_rho(dycore_t *h) { int rc = ready_join(h, LAZY_PVTF); return rc ? rc : do_rho(h, h->p); }
-int dycore_secondary_diag(dycore_t *h) { int rc = ready_join(h, LAZY_PVTF); return rc ? rc : do_secondary(h, h->p); }
-int dycore_compute_turbulence(dycore_t *h) { int rc = ready_join(h, LAZY_PHIVB | LAZY_PHI); return rc ? rc : do_turbulence(h, h->p); }
+int dycore_secondary_diag_rho(dycore_t *h) { int rc = ready_join(h, LAZY_PVTF | LAZY_POTTVB); return rc ? rc : do_rho(h, h->p); }
+int dycore_secondary_diag(dycore_t *h) { int rc = ready_join(h, LAZY_PVTF | LAZY_POTTVB); return rc ? rc : do_secondary(h, h->p); }
+int dycore_compute_turbulence(dycore_t *h) { int rc = ready_join(h, LAZY_PHIVB | LAZY_PHI | LAZY_POTTVB); return rc ? rc : do_turbulence(h, h->p); }
 
 int dycore_radiation(dycore_t *h, double solar_constant, int32_t nbins, const double *lambdas_center, const double *dlambdas)
 {
@@ -1396,6 +1389,7 @@ static int rows_op(dycore_t *h, int32_t n, const char *const *names, const int32
             rl.base[e] = q.*(d->member);
             rl.row[e] = rows[done];
             rl.nk[e] = h->nk_of(d->nk);
+            rl.k0[e] = 0; rl.kstep[e] = 1;
             rl.off[e] = off;
             off += (long long)rl.nk[e] * (h->g.nx + 3);
             if (rl.nk[e] > maxk) maxk = rl.nk[e];

@@ -370,8 +370,8 @@ constexpr int mom_off(int f, int tj, bool fw, bool pl = false, bool wt = false) 
     for (int g = (fw ? 2 : 0); g < f; g++) o += mom_rows(g, tj, fw, pl, wt) * FTW;
     return o;
 }
-// own-cell tiles behind the staged ones (FTI wide): the step-start winds of the corrector; WITH_TEMP: + POTTVB, + the step-start POTT of the corrector, + dPOTTdt_RAD
-constexpr int mom_own_tiles(bool cur, bool wt) { return (cur ? 0 : 2) + (wt ? (cur ? 1 : 2) + 1 : 0); }       // (+ 1: the radiative heating rate, staged only on a handle with i_radiation)
+// own-cell tiles behind the staged ones (FTI wide): the step-start winds of the corrector; WITH_TEMP: + the step-start POTT of the corrector, + dPOTTdt_RAD
+constexpr int mom_own_tiles(bool cur, bool wt) { return (cur ? 0 : 2) + (wt ? (cur ? 0 : 1) + 1 : 0); }       // (+ 1: the radiative heating rate, staged only on a handle with i_radiation)
 constexpr int mom_dma_slot(int tj, bool fw, bool cur, bool pl = false, bool wt = false) { return mom_off(FNF, tj, fw, pl, wt) + mom_own_tiles(cur, wt) * FTI * tj; }
 constexpr int mom_flux_slot(int tj, bool fw) { return fw ? (2 * tj + 5) * FTW : 0; }
 // ... then (fw) two factor tiles, dyis (tj+2 rows) and dxjs (tj+3 rows), shaped like the UFLX / VFLX tiles
@@ -382,6 +382,12 @@ constexpr size_t dma_lds_bytes(int tj, bool fw, bool cur, int depth, bool pl = f
 
 #ifndef DYC_DMA_AUX
 #define DYC_DMA_AUX 0       // cache policy of the LDS-DMA loads (2 = nt)
+#endif
+#ifndef DYC_MV_T
+#define DYC_MV_T 0          // whole-substep kernel: staged fields whose DMA the TEMPERATURE wavefronts issue (bit f = field f; k_momentum_dma)
+#endif
+#ifndef DYC_EXP_TEMP
+#define DYC_EXP_TEMP 0     // experiment builds only (wrong results): k_temp_canon without the PHIVB chain (1), the interface division (2), the Exner function (3)
 #endif
 #ifndef DYC_WT_SKIP
 #define DYC_WT_SKIP 0       // experiment builds only (wrong results): WITH_TEMP without the temperature (1) / momentum (2) arithmetic
@@ -476,6 +482,35 @@ __device__ __forceinline__ real dot6(const real (&w)[6], real x0, real x1, real 
         if (HAS_RAD_) t_ = fma((RAD_), (COLP_), t_);                                                                    \
         OUT_ = fma(mul_rn((DT_), t_), (RCN_), mul_rn(mul_rn((PO_), (COLD_)), (RCN_)));                                  \
     }
+// The same arithmetic in two pieces, for the kernels that do not read a stored POTTVB (k_temp_canon, the temperature
+// wavefronts of the whole-substep kernel): the interface value between levels k and k+1 (dyn_diagnostics.py:183-186) of the
+// state the tendency is evaluated on is formed in the thread from POTT and PVTFVB of the two levels, so the vertical
+// advection of a level can only be added once the level above it has been read -- a level is "closed" one iteration late,
+// as in the momentum wavefronts.  TEMP_PARTIAL: horizontal advection, diffusion, radiative heating of level k;
+// TEMP_CLOSE: + vertical advection between the level's two interfaces (LP_ = mul_rn(w, POTTVB) at the lower one) and the
+// pressure-weighted Euler step.  Every rounding written out: both kernels produce the same bits.
+#define TEMP_PARTIAL(OUT_, COLP_, CIM1_, CIP1_, CJM1_, CJP1_, HRA_, UF_, UF1_, VF_, VF1_, PT_, PIM1_, PIP1_, PJM1_, PJP1_, DIF_, HAS_RAD_, RAD_) \
+    real OUT_;                                                                                                          \
+    {                                                                                                                   \
+        const real sx_ = fma(-(UF1_), (PT_) + (PIP1_), mul_rn((UF_), (PIM1_) + (PT_)));                                 \
+        const real sy_ = fma(-(VF1_), (PT_) + (PJP1_), mul_rn((VF_), (PJM1_) + (PT_)));                                 \
+        real t_ = mul_rn(sx_ + sy_, (HRA_));                                                                            \
+        const real dif_ = (DIF_);                                                                                       \
+        if (dif_ > 0.0) {                                                                                               \
+            real d_ = mul_rn((CIM1_), (PIM1_));                                                                         \
+            d_ = fma((CIP1_), (PIP1_), d_); d_ = fma((CJM1_), (PJM1_), d_); d_ = fma((CJP1_), (PJP1_), d_);             \
+            d_ = fma((real)-4.0 * (COLP_), (PT_), d_);                                                                  \
+            t_ = fma(dif_, d_, t_);                                                                                     \
+        }                                                                                                               \
+        if (HAS_RAD_) t_ = fma((RAD_), (COLP_), t_);                                                                    \
+        OUT_ = t_;                                                                                                      \
+    }
+#define TEMP_CLOSE(OUT_, TPART_, CNEW_, COLD_, RCN_, WK_, VBK_, LP_, RDS_, PO_, DT_)                                    \
+    real OUT_;                                                                                                          \
+    {                                                                                                                   \
+        const real t_ = fma(mul_rn((CNEW_), fma((WK_), (VBK_), -(LP_))), (RDS_), (TPART_));                             \
+        OUT_ = fma(mul_rn((DT_), t_), (RCN_), mul_rn(mul_rn((PO_), (COLD_)), (RCN_)));                                  \
+    }
 // workgroup barrier that publishes this wave's LDS writes but leaves its vector-memory operations in flight
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
@@ -498,7 +533,7 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 // alternate buffers (the momentum wavefronts of neighbouring tiles still read the old ones), which the library swaps in
 // after the launch.  Whole columns only (the diagnostics integrate from the surface): no level chunks, so a latitude
 // band, whose few tiles need them to fill the chip, keeps the two separate kernels.
-struct TempArgs { const real *pott_old; real *pott_out, *pvb_out, *phi_out; long long *trace; };
+struct TempArgs { const real *pott_old; real *pott_out, *pvb_out; long long *trace; };
 // -DDYC_TRACE (experiment builds only): the wavefronts of ONE workgroup of the whole-substep kernel write their cycle counter at
 // four points of every level: [wave][level][point], point 0 = top of the iteration, 1 = stores and DMA issued, 2 = arithmetic
 // done, 3 = own DMA landed / flux entries formed (the barrier follows)
@@ -512,7 +547,7 @@ __global__ __launch_bounds__(FTI *TJ *(WITH_TEMP ? 2 : 1), ((TJ <= 4 && !WITH_TE
                                                       const real *u_old, const real *v_old,
                                                       real *u_out, real *v_out, real dt, TempArgs ta)
 {
-    static_assert(!WITH_TEMP || (FROM_WINDS && !TURB && !PHI_LOCAL && DEPTH == 2), "the temperature wavefronts read the re-formed flux tiles and the staged PHI");
+    static_assert(!WITH_TEMP || (FROM_WINDS && !TURB && PHI_LOCAL && DEPTH == 2), "the temperature wavefronts read the re-formed flux tiles; nobody stores PHI for the momentum wavefronts");
     static_assert(DEPTH == 1 || DEPTH == 2, "ring of 2 or 3 slots");
     static_assert(!(TURB && DEPTH != 1), "the turbulence-coupled variant keeps vector loads in the loop");
     static_assert(!PHI_LOCAL || FROM_WINDS, "PHI in the thread needs PVTF in the thread");
@@ -559,23 +594,30 @@ __global__ __launch_bounds__(FTI *TJ *(WITH_TEMP ? 2 : 1), ((TJ <= 4 && !WITH_TE
     const int P = g.P, nz = g.nz;
     const bool active = (i <= g.nx) && (j <= g.ny);
 
-    // ---- DMA assignment: waves 0..NSL-1 move slice `wave` (64 chunks) of each staged field;
-    // the last two waves move the UWIND / VWIND step-start tiles (ONSL slices each) ----
-    const int ch = wave * 64 + lane;                // this lane's chunk (full tiles)
+    // ---- DMA assignment: a staged field is moved in slices of 64 chunks, slice s by the s-th wavefront of the role that
+    // moves the field -- the momentum wavefronts, or (WITH_TEMP, bit f of MV_T) the temperature wavefronts: the momentum
+    // wavefront is the longer of the two instruction streams of a SIMD (timeline in profiles/r03_notes.md), and issuing a
+    // vector-memory instruction costs the issuing wavefront ~100 cycles; the role that moves the winds also forms the flux
+    // tiles from them (flux_own).  Without WITH_TEMP the last two waves move the UWIND / VWIND step-start tiles ----
+    constexpr unsigned MV_T = WITH_TEMP ? (unsigned)(DYC_MV_T) : 0u;
+    static_assert(((MV_T >> S_UW) & 1u) == ((MV_T >> S_VW) & 1u), "one role moves both wind fields (it forms the flux tiles)");
+    constexpr bool FLUX_T = ((MV_T >> S_UW) & 1u) != 0;       // the temperature wavefronts form the flux tiles
+    const int sl = role_t ? wave - TJ : wave;        // this wavefront's slice
+    const int ch = sl * 64 + lane;                  // this lane's chunk (full tiles)
     int goff = 0;                                   // its plane offset
     bool dma_on = false;
     int n_issue = 0;                                // DMA instructions this wave issues per level (wave-uniform)
-    if (wave < NSL) {
+    if (sl < NSL) {
         dma_on = ch < NCH;
         const int e = VW * (dma_on ? ch : 0), r = e / FTW, c2 = e - r * FTW;
         goff = min(j0 - 1 + r, g.NJ - 1) * P + min(i0 - FXO + c2, P - VW);
 #pragma unroll
         for (int f = (FROM_WINDS ? 2 : 0); f < FNF; f++)
-            if (wave * 64 < MROWS(f) * CPR) n_issue++;
+            if ((((MV_T >> f) & 1u) != 0) == role_t && sl * 64 < MROWS(f) * CPR) n_issue++;
     }
     // a slice of a step-start tile = VW rows of OCPR chunks (16 B each, i0 is 16-B aligned): lane -> (row, column)
     const int orow = lane / OCPR, ocol = i0 + VW * (lane % OCPR);
-    constexpr int NOWN = mom_own_tiles(OLD_IS_CUR, WITH_TEMP);         // own-cell tiles: [u_old, v_old,] [POTTVB, [pott_old,]] [dPOTTdt_RAD]
+    constexpr int NOWN = mom_own_tiles(OLD_IS_CUR, WITH_TEMP);         // own-cell tiles: [u_old, v_old, pott_old,] [dPOTTdt_RAD]
     const int nown = (WITH_TEMP && !g.i_rad) ? NOWN - 1 : NOWN;        // ... the last one only with radiative heating
     if (WITH_TEMP) {            // the temperature wavefronts move them: slice s (of nown * ONSL) by wavefront TJ + s % TJ
         if (role_t)
@@ -589,20 +631,20 @@ __global__ __launch_bounds__(FTI *TJ *(WITH_TEMP ? 2 : 1), ((TJ <= 4 && !WITH_TE
 
     auto issue = [&](int k, int slot) {
         real *buf = dsm + slot * DSLOT;
-        if (wave < NSL) {
+        if (sl < NSL) {
             if (dma_on) {
 #pragma unroll
                 for (int f = (FROM_WINDS ? 2 : 0); f < FNF; f++) {
-                    if (ch < MROWS(f) * CPR) {
+                    if ((((MV_T >> f) & 1u) != 0) == role_t && ch < MROWS(f) * CPR) {
                         const real *gp = src[f] + (size_t)k * g.plane + goff;
-                        lds_dma16(gp, buf + MOFF(f) + wave * 64 * VW);
+                        lds_dma16(gp, buf + MOFF(f) + sl * 64 * VW);
                     }
                 }
             }
         }
         if (WITH_TEMP) {
             if (role_t) {
-                const real *own[5] = {OLD_IS_CUR ? p.POTTVB : u_old, OLD_IS_CUR ? p.dPOTTdt_RAD : v_old, p.POTTVB, ta.pott_old, p.dPOTTdt_RAD};
+                const real *own[4] = {OLD_IS_CUR ? p.dPOTTdt_RAD : u_old, v_old, ta.pott_old, p.dPOTTdt_RAD};
 #pragma unroll
                 for (int s5 = 0; s5 < NOWN * ONSL; s5++) {
                     if (s5 % TJ == wave - TJ && s5 < nown * ONSL) {
@@ -638,7 +680,7 @@ __global__ __launch_bounds__(FTI *TJ *(WITH_TEMP ? 2 : 1), ((TJ <= 4 && !WITH_TE
     // factors of the flux-tile entries this lane forms (FROM_WINDS), same element -> grid cell map as its DMA chunks
     // (the column pressures in registers, the metric factors dyis / dxjs in two LDS tiles: the register file is full)
     const int chf = ch;
-    const bool flux_lane = wave < NSL && dma_on;
+    const bool flux_lane = sl < NSL && dma_on && (role_t == FLUX_T);
     real f_uc[VW], f_vc[VW];
 #pragma unroll
     for (int d = 0; d < VW; d++) { f_uc[d] = 0.0; f_vc[d] = 0.0; }
@@ -694,25 +736,26 @@ __global__ __launch_bounds__(FTI *TJ *(WITH_TEMP ? 2 : 1), ((TJ <= 4 && !WITH_TE
         const real cnew = p.COLP_NEW[c];
         real colp = p.COLP[c], cold = p.COLP_OLD[c], c_im1 = p.COLP[c - 1], c_ip1 = p.COLP[c + 1], c_jm1 = p.COLP[c - P], c_jp1 = p.COLP[c + P];
         real hr_area = (real)(0.5 * (1.0 / p.A[c])), r_cnew = (real)(1.0 / cnew);
+        real rcolO = canon_rcol(colp);
         cdouble_t *c_sig = (cdouble_t *)p.sigma_vb, *c_rdst = (cdouble_t *)p.rdsigma, *c_tdif = (cdouble_t *)p.POTT_dif_coef;
         const size_t pl = (size_t)g.plane;
-        real p_kp12 = interface_pressure(g.pair_top, c_sig[nz], cnew);
-        real pvb_kp1 = exner_vb(p_kp12);
-        real phivb_kp1 = p.HSURF[c] * CON_G;
-        real w_kp1 = p.WWIND[c + (size_t)nz * pl], pvbo_kp1 = p.POTTVB[c + (size_t)nz * pl];
-        real pottn_kp1 = 0.0, pvtf_kp1 = 0.0, pottvb_first = 0.0;
-        real p_up = interface_pressure(g.pair_top, c_sig[nz - 1], cnew), pvb_up = exner_vb(p_up);
-        if (active) ta.pvb_out[c + (size_t)nz * pl] = pvb_kp1;
-        real o_pott = 0.0, o_pvb = 0.0, o_phi = 0.0, o_vb = 0.0, o_sfc = 0.0;       // outputs of the level, stored at its end
+        // the surface interface: Exner value of the new column (stored), of the old one (read: the lower interface of the
+        // bottom level).  No hydrostatic integration here: the momentum wavefronts of the NEXT substep carry it themselves
+        if (active) ta.pvb_out[c + (size_t)nz * pl] = canon_exner(canon_pk(g.pair_top, c_sig[nz], cnew));
+        real pvbO_kp1 = p.PVTFVB[c + (size_t)nz * pl];
+        double pkO_kp1 = canon_pk(g.pair_top, c_sig[nz], colp);
+        real pvtfO_kp1 = 0.0, pt_kp1 = 0.0, w_kp1 = 0.0, lp_kp2 = 0.0, tpart_kp1 = 0.0, po_kp1 = 0.0;
+        real o_pott = 0.0, o_pvb = 0.0;       // outputs stored at the end of a level: POTT of level k+1, PVTFVB at interface k
         {   // every value loaded above is complete before the level loop starts (see the momentum wavefronts)
-            asm volatile("" : "+v"(colp), "+v"(cold), "+v"(c_im1), "+v"(c_ip1), "+v"(c_jm1), "+v"(c_jp1), "+v"(hr_area), "+v"(r_cnew), "+v"(phivb_kp1), "+v"(w_kp1), "+v"(pvbo_kp1), "+v"(pvb_up));
+            asm volatile("" : "+v"(colp), "+v"(cold), "+v"(c_im1), "+v"(c_ip1), "+v"(c_jm1), "+v"(c_jp1), "+v"(hr_area), "+v"(r_cnew), "+v"(rcolO), "+v"(pvbO_kp1));
         }
-        constexpr int OWN_PVB = OFF_OLD + (OLD_IS_CUR ? 0 : 2) * ON, OWN_PO = OFF_OLD + 3 * ON, OWN_RAD = OFF_OLD + (NOWN - 1) * ON;
+        constexpr int OWN_PO = OFF_OLD + 2 * ON, OWN_RAD = OFF_OLD + (NOWN - 1) * ON;
         const bool has_rad = g.i_rad;
         issue(nz - 1, 0);
         if (nz >= 2) issue(nz - 2, 1);
         wait_vmcnt(nz >= 2 ? n_issue : 0);
-        lds_barrier();          // (the flux tiles of level nz-1: the momentum wavefronts)
+        if (FLUX_T) flux_own(0, (nz - 1) & 1);
+        lds_barrier();          // (the flux tiles of level nz-1: whichever role moves the winds)
         int slot = 0;
 #pragma unroll 1
         for (int k = nz - 1; k >= 0; k--) {
@@ -724,49 +767,43 @@ __global__ __launch_bounds__(FTI *TJ *(WITH_TEMP ? 2 : 1), ((TJ <= 4 && !WITH_TE
             const real *fb = dsm + NS * DSLOT + (k & 1) * FSLOT;
             if (active && DYC_MOM_MODE != 1 && DYC_WT_SKIP != 1) {
                 const real pt = SM(S_POTT, 0, 0);
-                real w_k = 0.0, pvbo_k = 0.0;
-                if (k > 0) { w_k = SM(S_W, 0, 0); pvbo_k = db[OWN_PVB + ty * FTI + tx]; }
+                const real w_k = k > 0 ? SM(S_W, 0, 0) : (real)0.0;
+                const real pvbO_k = SM(S_PVB, 0, 0);
                 const real po = OLD_IS_CUR ? pt : db[OWN_PO + ty * FTI + tx];
-                // tendency and Euler step on the re-formed mass-flux tiles (the values k_pott_fused re-forms itself)
-                TEMP_NEW_POTT(pott, colp, cnew, cold, c_im1, c_ip1, c_jm1, c_jp1, hr_area, r_cnew, SM(S_UF, 0, 0), SM(S_UF, 1, 0), SM(S_VF, 0, 0), SM(S_VF, 0, 1),
-                              pt, SM(S_POTT, -1, 0), SM(S_POTT, 1, 0), SM(S_POTT, 0, -1), SM(S_POTT, 0, 1),
-                              w_k, pvbo_k, w_kp1, pvbo_kp1, c_rdst[k], c_tdif[k], false, (real)0.0,
-                              has_rad, db[OWN_RAD + ty * FTI + tx], po, dt)
-                // diagnostics of the new column, level k (k_pott_fused: the pow of the next interface one level ahead)
-                const DiagLevel dl = diag_level_pre(p_up, pvb_up, pott, p_kp12, pvb_kp1, phivb_kp1);
-                if (k > 0) {
-                    p_up = interface_pressure(g.pair_top, c_sig[k - 1], cnew);
-                    pvb_up = exner_vb(p_up);
-                }
-                real vb = 0.0;
+                // old column: Exner value of this level, POTTVB at its lower interface k+1 -- which closes level k+1
+                // (k_temp_canon: the same calls, the same bits)
+                const double pkO_k = canon_pk(g.pair_top, c_sig[k], colp);
+                const real pvtfO_k = canon_pvtf(pvbO_kp1, pkO_kp1, pvbO_k, pkO_k, rcolO, c_rdst[k]);
+                real lp_kp1 = 0.0;
                 if (k < nz - 1) {
-                    vb = pottvb_between(pvb_kp1, dl.pvtf, pott, pvtf_kp1, pottn_kp1);
-                    if (k == nz - 2) o_sfc = pottn_kp1 - (vb - pottn_kp1);      // dyn_diagnostics.py:191-194, from the level below
-                    if (k == 0) pottvb_first = vb;
+                    const real vb = pottvb_between(pvbO_kp1, pvtfO_k, pt, pvtfO_kp1, pt_kp1);
+                    TEMP_CLOSE(pottn, tpart_kp1, cnew, cold, r_cnew, w_kp1, vb, lp_kp2, c_rdst[k + 1], po_kp1, dt)
+                    o_pott = pottn;
+                    lp_kp1 = mul_rn(w_kp1, vb);
                 }
-                o_pott = pott; o_pvb = dl.pvb_k; o_phi = dl.phi; o_vb = vb;
-                p_kp12 = dl.p_km12; pvb_kp1 = dl.pvb_k; phivb_kp1 = dl.phivb;
-                pottn_kp1 = pott; pvtf_kp1 = dl.pvtf;
-                w_kp1 = w_k; pvbo_kp1 = pvbo_k;
+                // tendency of level k on the re-formed mass-flux tiles, without the vertical advection
+                TEMP_PARTIAL(tpart, colp, c_im1, c_ip1, c_jm1, c_jp1, hr_area, SM(S_UF, 0, 0), SM(S_UF, 1, 0), SM(S_VF, 0, 0), SM(S_VF, 0, 1),
+                             pt, SM(S_POTT, -1, 0), SM(S_POTT, 1, 0), SM(S_POTT, 0, -1), SM(S_POTT, 0, 1), c_tdif[k], has_rad, db[OWN_RAD + ty * FTI + tx])
+                o_pvb = canon_exner(canon_pk(g.pair_top, c_sig[k], cnew));
+                pvbO_kp1 = pvbO_k; pkO_kp1 = pkO_k; pvtfO_kp1 = pvtfO_k; pt_kp1 = pt; w_kp1 = w_k;
+                lp_kp2 = lp_kp1; tpart_kp1 = tpart; po_kp1 = po;
             }
             TRACE_PT(k, 2);
             // Everything this wavefront sends to memory goes out HERE, at the end of the level: the momentum wavefronts' burst
             // of DMA and stores at the top of a level fills the queues, and a vector-memory instruction that finds them full
             // blocks its wavefront (timeline in profiles/r02_notes.md: 750 ticks per level with the stores and the DMA at the
             // top, 80 now).  Its own-cell tiles of level k-1 went out one level ago, behind that level's stores: vmcnt(0).
-            if (k - 1 >= 0 && DYC_MOM_MODE != 2) wait_vmcnt(0);
+            if (k - 1 >= 0 && DYC_MOM_MODE != 2) {
+                wait_vmcnt(0);
+                if (FLUX_T) flux_own(slot1, (k - 1) & 1);      // the winds of level k-1 are among what it moved: their flux entries
+            }
             TRACE_PT(k, 5);
-            // ---- the outputs of level k: a whole level to retire before the next wait ----
+            // ---- the outputs of this iteration: a whole level to retire before the next wait ----
             asm volatile("" ::: "memory");
             if (active) {
                 const size_t q0 = c + (size_t)k * pl;
-                __builtin_nontemporal_store(o_pott, ta.pott_out + q0);
+                if (k < nz - 1) __builtin_nontemporal_store(o_pott, ta.pott_out + q0 + pl);
                 __builtin_nontemporal_store(o_pvb, ta.pvb_out + q0);
-                __builtin_nontemporal_store(o_phi, ta.phi_out + q0);
-                if (k < nz - 1) {
-                    __builtin_nontemporal_store(o_vb, p.POTTVB + q0 + pl);
-                    if (k == nz - 2 && nz > 2) __builtin_nontemporal_store(o_sfc, p.POTTVB + c + (size_t)nz * pl);   // surface extrapolation
-                }
             }
             asm volatile("" ::: "memory");
             if (k - 2 >= 0 && DYC_MOM_MODE != 2) issue(k - 2, (slot + 2) % NS);        // its own-cell tiles of level k-2
@@ -774,7 +811,10 @@ __global__ __launch_bounds__(FTI *TJ *(WITH_TEMP ? 2 : 1), ((TJ <= 4 && !WITH_TE
             lds_barrier();
             slot = slot1;
         }
-        if (active && nz >= 2) __builtin_nontemporal_store(pottn_kp1 - (pottvb_first - pottn_kp1), p.POTTVB + c);      // the model top
+        if (active) {           // the top level: its upper interface is the model top (sigma-dot = 0)
+            TEMP_CLOSE(pott0, tpart_kp1, cnew, cold, r_cnew, (real)0.0, (real)0.0, lp_kp2, c_rdst[0], po_kp1, dt)
+            __builtin_nontemporal_store(pott0, ta.pott_out + c);
+        }
         return;
     }
     // =====================================================================================================
@@ -863,7 +903,7 @@ __global__ __launch_bounds__(FTI *TJ *(WITH_TEMP ? 2 : 1), ((TJ <= 4 && !WITH_TE
     // X_old * eu1 + dX * eu2 with eu1 = P_old * (1 / P), eu2 = dt * (1 / P) per column
     const real eu1 = cao_is * (1.0 / ca_is), eu2 = dt * (1.0 / ca_is), ev1 = cao_js * (1.0 / ca_js), ev2 = dt * (1.0 / ca_js);
     // PVTF in the thread (FROM_WINDS): 1 / ((1 + kappa) COLP) at the own cell and its western / southern neighbour
-    const real rcp_c = 1.0 / ((1.0 + CON_KAPPA) * colp), rcp_im1 = 1.0 / ((1.0 + CON_KAPPA) * colp_im1), rcp_jm1 = 1.0 / ((1.0 + CON_KAPPA) * colp_jm1);
+    const real rcp_c = canon_rcol(colp), rcp_im1 = canon_rcol(colp_im1), rcp_jm1 = canon_rcol(colp_jm1);
 
     // carried across levels.  The column is walked BOTTOM-UP (level k1-1 first), the direction of the hydrostatic
     // integration, so that PHI can be carried along (PHI_LOCAL); the vertical advection of a level is closed one
@@ -901,7 +941,7 @@ __global__ __launch_bounds__(FTI *TJ *(WITH_TEMP ? 2 : 1), ((TJ <= 4 && !WITH_TE
     if (AHEAD >= 3 && k1 - 3 >= k0) issue(k1 - 3, 2);
     real tbu_nx = 0.0, tbv_nx = 0.0;  // turbulent tendencies of the next level
     if (TURB) { tbu_nx = p.TURB_U[c + (size_t)(k1 - 1) * g.plane]; tbv_nx = v_on ? p.TURB_V[c + (size_t)(k1 - 1) * g.plane] : 0.0; }
-    wait_vmcnt((AHEAD >= 2 && k1 - AHEAD >= k0) ? n_issue : 0);        // everything but the last level issued has landed
+    if (n_issue > 0) wait_vmcnt((AHEAD >= 2 && k1 - AHEAD >= k0) ? n_issue : 0);        // everything but the last level issued has landed
     flux_own(0, (k1 - 1) & 1);
     lds_barrier();
     int slot = 0;                       // ring slot of level k
@@ -1006,14 +1046,10 @@ __global__ __launch_bounds__(FTI *TJ *(WITH_TEMP ? 2 : 1), ((TJ <= 4 && !WITH_TE
             const real pvb_k = SM(S_PVB, 0, 0), pvb_im1_k = SM(S_PVB, -1, 0), pvb_jm1_k = SM(S_PVB, 0, -1);
             const real pott = SM(S_POTT, 0, 0), pott_im1 = SM(S_POTT, -1, 0), pott_jm1 = SM(S_POTT, 0, -1);
             real pvtf, pvtf_im1, pvtf_jm1;
-            if (FROM_WINDS) {
-                // (double intermediates: the difference of the two products cancels five digits; a no-op in the double build)
-                const double pk_c = (double)g.pair_top + (double)svb * colp, pk1_c = (double)g.pair_top + (double)svb1 * colp;
-                const double pk_w = (double)g.pair_top + (double)svb * colp_im1, pk1_w = (double)g.pair_top + (double)svb1 * colp_im1;
-                const double pk_s = (double)g.pair_top + (double)svb * colp_jm1, pk1_s = (double)g.pair_top + (double)svb1 * colp_jm1;
-                pvtf = (pvb_kp1 * pk1_c - pvb_k * pk_c) * (rcp_c * rds);
-                pvtf_im1 = (pvb_im1_kp1 * pk1_w - pvb_im1_k * pk_w) * (rcp_im1 * rds);
-                pvtf_jm1 = (pvb_jm1_kp1 * pk1_s - pvb_jm1_k * pk_s) * (rcp_jm1 * rds);
+            if (FROM_WINDS) {       // the canonical forms (kernels_stage.h): the same bits in every kernel, chunk and band
+                pvtf = canon_pvtf(pvb_kp1, canon_pk(g.pair_top, svb1, colp), pvb_k, canon_pk(g.pair_top, svb, colp), rcp_c, rds);
+                pvtf_im1 = canon_pvtf(pvb_im1_kp1, canon_pk(g.pair_top, svb1, colp_im1), pvb_im1_k, canon_pk(g.pair_top, svb, colp_im1), rcp_im1, rds);
+                pvtf_jm1 = canon_pvtf(pvb_jm1_kp1, canon_pk(g.pair_top, svb1, colp_jm1), pvb_jm1_k, canon_pk(g.pair_top, svb, colp_jm1), rcp_jm1, rds);
             } else {
                 pvtf = SM(S_PVTF, 0, 0); pvtf_im1 = SM(S_PVTF, -1, 0); pvtf_jm1 = SM(S_PVTF, 0, -1);
             }
@@ -1023,12 +1059,12 @@ __global__ __launch_bounds__(FTI *TJ *(WITH_TEMP ? 2 : 1), ((TJ <= 4 && !WITH_TE
             // the expressions of diag_level_pre on the thread's own PVTF
             real phi, phi_im1, phi_jm1;
             if (PHI_LOCAL) {
-                phi = phivb_c - CON_CP * (pott * (pvtf - pvb_kp1));
-                phi_im1 = phivb_w - CON_CP * (pott_im1 * (pvtf_im1 - pvb_im1_kp1));
-                phi_jm1 = phivb_s - CON_CP * (pott_jm1 * (pvtf_jm1 - pvb_jm1_kp1));
-                phivb_c = phi - CON_CP * (pott * (pvb_k - pvtf));
-                phivb_w = phi_im1 - CON_CP * (pott_im1 * (pvb_im1_k - pvtf_im1));
-                phivb_s = phi_jm1 - CON_CP * (pott_jm1 * (pvb_jm1_k - pvtf_jm1));
+                phi = canon_phi(phivb_c, pott, pvtf, pvb_kp1);
+                phi_im1 = canon_phi(phivb_w, pott_im1, pvtf_im1, pvb_im1_kp1);
+                phi_jm1 = canon_phi(phivb_s, pott_jm1, pvtf_jm1, pvb_jm1_kp1);
+                phivb_c = canon_phivb(phi, pott, pvb_k, pvtf);
+                phivb_w = canon_phivb(phi_im1, pott_im1, pvb_im1_k, pvtf_im1);
+                phivb_s = canon_phivb(phi_jm1, pott_jm1, pvb_jm1_k, pvtf_jm1);
             } else {
                 phi = SM(S_PHI, 0, 0); phi_im1 = SM(S_PHI, -1, 0); phi_jm1 = SM(S_PHI, 0, -1);
             }
@@ -1098,7 +1134,7 @@ __global__ __launch_bounds__(FTI *TJ *(WITH_TEMP ? 2 : 1), ((TJ <= 4 && !WITH_TE
         if (WITH_TEMP) TRACE_PT(k, 2);
         // this wave's part of level k-1 has landed (the deeper prefetch stays in flight); form its flux entries
         if (k - 1 >= k0 && DYC_MOM_MODE != 2) {
-            wait_vmcnt((DEPTH == 2 && k - AHEAD >= k0) ? n_issue : 0);        // level k - AHEAD + 1 has landed
+            if (n_issue > 0) wait_vmcnt((DEPTH == 2 && k - AHEAD >= k0) ? n_issue : 0);        // level k - AHEAD + 1 has landed (a wavefront that moves nothing does not wait for its stores either)
             if (WITH_TEMP) TRACE_PT(k, 5);
             flux_own(slot1, (k - 1) & 1);
         }
@@ -1318,13 +1354,27 @@ __global__ __launch_bounds__(TI *TJ) void k_derive_flxdiv(Geo g, Ptrs p)
     }
 }
 // PVTF (dyn_diagnostics.py:146-153) from PVTFVB and COLP: whole array including halos, the expression of diag_level_pre
-__global__ __launch_bounds__(TI *TJ) void k_derive_pvtf(Geo g, Ptrs p)
+// (`canon`: the canonical form the production step evaluates in its threads, kernels_stage.h)
+__global__ __launch_bounds__(TI *TJ) void k_derive_pvtf(Geo g, Ptrs p, int canon)
 {
 #pragma clang fp contract(off)
     DYC_IJ(0, 0)
     if (i > g.nx + 1 || j > g.ny + 1) return;
     const size_t c = at2(g, i, j);
     const real colp = p.COLP[c];
+    if (canon) {
+        const real rcol = canon_rcol(colp);
+        double pk = canon_pk(g.pair_top, p.sigma_vb[0], colp);
+        real pvb_k = p.PVTFVB[c];
+        for (int k = 0; k < g.nz; k++) {
+            const size_t q = c + (size_t)k * g.plane;
+            const double pk1 = canon_pk(g.pair_top, p.sigma_vb[k + 1], colp);
+            const real pvb_kp1 = p.PVTFVB[q + g.plane];
+            p.PVTF[q] = canon_pvtf(pvb_kp1, pk1, pvb_k, pk, rcol, p.rdsigma[k]);
+            pk = pk1; pvb_k = pvb_kp1;
+        }
+        return;
+    }
     real p_km12 = interface_pressure(g.pair_top, p.sigma_vb[0], colp), pvb_k = p.PVTFVB[c];
     for (int k = 0; k < g.nz; k++) {
         const size_t q = c + (size_t)k * g.plane;
@@ -1333,18 +1383,63 @@ __global__ __launch_bounds__(TI *TJ) void k_derive_pvtf(Geo g, Ptrs p)
         p_km12 = p_kp12; pvb_k = pvb_kp1;
     }
 }
+// POTTVB (dyn_diagnostics.py:179-195) from POTT, PVTFVB and COLP: whole array including halos, for a handle whose step does
+// not store it (k_temp_canon / the whole-substep kernel form the interface values they need in the thread, with these calls)
+__global__ __launch_bounds__(TI *TJ) void k_derive_pottvb(Geo g, Ptrs p)
+{
+    DYC_IJ(0, 0)
+    if (i > g.nx + 1 || j > g.ny + 1) return;
+    const size_t c = at2(g, i, j);
+    const int nz = g.nz;
+    const real colp = p.COLP[c], rcol = canon_rcol(colp);
+    double pk1 = canon_pk(g.pair_top, p.sigma_vb[nz], colp);
+    real pvb_kp1 = p.PVTFVB[c + (size_t)nz * g.plane];
+    real pott_kp1 = 0.0, pvtf_kp1 = 0.0, first = 0.0;
+    for (int k = nz - 1; k >= 0; k--) {
+        const size_t q = c + (size_t)k * g.plane;
+        const double pk = canon_pk(g.pair_top, p.sigma_vb[k], colp);
+        const real pvb_k = p.PVTFVB[q], pott = p.POTT[q];
+        const real pvtf = canon_pvtf(pvb_kp1, pk1, pvb_k, pk, rcol, p.rdsigma[k]);
+        if (k < nz - 1) {
+            const real vb = pottvb_between(pvb_kp1, pvtf, pott, pvtf_kp1, pott_kp1);
+            p.POTTVB[q + g.plane] = vb;
+            if (k == nz - 2 && nz > 2) p.POTTVB[c + (size_t)nz * g.plane] = pott_kp1 - (vb - pott_kp1);     // surface, dyn_diagnostics.py:191-194
+            if (k == 0) first = vb;
+        }
+        pk1 = pk; pvb_kp1 = pvb_k; pott_kp1 = pott; pvtf_kp1 = pvtf;
+    }
+    if (nz >= 2) p.POTTVB[c] = pott_kp1 - (first - pott_kp1);       // model top, :187-190
+}
 // PHI and PHIVB (dyn_diagnostics.py:160-174) from POTT, PVTFVB, COLP and HSURF: whole array including halos, the
-// expressions of diag_level_pre on the stored PVTFVB -- the bits k_pott_fused would have stored
-__global__ __launch_bounds__(TI *TJ) void k_derive_phi(Geo g, Ptrs p)
+// expressions of diag_level_pre on the stored PVTFVB -- the bits k_pott_fused would have stored; `canon`: the canonical
+// forms, i.e. the values the momentum kernel of the production step carries in its threads
+__global__ __launch_bounds__(TI *TJ) void k_derive_phi(Geo g, Ptrs p, int canon)
 {
     DYC_IJ(0, 0)
     if (i > g.nx + 1 || j > g.ny + 1) return;
     const size_t c = at2(g, i, j);
     const int nz = g.nz;
     const real colp = p.COLP[c];
-    real p_kp12 = interface_pressure(g.pair_top, p.sigma_vb[nz], colp), pvb_kp1 = p.PVTFVB[c + (size_t)nz * g.plane];
     real phivb_kp1 = p.HSURF[c] * CON_G;
     p.PHIVB[c + (size_t)nz * g.plane] = phivb_kp1;
+    if (canon) {
+        const real rcol = canon_rcol(colp);
+        double pk1 = canon_pk(g.pair_top, p.sigma_vb[nz], colp);
+        real pvb_kp1 = p.PVTFVB[c + (size_t)nz * g.plane];
+        for (int k = nz - 1; k >= 0; k--) {
+            const size_t q = c + (size_t)k * g.plane;
+            const double pk = canon_pk(g.pair_top, p.sigma_vb[k], colp);
+            const real pvb_k = p.PVTFVB[q], pott = p.POTT[q];
+            const real pvtf = canon_pvtf(pvb_kp1, pk1, pvb_k, pk, rcol, p.rdsigma[k]);
+            const real phi = canon_phi(phivb_kp1, pott, pvtf, pvb_kp1);
+            phivb_kp1 = canon_phivb(phi, pott, pvb_k, pvtf);
+            p.PHI[q] = phi;
+            p.PHIVB[q] = phivb_kp1;
+            pk1 = pk; pvb_kp1 = pvb_k;
+        }
+        return;
+    }
+    real p_kp12 = interface_pressure(g.pair_top, p.sigma_vb[nz], colp), pvb_kp1 = p.PVTFVB[c + (size_t)nz * g.plane];
     for (int k = nz - 1; k >= 0; k--) {
         const size_t q = c + (size_t)k * g.plane;
         const DiagLevel dl = diag_level_pre(interface_pressure(g.pair_top, p.sigma_vb[k], colp), p.PVTFVB[q], p.POTT[q], p_kp12, pvb_kp1, phivb_kp1);
@@ -1487,6 +1582,109 @@ __global__ __launch_bounds__(TI *TJ) void k_pott_fused(Geo g, Ptrs p, const real
     }
     if (k == 0) level(0, A);
     if (nz >= 2) stb(p.POTTVB, bc, pottn_kp1 - (pottvb_first - pottn_kp1));
+}
+
+
+// ------------------------------------------------------------------------------------
+// k_temp_canon: the temperature kernel of the production dry / moist step (latitude bands; one GPU with
+// DYCORE_STEP_FUSED=0): dPOTTdt (dyn_POTT.py:180-216) + Euler step of POTT (dyn_timestep.py:70-79) + the Exner function
+// of the new column (dyn_diagnostics.py:139-156) in one bottom-up sweep.  Against k_pott_fused it moves two fields less:
+//   * POTTVB is neither read nor written: the interface values of the state the tendency is taken at are formed in the
+//     thread from POTT and PVTFVB of the two adjacent levels (canon_pvtf, pottvb_between) -- PVTFVB is read at the own
+//     cell where POTTVB was (and updated in place behind the read), so -1 write;
+//   * PHI is not written: the momentum kernel carries the hydrostatic integration in its threads (PHI_LOCAL).  Its level
+//     chunks start from the PHIVB planes stored here at every PHIVB_STRIDE-th interface (1/4 of a pass), computed with
+//     the same canonical forms, so that a chunk continues the chunk below it bit for bit.
+// 5 reads (+1 in the corrector) + 2 1/4 writes.  POTTVB, PHI, PHIVB, PVTF of the new state are derived on demand
+// (k_derive_*).  A level is closed one iteration late (TEMP_PARTIAL / TEMP_CLOSE above).
+__global__ __launch_bounds__(TI *TJ) void k_temp_canon(Geo g, Ptrs p, const real *pott_old, real *pott_out, real dt, int lin)
+{
+    int i, j;
+    if (!owned_cell(g, lin, i, j)) return;
+    const int P = g.P, nz = g.nz;
+    const size_t c = at2(g, i, j);
+    const unsigned bc = (unsigned)(c * sizeof(real)), bpl = (unsigned)(g.plane * sizeof(real)), bP = (unsigned)(P * sizeof(real));
+    const real colp = p.COLP[c], cnew = p.COLP_NEW[c], cold = p.COLP_OLD[c];
+    const real c_im1 = p.COLP[c - 1], c_ip1 = p.COLP[c + 1], c_jm1 = p.COLP[c - P], c_jp1 = p.COLP[c + P];
+    const real hr_area = (real)(0.5 * (1.0 / p.A[c])), r_cnew = (real)(1.0 / cnew);
+    const real rcolO = canon_rcol(colp), rcolN = canon_rcol(cnew);
+    const real m_dy0 = p.dyis[c], m_dy1 = p.dyis[c + 1], m_dx0 = p.dxjs[c], m_dx1 = p.dxjs[c + P];
+    // per-level constants through the constant address space: scalar loads.  As plain loads next to the kernel's stores
+    // they compile to VECTOR loads, each followed by s_waitcnt vmcnt(0) -- which drains the level prefetched ahead
+    typedef const __attribute__((address_space(4))) real cdouble_t;
+    cdouble_t *c_sig = (cdouble_t *)p.sigma_vb, *c_rds = (cdouble_t *)p.rdsigma, *c_dif = (cdouble_t *)p.POTT_dif_coef;
+    // the surface interface: new column (written), old column (read first: PVTFVB is updated in place, own cell only)
+    double pkN_kp1 = canon_pk(g.pair_top, c_sig[nz], cnew), pkN_kp2 = 0.0;
+    real pvbN_kp1 = canon_exner(pkN_kp1), pvbN_kp2 = 0.0;
+    real phivbN_kp1 = p.HSURF[c] * CON_G, phivbN_kp2 = 0.0;
+    real pvbO_kp1 = ldn(p.PVTFVB, bc + (unsigned)nz * bpl);
+    double pkO_kp1 = canon_pk(g.pair_top, c_sig[nz], colp);
+    stb(p.PVTFVB, bc + (unsigned)nz * bpl, pvbN_kp1);
+    real pvtfO_kp1 = 0.0, pt_kp1 = 0.0, w_kp1 = 0.0, lp_kp2 = 0.0, tpart_kp1 = 0.0, po_kp1 = 0.0;
+    struct In { real pt, im1, ip1, jm1, jp1, uf, uf1, vf, vf1, w, pvb, po; };
+    auto load = [&](int k, In &r) {
+        const unsigned q = bc + (unsigned)k * bpl;
+        r.pt = ldb(p.POTT, q); r.im1 = ldb(p.POTT, q - (unsigned)sizeof(real)); r.ip1 = ldb(p.POTT, q + (unsigned)sizeof(real));
+        r.jm1 = ldb(p.POTT, q - bP); r.jp1 = ldb(p.POTT, q + bP);
+        r.uf = ldb(p.UWIND, q); r.uf1 = ldb(p.UWIND, q + (unsigned)sizeof(real)); r.vf = ldb(p.VWIND, q); r.vf1 = ldb(p.VWIND, q + bP);
+        r.w = ldn(p.WWIND, q); r.pvb = ldn(p.PVTFVB, q); r.po = ldn(pott_old, q);
+    };
+    auto level = [&](int k, In &cur) {
+        const unsigned q = bc + (unsigned)k * bpl;
+        // the mass fluxes, dyn_continuity.py:40-45, operand order of k_continuity_reg
+        cur.uf = (c_im1 + colp) / 2.0 * cur.uf * m_dy0;
+        cur.uf1 = (colp + c_ip1) / 2.0 * cur.uf1 * m_dy1;
+        cur.vf = (c_jm1 + colp) / 2.0 * cur.vf * m_dx0;
+        cur.vf1 = (colp + c_jp1) / 2.0 * cur.vf1 * m_dx1;
+        // old column: Exner value of this level, POTTVB at its lower interface k+1 -- which closes level k+1
+        const double pkO_k = canon_pk(g.pair_top, c_sig[k], colp);
+        const real pvtfO_k = canon_pvtf(pvbO_kp1, pkO_kp1, cur.pvb, pkO_k, rcolO, c_rds[k]);
+        real lp_kp1 = 0.0;          // sigma-dot = 0 at the surface
+        if (k < nz - 1) {
+#if DYC_EXP_TEMP == 2
+            const real vb = cur.pt + pvtfO_k;
+#else
+            const real vb = pottvb_between(pvbO_kp1, pvtfO_k, cur.pt, pvtfO_kp1, pt_kp1);
+#endif
+            TEMP_CLOSE(pottn, tpart_kp1, cnew, cold, r_cnew, w_kp1, vb, lp_kp2, c_rds[k + 1], po_kp1, dt)
+            stb(pott_out, q + bpl, pottn);
+            lp_kp1 = mul_rn(w_kp1, vb);
+            // hydrostatic integration of the new column through level k+1; PHIVB at interface k+1
+#if DYC_EXP_TEMP != 1
+            const real pvtfN = canon_pvtf(pvbN_kp2, pkN_kp2, pvbN_kp1, pkN_kp1, rcolN, c_rds[k + 1]);
+            phivbN_kp1 = canon_phivb(canon_phi(phivbN_kp2, pottn, pvtfN, pvbN_kp2), pottn, pvbN_kp1, pvtfN);
+            if ((k + 1) % PHIVB_STRIDE == 0) stb(p.PHIVB, q + bpl, phivbN_kp1);
+#endif
+        }
+        TEMP_PARTIAL(tpart, colp, c_im1, c_ip1, c_jm1, c_jp1, hr_area, cur.uf, cur.uf1, cur.vf, cur.vf1, cur.pt, cur.im1, cur.ip1, cur.jm1, cur.jp1,
+                     c_dif[k], g.i_rad, ldb(p.dPOTTdt_RAD, q))
+        // Exner function of the new column at interface k
+        const double pkN_k = canon_pk(g.pair_top, c_sig[k], cnew);
+#if DYC_EXP_TEMP == 3
+        const real pvbN_k = (real)pkN_k;
+#else
+        const real pvbN_k = canon_exner(pkN_k);
+#endif
+        stb(p.PVTFVB, q, pvbN_k);
+        pvbO_kp1 = cur.pvb; pkO_kp1 = pkO_k; pvtfO_kp1 = pvtfO_k; pt_kp1 = cur.pt;
+        w_kp1 = k > 0 ? cur.w : (real)0.0;
+        lp_kp2 = lp_kp1; tpart_kp1 = tpart; po_kp1 = cur.po;
+        pvbN_kp2 = pvbN_kp1; pkN_kp2 = pkN_kp1; pvbN_kp1 = pvbN_k; pkN_kp1 = pkN_k; phivbN_kp2 = phivbN_kp1;
+    };
+    In A, B;
+    load(nz - 1, A);
+    int k = nz - 1;
+#pragma unroll 1
+    for (; k >= 1; k -= 2) {
+        load(k - 1, B);
+        level(k, A);
+        if (k >= 2) load(k - 2, A);
+        level(k - 1, B);
+    }
+    if (k == 0) level(0, A);
+    // the top level: its upper interface is the model top (sigma-dot = 0)
+    TEMP_CLOSE(pott0, tpart_kp1, cnew, cold, r_cnew, (real)0.0, (real)0.0, lp_kp2, c_rds[0], po_kp1, dt)
+    stb(pott_out, bc, pott0);
 }
 
 }  // namespace dyc

@@ -819,6 +819,42 @@ __device__ __forceinline__ DiagLevel diag_level(real pair_top, real svb_k, real 
     const real p_km12 = interface_pressure(pair_top, svb_k, colp);
     return diag_level_pre(p_km12, exner_vb(p_km12), pott, p_kp12, pvb_kp1, phivb_kp1);
 }
+// ---- the diagnostics as the FUSED step evaluates them ("canonical" forms) --------------------------------------------
+// The fused step stores neither PVTF nor PHI: the momentum kernel forms both in the thread, for its own column and its
+// western and southern neighbour, from PVTFVB, POTT, the column pressure and the surface geopotential; the temperature
+// kernel forms them for the new column where a level chunk of the momentum kernel needs a stored PHIVB to start from.
+// Different kernels, tiles, level chunks and latitude bands must get the SAME bits for the same cell (a chunk continues
+// the hydrostatic integration of the chunk below it from a stored plane, a band that of the single-domain run), so
+// every rounding is written out here and every kernel calls these functions.
+//   PVTF (dyn_diagnostics.py:146-153): the reference divides by (1 + kappa)(p[k+1] - p[k]); p[k+1] - p[k] is dsigma[k] COLP, so
+//   the quotient is a product with rr = (1 / ((1 + kappa) COLP)) (1 / dsigma[k]) -- one division per column instead of one
+//   per level and cell; it differs from the reference's quotient by the rounding of p[k+1] - p[k] (~4e-15 relative).
+//   (double intermediates: the difference of the two products cancels five digits; a no-op in the double build)
+__device__ __forceinline__ double canon_pk(real pair_top, real svb, real colp)
+{
+#pragma clang fp contract(off)
+    return (double)pair_top + (double)svb * (double)colp;       // dyn_diagnostics.py:146, two roundings as written there
+}
+__device__ __forceinline__ real canon_rcol(real colp) { return (real)(1.0 / ((1.0 + (double)CON_KAPPA) * (double)colp)); }
+__device__ __forceinline__ real canon_pvtf(real pvb_kp1, double p_kp1, real pvb_k, double p_k, real rcol, real rds)
+{
+#pragma clang fp contract(off)
+    const double lo = (double)pvb_k * p_k;
+    return (real)(fma((double)pvb_kp1, p_kp1, -lo) * ((double)rcol * (double)rds));
+}
+// Exner function at an interface from its (double) pressure
+__device__ __forceinline__ real canon_exner(double pk) { return (real)exner_pow(pk); }
+// hydrostatic integration, dyn_diagnostics.py:160-174: PHI[k] from PHIVB[k+1], PHIVB[k] from PHI[k]
+__device__ __forceinline__ real canon_phi(real phivb_kp1, real pott, real pvtf, real pvb_kp1)
+{
+#pragma clang fp contract(off)
+    return phivb_kp1 - CON_CP * (pott * (pvtf - pvb_kp1));
+}
+__device__ __forceinline__ real canon_phivb(real phi, real pott, real pvb_k, real pvtf)
+{
+#pragma clang fp contract(off)
+    return phi - CON_CP * (pott * (pvb_k - pvtf));
+}
 // interface value between levels k and k+1, dyn_diagnostics.py:183-186
 __device__ __forceinline__ real pottvb_between(real pvb_kp1, real pvtf, real pott, real pvtf_kp1, real pott_kp1)
 {
@@ -872,29 +908,6 @@ __global__ __launch_bounds__(TI *TJ) void k_primary_diag(Geo g, Ptrs p)
     DYC_IJ(0, 0)
     if (i > g.nx + 1 || j > g.ny + 1) return;
     diag_column(g, p, i, j);
-}
-
-// the same on two rows only: the halo rows a latitude band receives from its neighbours.  The two rows
-// are ~3000 columns, each a serial bottom-up recurrence: to keep the launch short (it sits between the
-// arrival of the rows and the momentum tiles that need them), a workgroup of 64 columns first evaluates
-// the Exner function of all its (column, interface) pairs in parallel (4 waves) and only then walks up
-// the columns with those values taken from LDS.  Same helper functions, same bits as diag_column.
-__global__ __launch_bounds__(256) void k_primary_diag_rows(Geo g, Ptrs p, int row_a, int row_b)
-{
-    extern __shared__ real s_pvb[];                   // [nz + 1][64]
-    const int i0 = blockIdx.x * 64;
-    const int j = blockIdx.y == 0 ? row_a : row_b;
-    if (j < 0) return;
-    const int nz = g.nz;
-    for (int t = threadIdx.x; t < 64 * (nz + 1); t += 256) {
-        const int k = t / 64, li = t - k * 64, i = i0 + li;
-        if (i <= g.nx + 1)
-            s_pvb[t] = exner_vb(interface_pressure(g.pair_top, p.sigma_vb[k], p.COLP[at2(g, i, j)]));
-    }
-    __syncthreads();
-    const int i = i0 + threadIdx.x;
-    if (threadIdx.x >= 64 || i > g.nx + 1) return;
-    diag_column(g, p, i, j, s_pvb + threadIdx.x, 64);
 }
 
 // secondary diagnostics, RHO / RHOVB only: dyn_diagnostics.py:199-222
@@ -1095,13 +1108,14 @@ __global__ void k_to_host(Geo g, const real *__restrict__ src, real *__restrict_
     }
 }
 // ---- halo rows of a latitude band <-> contiguous message buffer (multi-GPU) -------------
-// One launch moves up to 12 (field,row) pairs: entry e copies the nk[e] levels of row
+// One launch moves up to 24 (field,row) pairs: entry e copies the nk[e] levels of row
 // row[e], columns 0..nx+2, to/from buf + off[e].
-constexpr int ROWLIST_MAX = 12;
+// (k0, kstep: the levels k0, k0 + kstep, ... -- the PHIVB planes at every PHIVB_STRIDE-th interface travel this way)
+constexpr int ROWLIST_MAX = 24;
 struct RowList {
     int n;
     real *base[ROWLIST_MAX];
-    int row[ROWLIST_MAX], nk[ROWLIST_MAX];
+    int row[ROWLIST_MAX], nk[ROWLIST_MAX], k0[ROWLIST_MAX], kstep[ROWLIST_MAX];
     long long off[ROWLIST_MAX];
 };
 __global__ void k_rows(Geo g, RowList rl, real *buf, int unpack)
@@ -1109,7 +1123,7 @@ __global__ void k_rows(Geo g, RowList rl, real *buf, int unpack)
     const int e = blockIdx.z, k = blockIdx.y;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= rl.n || k >= rl.nk[e] || i > g.nx + 2) return;
-    real *f = rl.base[e] + (size_t)k * g.plane + (size_t)rl.row[e] * g.P;
+    real *f = rl.base[e] + (size_t)(rl.k0[e] + k * rl.kstep[e]) * g.plane + (size_t)rl.row[e] * g.P;
     real *b = buf + rl.off[e] + (size_t)k * (g.nx + 3) + i;
     if (unpack) { f[i] = *b; return; }
     // a packed row carries the periodic images of its interior columns (misc_boundaries.py:22-31), so a

@@ -37,7 +37,7 @@ ABI_SYMBOLS = [
     'dycore_secondary_diag_rho', 'dycore_secondary_diag', 'dycore_compute_turbulence', 'dycore_radiation',
     'dycore_step_matsuno', 'dycore_time_steps',
     'dycore_step_begin', 'dycore_substep_part', 'dycore_use_stream', 'dycore_get_stream', 'dycore_overlap_parts', 'dycore_flux_from_winds', 'dycore_rows_size', 'dycore_pack_rows',
-    'dycore_unpack_rows', 'dycore_substep_field',
+    'dycore_unpack_rows', 'dycore_substep_field', 'dycore_band_row_fields',
     'dycore_profile', 'dycore_n_kernels', 'dycore_kernel_stats',
     'dycore_bands_unique_id', 'dycore_bands_create_rccl', 'dycore_bands_create_local', 'dycore_bands_connect',
     'dycore_bands_step_matsuno', 'dycore_bands_destroy',
@@ -129,6 +129,8 @@ def load_library(path=None, dtype=np.float64):
     lib.dycore_get_stream.restype = C.c_void_p
     lib.dycore_substep_field.argtypes = [hp, C.c_int32, C.c_char_p]
     lib.dycore_substep_field.restype = C.c_char_p
+    if hasattr(lib, 'dycore_band_row_fields'):
+        lib.dycore_band_row_fields.argtypes = [hp, C.c_char_p, C.c_int32]
     cpp = C.POINTER(C.c_char_p)
     lib.dycore_rows_size.argtypes = [hp, C.c_int32, cpp, C.POINTER(C.c_int64)]
     lib.dycore_pack_rows.argtypes = [hp, C.c_int32, cpp, C.POINTER(C.c_int32), C.c_void_p]
@@ -321,6 +323,13 @@ class HipDycore:
         """The fused step re-forms UFLX, VFLX from the winds (they are not stored): a band exchanges
         rows of UCOL, VCOL instead."""
         return bool(self.lib.dycore_flux_from_winds(self._h))
+
+    @property
+    def band_diag_fields(self):
+        """Diagnostic fields whose halo rows a band receives from their owner with the POTT rows (never re-diagnosed)."""
+        buf = C.create_string_buffer(256)
+        self._check(self.lib.dycore_band_row_fields(self._h, buf, 256))
+        return [n for n in buf.value.decode().split(',') if n]
 
     def substep_part(self, dt, substep, part):
         self._check(self.lib.dycore_substep_part(self._h, float(dt), int(substep), int(part)))

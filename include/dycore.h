@@ -195,6 +195,11 @@ int dycore_overlap_parts(dycore_t *h);
  * of VWIND with the winds. */
 int dycore_flux_from_winds(dycore_t *h);
 int dycore_substep_part(dycore_t *h, double dt, int32_t substep, int32_t part);
+/* Comma-separated names of the diagnostic fields whose halo rows travel with the POTT rows of a band exchange (phase B):
+ * a band never re-diagnoses rows it does not own, it receives their owner's values (PVTFVB and, depending on what the
+ * handle's step stores, PHIVB / PHI / POTTVB / PVTF).  Empty for a handle on the staged step, whose part 2 diagnoses the
+ * whole band including its halo rows (dyn_org_discretizations.py:321-326). */
+int dycore_band_row_fields(dycore_t *h, char *buf, int32_t nbytes);
 int dycore_use_stream(dycore_t *h, void *stream);
 /* the handle's own stream (DycoreConfig.stream, or the one the library created) */
 void *dycore_get_stream(dycore_t *h);

@@ -45,12 +45,15 @@ KERNEL_PASSES = {
     'k_continuity': 5, 'k_continuity_reg': 3,   # fused: R UWIND,VWIND W WWIND (UFLX, VFLX are not stored)
     'k_prepare': 15, 'k_uflx_tendency': 13, 'k_vflx_tendency': 13,
     'k_pott_tendency': 6, 'k_euler_forward': 9, 'k_primary_diag': 5, 'k_diag_rho': 6,
-    'k_momentum_dma': 9.0,       # R UWIND,VWIND,WWIND,PHI,POTT,PVTFVB (+2 old in the corrector) W UWIND,VWIND (PVTF is formed in the thread)
-    'k_momentum_fused': 10.0,    # its register-staged fallback (nz > 160): the same fields + PVTF
-    # momentum + temperature of a substep in one launch (single GPU): R UWIND,VWIND,WWIND,PHI,POTT,PVTFVB,POTTVB (+3 old in the
-    # corrector) W UWIND,VWIND,POTT,PVTFVB,PHI,POTTVB -- the temperature wavefronts read the tiles the momentum wavefronts stage
-    'k_substep_fused': 14.5,
-    'k_pott_fused': 9.5,         # R POTT,UWIND,VWIND,WWIND,POTTVB (+1 old) W POTT,PVTFVB,PHI,POTTVB (PVTF is derived on demand)
+    # production (round 3): neither PHI nor POTTVB nor PVTF is stored -- the momentum wavefronts carry the hydrostatic
+    # integration, the temperature sweep forms the interface POTT it needs from POTT and PVTFVB of two levels
+    'k_momentum_dma': 8.0,       # R UWIND,VWIND,WWIND,POTT,PVTFVB (+2 old in the corrector) W UWIND,VWIND: 7 / 9
+    'k_momentum_fused': 10.0,    # its register-staged fallback (nz > 160): the same fields + PHI, PVTF
+    # momentum + temperature of a substep in one launch (single GPU): R UWIND,VWIND,WWIND,POTT,PVTFVB (+3 old in the
+    # corrector) W UWIND,VWIND,POTT,PVTFVB: 9 / 12 -- the temperature wavefronts read the tiles the momentum wavefronts stage
+    'k_substep_fused': 10.5,
+    'k_pott_fused': 9.5,         # (turbulence-coupled handles) R POTT,UWIND,VWIND,WWIND,POTTVB (+1 old) W POTT,PVTFVB,PHI,POTTVB
+    'k_temp_canon': 7.75,        # R POTT,UWIND,VWIND,WWIND,PVTFVB (+1 old) W POTT,PVTFVB (+ PHIVB at every 4th interface): 7.25 / 8.25
     'k_moist': 8.0,              # R QV,QC,UWIND,VWIND,WWIND (+2 old) W QV,QC
     'k_turb_tendencies': 16.0,   # R UWIND,VWIND,PHI,PHIVB,RHO,RHOVB,KMOM,KHEAT,POTT(,QV,QC) W TURB_U,V,T(,QV,QC)
 }

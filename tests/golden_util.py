@@ -56,3 +56,32 @@ def rel_max_err(test, ref, name, nx, ny):
     err = d / scale if scale > 0 else d
     ERR_LOG.append((os.environ.get('PYTEST_CURRENT_TEST', '').split(' ')[0], name, float(err)))
     return err, int(m.sum()), bad
+
+
+def rel_level_err(test, ref, name, nx, ny):
+    """The same norm taken LEVEL BY LEVEL: max over k of max|test-ref|_k / max|ref|_k (scale = the largest reference
+    value of THAT level), so that small-magnitude regions of a field (WWIND aloft, QC where it lives at 1e-10, the
+    winds of quiet levels) are not hidden behind the field's global maximum.  A level whose reference is identically
+    zero (WWIND at the model top and at the surface) must be reproduced exactly.  Returns (err, worst level); 2-D
+    fields fall back to rel_max_err."""
+    si, sj = compare_region(name, nx, ny)
+    t = np.asarray(test)[si, sj]
+    r = np.asarray(ref)[si, sj]
+    if r.ndim < 3 or r.shape[2] == 1:
+        return rel_max_err(test, ref, name, nx, ny)[0], 0
+    worst, kworst = 0.0, 0
+    for k in range(r.shape[2]):
+        rk, tk = r[:, :, k], t[:, :, k]
+        m = np.isfinite(rk)
+        if not m.any():
+            continue
+        if not np.isfinite(tk[m]).all():
+            worst, kworst = np.inf, k
+            break
+        scale = np.max(np.abs(rk[m]))
+        d = np.max(np.abs(tk[m] - rk[m]))
+        e = d / scale if scale > 0 else (0.0 if d == 0 else np.inf)
+        if e > worst:
+            worst, kworst = float(e), k
+    ERR_LOG.append((os.environ.get('PYTEST_CURRENT_TEST', '').split(' ')[0], name + ' (per level, worst k=%d)' % kworst, float(worst)))
+    return worst, kworst

@@ -9,7 +9,7 @@ import datetime
 import numpy as np
 import pytest
 
-from golden_util import rel_max_err
+from golden_util import rel_max_err, rel_level_err
 from oracle_binding import Oracle, oracle_radiation, RAD_INPUTS
 
 from climate_model_amd import Namelist, Grid, ModelFields, HipDycore
@@ -35,10 +35,20 @@ def _physics_inputs(GR, F, i_turb, seed=4):
             F.host[n][...] = rng.uniform(lo, hi, F.host[n].shape)
 
 
-def _check(core, o, names, nx, ny, what, tol=TOL):
+# level by level (golden_util.rel_level_err: scale = max|ref| of that level) on the full-size runs; observed margins in
+# profiles/r03_parity_margins.txt
+LEVEL_TOL = {'QC': 1e-8}
+LEVEL_STEP_TOL = 1e-9
+
+
+def _check(core, o, names, nx, ny, what, tol=TOL, per_level=False):
     for n in names:
-        err, ncmp, bad = rel_max_err(core.download(n), o.F[n], n, nx, ny)
+        got = core.download(n)
+        err, ncmp, bad = rel_max_err(got, o.F[n], n, nx, ny)
         assert bad == 0 and ncmp > 0 and err <= tol.get(n, STEP_TOL), '%s %s: rel err %.3e (%d bad)' % (what, n, err, bad)
+        if per_level:
+            lerr, kw = rel_level_err(got, o.F[n], n, nx, ny)
+            assert lerr <= LEVEL_TOL.get(n, LEVEL_STEP_TOL), '%s %s: per-level rel err %.3e at level %d' % (what, n, lerr, kw)
 
 
 def test_config5_full_size_vs_oracle():
@@ -84,7 +94,7 @@ def test_config5_full_size_vs_oracle():
     o.F['dPOTTdt_RAD'][...] = heat
     o.primary_diag()
     o.step_matsuno(GR.dt, 1, with_rho=False)
-    _check(core, o, ['COLP', 'UWIND', 'VWIND', 'POTT', 'QV', 'QC', 'PHI', 'WWIND'], GR.nx, GR.ny, 'config 5')
+    _check(core, o, ['COLP', 'UWIND', 'VWIND', 'POTT', 'QV', 'QC', 'PHI', 'WWIND'], GR.nx, GR.ny, 'config 5', per_level=True)
     core.close()
 
 
@@ -147,7 +157,7 @@ def test_turbulent_moist_full_size_vs_oracle():
     o = Oracle(GR.nx, GR.ny, GR.nz, GR.GRF['CPU'], state, pair_top=nl.pair_top, i_turb=1, i_moist=1, fill_nan=False)
     o.primary_diag()
     o.step_matsuno(GR.dt, 1, with_rho=True)
-    _check(core, o, ['COLP', 'UWIND', 'VWIND', 'POTT', 'QV', 'QC', 'PHI'], GR.nx, GR.ny, 'turbulent moist 0.25 deg', TOL_TURB)
+    _check(core, o, ['COLP', 'UWIND', 'VWIND', 'POTT', 'QV', 'QC', 'PHI'], GR.nx, GR.ny, 'turbulent moist 0.25 deg', TOL_TURB, per_level=True)
     core.close()
 
 

@@ -4,7 +4,7 @@
 import numpy as np
 import pytest
 
-from golden_util import rel_max_err
+from golden_util import rel_max_err, rel_level_err
 from oracle_binding import Oracle
 
 from climate_model_amd import Namelist, Grid, ModelFields, HipDycore
@@ -15,6 +15,7 @@ from climate_model_amd.synthetic import initialize_fields
 pytestmark = pytest.mark.gpu
 STATE = ['HSURF', 'COLP', 'UWIND', 'VWIND', 'POTT', 'WWIND', 'POTTVB']
 PROGNOSTIC = ['COLP', 'UWIND', 'VWIND', 'POTT']
+LEVEL_TOL = 1e-9      # per-level max-norm (golden_util.rel_level_err)
 
 
 def _setup(d, nz):
@@ -47,6 +48,10 @@ def test_baseline_configs_vs_oracle(d, nz, nsteps):
     for n in got:
         err, ncmp, bad = rel_max_err(got[n], o.F[n], n, GR.nx, GR.ny)
         assert bad == 0 and ncmp > 0 and err <= 1e-10, '%s at %g deg x %d: rel err %.3e (%d bad)' % (n, d, nz, err, bad)
+        # ... and level by level (scale = max|ref| of that level): WWIND aloft and the winds of quiet levels are not
+        # hidden behind the field's global maximum; observed margins in profiles/r03_parity_margins.txt
+        lerr, kw = rel_level_err(got[n], o.F[n], n, GR.nx, GR.ny)
+        assert lerr <= LEVEL_TOL, '%s at %g deg x %d: per-level rel err %.3e at level %d' % (n, d, nz, lerr, kw)
 
 
 def test_zonal_shift_invariance_full_size():

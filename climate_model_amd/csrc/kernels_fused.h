@@ -715,11 +715,24 @@ __global__ __launch_bounds__(FTI *TJ *(WITH_TEMP ? 2 : 1), ((TJ <= 4 && !WITH_TE
             const real *nb = dsm + slot * DSLOT;
             real *nf = dsm + NS * DSLOT + fslot * FSLOT;
             const int e = VW * chf;
+            // every LDS read first, then the products, then the writes: written as one loop the compiler orders each write
+            // before the next element's reads (it cannot tell the tiles apart) -- three LDS round trips one after the other
+            // on the critical path between "my DMA has landed" and the barrier.  (A chunk lies inside the UFLX tile or
+            // beyond it as a whole; beyond it the reads hit the neighbouring tiles and are discarded.)
+            real wu_[VW], wv_[VW], fu_[VW], fv_[VW];
 #pragma unroll
             for (int d = 0; d < VW; d++) {
-                if (e + d < (TJ + 2) * FTW) nf[mom_off(S_UF, TJ, true) + e + d] = f_uc[d] * nb[mom_off(S_UW, TJ, true) + e + d] * fac[mom_off(S_UF, TJ, true) + e + d];
-                nf[mom_off(S_VF, TJ, true) + e + d] = f_vc[d] * nb[mom_off(S_VW, TJ, true) + e + d] * fac[mom_off(S_VF, TJ, true) + e + d];
+                wu_[d] = nb[mom_off(S_UW, TJ, true) + e + d]; wv_[d] = nb[mom_off(S_VW, TJ, true) + e + d];
+                fu_[d] = fac[mom_off(S_UF, TJ, true) + e + d]; fv_[d] = fac[mom_off(S_VF, TJ, true) + e + d];
             }
+#pragma unroll
+            for (int d = 0; d < VW; d++) { wu_[d] = f_uc[d] * wu_[d] * fu_[d]; wv_[d] = f_vc[d] * wv_[d] * fv_[d]; }
+            if (e < (TJ + 2) * FTW) {
+#pragma unroll
+                for (int d = 0; d < VW; d++) nf[mom_off(S_UF, TJ, true) + e + d] = wu_[d];
+            }
+#pragma unroll
+            for (int d = 0; d < VW; d++) nf[mom_off(S_VF, TJ, true) + e + d] = wv_[d];
         }
     };
     const int lx = tx + FXO, ly = ty + 1; // tile column 0 is longitude i0 - FXO (16-B aligned in HBM)

@@ -531,6 +531,47 @@ int ensure_planes(dycore *h)
     h->planes_valid = true;
     return 0;
 }
+// Work list of a k_momentum_dma launch (MomPlan).  With `slots` workgroups resident at a time, T tiles of nz levels take
+// ceil(T / slots) rounds; ks level chunks per tile take ceil(T * ks / slots) rounds of nz / ks levels + the chunk's
+// prologue (2-D loads, factor tiles, first DMA: ~mom_pro levels).  Candidates: the whole row set in 1 .. 16 chunks per
+// tile, or -- for a contiguous row set of more than one round -- the tile rows that fill whole rounds as full tiles
+// (segment a) and the remaining rows cut into up to 16 chunks (segment b), so that the last round costs a fraction of a tile.
+MomPlan make_mom_plan(const dycore *h, int gbx, const RowSet &trows, int slots)
+{
+    MomPlan plan = {trows, 1, 0, {0, 0, 0, 0}, 1, h->mom_patch};
+    const long tiles = (long)gbx * trows.n;
+    const double pro = h->mom_pro;
+    auto rounds = [&](long wg) { return (double)((wg + slots - 1) / slots); };
+    double best = -1.0;
+    // any number of chunks up to 16 (chunk kc covers levels [kc nz / ks, (kc + 1) nz / ks)); a chunk of fewer
+    // than 4 levels is all prologue
+    const int nzb = (h->g.nz + PHIVB_STRIDE - 1) / PHIVB_STRIDE;     // level chunks are whole blocks of PHIVB_STRIDE levels (k_momentum_dma)
+    auto chunk_levels = [&](int cand) { return (double)std::min(h->g.nz, PHIVB_STRIDE * ((nzb + cand - 1) / cand)); };
+    for (int cand = 1; cand <= 16; cand++) {
+        if (cand > nzb) break;
+        const double cost = rounds(tiles * cand) * (chunk_levels(cand) + (cand > 1 ? pro : 0.0));
+        if (best < 0 || cost < best - 1e-9) { best = cost; plan.ks_a = cand; }
+    }
+    if (h->mom_ks) plan.ks_a = std::min(h->mom_ks, nzb);
+    const long full = tiles / slots;              // whole rounds of full tiles
+    if (h->mom_split && !h->mom_ks && trows.gap == 0 && full >= 1 && tiles % slots) {
+        const int r1 = (int)(full * slots / gbx);       // tile rows inside those rounds
+        const int r2 = trows.n - r1;
+        if (r1 >= 1 && r2 >= 1) {
+            for (int cand = 1; cand <= 16; cand++) {
+                if (cand > nzb) break;
+                const double cost = rounds((long)gbx * r1) * h->g.nz + rounds((long)gbx * r2 * cand) * (chunk_levels(cand) + (cand > 1 ? pro : 0.0));
+                if (cost < best - 1e-9) {
+                    best = cost;
+                    plan.a = {trows.first, r1, r1, 0}; plan.ks_a = 1;
+                    plan.b = {trows.first + r1, r2, r2, 0}; plan.ks_b = cand;
+                }
+            }
+        }
+    }
+    plan.nblk_a = 8 * ((gbx * plan.a.n * plan.ks_a + 7) / 8);
+    return plan;
+}
 // prepare + dUFLXdt + dVFLXdt (+ Euler step of the winds when u_out != nullptr)
 int do_momentum_fused(dycore *h, const Ptrs &p, const real *u_old, const real *v_old,
                       real *u_out, real *v_out, real dt, int mode = ROWS_ALL)
@@ -574,46 +615,7 @@ int do_momentum_fused(dycore *h, const Ptrs &p, const real *u_old, const real *v
             for (int by = gby2 - 1; by >= 0 && by * tj + 1 + tj + 1 > h->g.ny; by--) dep_n++;
         RowSet trows;
         if (!row_subset(gby2, h->g.pole_s ? 0 : 1, dep_n, mode, trows)) return 0;
-        // Work list (MomPlan).  One workgroup per CU: T tiles of nz levels take ceil(T / CUs) rounds;
-        // ks level chunks per tile take ceil(T * ks / CUs) rounds of nz / ks levels + the chunk's
-        // prologue (2-D loads, factor tiles, first DMA: ~mom_pro levels).  Candidates: the whole row set
-        // in 1, 2 or 4 chunks per tile, or -- for a contiguous row set of more than one round -- the
-        // tile rows that fill whole rounds as full tiles (segment a) and the remaining rows cut into
-        // up to 16 chunks (segment b), so that the last round costs a fraction of a tile.
-        MomPlan plan = {trows, 1, 0, {0, 0, 0, 0}, 1, h->mom_patch};
-        {
-            const long tiles = (long)gbx * trows.n;
-            const double pro = h->mom_pro;
-            auto rounds = [&](long wg) { return (double)((wg + slots - 1) / slots); };
-            double best = -1.0;
-            // any number of chunks up to 16 (chunk kc covers levels [kc nz / ks, (kc + 1) nz / ks)); a chunk of fewer
-            // than 4 levels is all prologue
-            const int nzb = (h->g.nz + PHIVB_STRIDE - 1) / PHIVB_STRIDE;     // level chunks are whole blocks of PHIVB_STRIDE levels (k_momentum_dma)
-            auto chunk_levels = [&](int cand) { return (double)std::min(h->g.nz, PHIVB_STRIDE * ((nzb + cand - 1) / cand)); };
-            for (int cand = 1; cand <= 16; cand++) {
-                if (cand > nzb) break;
-                const double cost = rounds(tiles * cand) * (chunk_levels(cand) + (cand > 1 ? pro : 0.0));
-                if (best < 0 || cost < best - 1e-9) { best = cost; plan.ks_a = cand; }
-            }
-            if (h->mom_ks) plan.ks_a = std::min(h->mom_ks, nzb);
-            const long full = tiles / slots;              // whole rounds of full tiles
-            if (h->mom_split && !h->mom_ks && trows.gap == 0 && full >= 1 && tiles % slots) {
-                const int r1 = (int)(full * slots / gbx);       // tile rows inside those rounds
-                const int r2 = trows.n - r1;
-                if (r1 >= 1 && r2 >= 1) {
-                    for (int cand = 1; cand <= 16; cand++) {
-                        if (cand > nzb) break;
-                        const double cost = rounds((long)gbx * r1) * h->g.nz + rounds((long)gbx * r2 * cand) * (chunk_levels(cand) + (cand > 1 ? pro : 0.0));
-                        if (cost < best - 1e-9) {
-                            best = cost;
-                            plan.a = {trows.first, r1, r1, 0}; plan.ks_a = 1;
-                            plan.b = {trows.first + r1, r2, r2, 0}; plan.ks_b = cand;
-                        }
-                    }
-                }
-            }
-        }
-        plan.nblk_a = 8 * ((gbx * plan.a.n * plan.ks_a + 7) / 8);
+        const MomPlan plan = make_mom_plan(h, gbx, trows, slots);
         const dim3 gr2(plan.nblk_a + 8 * ((gbx * plan.b.n * plan.ks_b + 7) / 8)), blk(FTI, tj);
         const bool cur = (u_old == p.UWIND);
         const bool fw = flux_from_winds(h) && (h->fw_mask & 2);
@@ -648,9 +650,21 @@ int do_substep_fused(dycore *h, const Ptrs &p, const real *u_old, const real *v_
     Scope s(h, K_SUBSTEP);
     constexpr int tj = 4;
     const int gbx = (h->g.nx + FTI - 1) / FTI, gby = (h->g.ny + tj - 1) / tj;
-    MomPlan plan = {{0, gby, gby, 0}, 1, 8 * ((gbx * gby + 7) / 8), {0, 0, 0, 0}, 1, h->mom_patch};
-    const dim3 gr(plan.nblk_a), blk(FTI, 2 * tj);
+    // one workgroup of eight wavefronts per CU; the tile rows beyond the last full round are cut into level chunks
+    const MomPlan plan = make_mom_plan(h, gbx, RowSet{0, gby, gby, 0}, h->n_cu);
+    const dim3 gr(plan.nblk_a + 8 * ((gbx * plan.b.n * plan.ks_b + 7) / 8)), blk(FTI, 2 * tj);
     const bool cur = (u_old == p.UWIND);
+    // the PHIVB planes the chunks' momentum wavefronts start from (own row, southern neighbour), of the state `p` this launch
+    // evaluates on -- nobody else keeps them on this path
+    for (int seg = 0; seg < 2; seg++) {
+        const RowSet &rs = seg ? plan.b : plan.a;
+        const int ks = seg ? plan.ks_b : plan.ks_a;
+        if (rs.n <= 0 || ks <= 1) continue;
+        const int j_lo = std::max(0, rs.first * tj), j_hi = std::min(h->g.ny + 1, (rs.first + rs.n) * tj);
+        hipLaunchKernelGGL(k_phivb_rows, dim3((h->g.nx + 2 + TI - 1) / TI, (j_hi - j_lo + 1 + TJ - 1) / TJ), dim3(TI, TJ), 0, h->stream, h->g, p, j_lo, j_hi);
+        int rc = launch_check("k_phivb_rows");
+        if (rc) return rc;
+    }
 #ifdef DYC_TRACE
     static long long *trace_buf = nullptr;
     if (!trace_buf && hipMalloc((void **)&trace_buf, 8 * 256 * 8 * sizeof(long long)) == hipSuccess) (void)hipMemset(trace_buf, 0, 8 * 256 * 8 * sizeof(long long));

@@ -530,9 +530,10 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 // kernel reads POTT, UWIND, VWIND, WWIND like the momentum kernel, so one staging serves both (4 of its 5 read passes
 // disappear: 14.5 instead of 18.5 field passes per substep).  Each SIMD then holds one momentum and one temperature
 // wavefront -- two different instruction streams between the same per-level barriers.  The new PVTFVB and PHI go to
-// alternate buffers (the momentum wavefronts of neighbouring tiles still read the old ones), which the library swaps in
-// after the launch.  Whole columns only (the diagnostics integrate from the surface): no level chunks, so a latitude
-// band, whose few tiles need them to fill the chip, keeps the two separate kernels.
+// alternate buffer (the momentum wavefronts of neighbouring tiles still read the old one), which the library swaps in
+// after the launch.  Level chunks (MomPlan) as in the momentum-only instances: the temperature sweep carries nothing further
+// than one level since it stopped integrating PHI (round 3), the momentum wavefronts of a chunk that ends inside the column
+// start their hydrostatic integration from a stored PHIVB plane (k_phivb_rows, launched for the tile rows that are cut).
 struct TempArgs { const real *pott_old; real *pott_out, *pvb_out; long long *trace; };
 // -DDYC_TRACE (experiment builds only): the wavefronts of ONE workgroup of the whole-substep kernel write their cycle counter at
 // four points of every level: [wave][level][point], point 0 = top of the iteration, 1 = stores and DMA issued, 2 = arithmetic
@@ -754,24 +755,35 @@ __global__ __launch_bounds__(FTI *TJ *(WITH_TEMP ? 2 : 1), ((TJ <= 4 && !WITH_TE
         const size_t pl = (size_t)g.plane;
         // the surface interface: Exner value of the new column (stored), of the old one (read: the lower interface of the
         // bottom level).  No hydrostatic integration here: the momentum wavefronts of the NEXT substep carry it themselves
-        if (active) ta.pvb_out[c + (size_t)nz * pl] = canon_exner(canon_pk(g.pair_top, c_sig[nz], cnew));
-        real pvbO_kp1 = p.PVTFVB[c + (size_t)nz * pl];
-        double pkO_kp1 = canon_pk(g.pair_top, c_sig[nz], colp);
+        if (active && k1 == nz) ta.pvb_out[c + (size_t)nz * pl] = canon_exner(canon_pk(g.pair_top, c_sig[nz], cnew));
+        // Level chunk [k0, k1): nothing in this sweep is carried further than one level -- a level is closed one iteration
+        // late, with the interface value between it and the level above.  A chunk that ends inside the column (k1 < nz)
+        // therefore starts from level k1's POTT, Exner value and sigma-dot (read here; level k1 itself belongs to the chunk
+        // below), and one that begins inside it (k0 > 0) closes its top level with level k0-1's (epilogue).  Both chunks
+        // evaluate the interface they share with the same call on the same operands: the same bits as the whole column.
+        real pvbO_kp1 = p.PVTFVB[c + (size_t)k1 * pl];
+        double pkO_kp1 = canon_pk(g.pair_top, c_sig[k1], colp);
         real pvtfO_kp1 = 0.0, pt_kp1 = 0.0, w_kp1 = 0.0, lp_kp2 = 0.0, tpart_kp1 = 0.0, po_kp1 = 0.0;
+        if (k1 < nz) {
+            const real pvbO_kp2 = p.PVTFVB[c + (size_t)(k1 + 1) * pl];
+            pvtfO_kp1 = canon_pvtf(pvbO_kp2, canon_pk(g.pair_top, c_sig[k1 + 1], colp), pvbO_kp1, pkO_kp1, rcolO, c_rdst[k1]);
+            pt_kp1 = p.POTT[c + (size_t)k1 * pl];
+            w_kp1 = p.WWIND[c + (size_t)k1 * pl];
+        }
         real o_pott = 0.0, o_pvb = 0.0;       // outputs stored at the end of a level: POTT of level k+1, PVTFVB at interface k
         {   // every value loaded above is complete before the level loop starts (see the momentum wavefronts)
-            asm volatile("" : "+v"(colp), "+v"(cold), "+v"(c_im1), "+v"(c_ip1), "+v"(c_jm1), "+v"(c_jp1), "+v"(hr_area), "+v"(r_cnew), "+v"(rcolO), "+v"(pvbO_kp1));
+            asm volatile("" : "+v"(colp), "+v"(cold), "+v"(c_im1), "+v"(c_ip1), "+v"(c_jm1), "+v"(c_jp1), "+v"(hr_area), "+v"(r_cnew), "+v"(rcolO), "+v"(pvbO_kp1), "+v"(pvtfO_kp1), "+v"(pt_kp1), "+v"(w_kp1));
         }
         constexpr int OWN_PO = OFF_OLD + 2 * ON, OWN_RAD = OFF_OLD + (NOWN - 1) * ON;
         const bool has_rad = g.i_rad;
-        issue(nz - 1, 0);
-        if (nz >= 2) issue(nz - 2, 1);
-        wait_vmcnt(nz >= 2 ? n_issue : 0);
-        if (FLUX_T) flux_own(0, (nz - 1) & 1);
-        lds_barrier();          // (the flux tiles of level nz-1: whichever role moves the winds)
+        issue(k1 - 1, 0);
+        if (k1 - 2 >= k0) issue(k1 - 2, 1);
+        wait_vmcnt(k1 - 2 >= k0 ? n_issue : 0);
+        if (FLUX_T) flux_own(0, (k1 - 1) & 1);
+        lds_barrier();          // (the flux tiles of level k1-1: whichever role moves the winds)
         int slot = 0;
 #pragma unroll 1
-        for (int k = nz - 1; k >= 0; k--) {
+        for (int k = k1 - 1; k >= k0; k--) {
             int slot1 = slot + 1;
             if (slot1 == NS) slot1 = 0;
             TRACE_PT(k, 0);
@@ -790,8 +802,10 @@ __global__ __launch_bounds__(FTI *TJ *(WITH_TEMP ? 2 : 1), ((TJ <= 4 && !WITH_TE
                 real lp_kp1 = 0.0;
                 if (k < nz - 1) {
                     const real vb = pottvb_between(pvbO_kp1, pvtfO_k, pt, pvtfO_kp1, pt_kp1);
-                    TEMP_CLOSE(pottn, tpart_kp1, cnew, cold, r_cnew, w_kp1, vb, lp_kp2, c_rdst[k + 1], po_kp1, dt)
-                    o_pott = pottn;
+                    if (k < k1 - 1) {       // (level k1 is closed by the chunk below)
+                        TEMP_CLOSE(pottn, tpart_kp1, cnew, cold, r_cnew, w_kp1, vb, lp_kp2, c_rdst[k + 1], po_kp1, dt)
+                        o_pott = pottn;
+                    }
                     lp_kp1 = mul_rn(w_kp1, vb);
                 }
                 // tendency of level k on the re-formed mass-flux tiles, without the vertical advection
@@ -806,7 +820,7 @@ __global__ __launch_bounds__(FTI *TJ *(WITH_TEMP ? 2 : 1), ((TJ <= 4 && !WITH_TE
             // of DMA and stores at the top of a level fills the queues, and a vector-memory instruction that finds them full
             // blocks its wavefront (timeline in profiles/r02_notes.md: 750 ticks per level with the stores and the DMA at the
             // top, 80 now).  Its own-cell tiles of level k-1 went out one level ago, behind that level's stores: vmcnt(0).
-            if (k - 1 >= 0 && DYC_MOM_MODE != 2) {
+            if (k - 1 >= k0 && DYC_MOM_MODE != 2) {
                 wait_vmcnt(0);
                 if (FLUX_T) flux_own(slot1, (k - 1) & 1);      // the winds of level k-1 are among what it moved: their flux entries
             }
@@ -815,18 +829,25 @@ __global__ __launch_bounds__(FTI *TJ *(WITH_TEMP ? 2 : 1), ((TJ <= 4 && !WITH_TE
             asm volatile("" ::: "memory");
             if (active) {
                 const size_t q0 = c + (size_t)k * pl;
-                if (k < nz - 1) __builtin_nontemporal_store(o_pott, ta.pott_out + q0 + pl);
+                if (k < k1 - 1) __builtin_nontemporal_store(o_pott, ta.pott_out + q0 + pl);
                 __builtin_nontemporal_store(o_pvb, ta.pvb_out + q0);
             }
             asm volatile("" ::: "memory");
-            if (k - 2 >= 0 && DYC_MOM_MODE != 2) issue(k - 2, (slot + 2) % NS);        // its own-cell tiles of level k-2
+            if (k - 2 >= k0 && DYC_MOM_MODE != 2) issue(k - 2, (slot + 2) % NS);        // its own-cell tiles of level k-2
             TRACE_PT(k, 3);
             lds_barrier();
             slot = slot1;
         }
-        if (active) {           // the top level: its upper interface is the model top (sigma-dot = 0)
-            TEMP_CLOSE(pott0, tpart_kp1, cnew, cold, r_cnew, (real)0.0, (real)0.0, lp_kp2, c_rdst[0], po_kp1, dt)
-            __builtin_nontemporal_store(pott0, ta.pott_out + c);
+        if (active) {           // the top level of the chunk
+            real w_top = 0.0, vb_top = 0.0;     // its upper interface is the model top (sigma-dot = 0) ...
+            if (k0 > 0) {                       // ... or interface k0, shared with the chunk above: level k0-1's values
+                const real pvbO_m = p.PVTFVB[c + (size_t)(k0 - 1) * pl], pt_m = p.POTT[c + (size_t)(k0 - 1) * pl];
+                const real pvtfO_m = canon_pvtf(pvbO_kp1, pkO_kp1, pvbO_m, canon_pk(g.pair_top, c_sig[k0 - 1], colp), rcolO, c_rdst[k0 - 1]);
+                vb_top = pottvb_between(pvbO_kp1, pvtfO_m, pt_m, pvtfO_kp1, pt_kp1);
+                w_top = w_kp1;
+            }
+            TEMP_CLOSE(pott0, tpart_kp1, cnew, cold, r_cnew, w_top, vb_top, lp_kp2, c_rdst[k0], po_kp1, dt)
+            __builtin_nontemporal_store(pott0, ta.pott_out + c + (size_t)k0 * pl);
         }
         return;
     }
@@ -1459,6 +1480,30 @@ __global__ __launch_bounds__(TI *TJ) void k_derive_phi(Geo g, Ptrs p, int canon)
         p.PHI[q] = dl.phi;
         p.PHIVB[q] = dl.phivb;
         p_kp12 = dl.p_km12; pvb_kp1 = dl.pvb_k; phivb_kp1 = dl.phivb;
+    }
+}
+// The PHIVB planes of rows j_lo .. j_hi (columns 0 .. nx+1): PHIVB at every PHIVB_STRIDE-th interface, integrated from the
+// surface with the canonical forms -- what the momentum wavefronts of a level chunk start from.  The whole-substep kernel
+// does not keep the planes (its temperature wavefronts do not integrate PHI); its launch cuts only the tile rows beyond
+// the last full round of workgroups into chunks, and this kernel serves those rows (a few of 720) just before it.
+__global__ __launch_bounds__(TI *TJ) void k_phivb_rows(Geo g, Ptrs p, int j_lo, int j_hi)
+{
+    const int i = blockIdx.x * TI + threadIdx.x, j = j_lo + blockIdx.y * TJ + threadIdx.y;
+    if (i > g.nx + 1 || j > j_hi) return;
+    const size_t c = at2(g, i, j);
+    const int nz = g.nz;
+    const real colp = p.COLP[c], rcol = canon_rcol(colp);
+    real phivb_kp1 = p.HSURF[c] * CON_G;
+    double pk1 = canon_pk(g.pair_top, p.sigma_vb[nz], colp);
+    real pvb_kp1 = p.PVTFVB[c + (size_t)nz * g.plane];
+    for (int k = nz - 1; k >= 1; k--) {
+        const size_t q = c + (size_t)k * g.plane;
+        const double pk = canon_pk(g.pair_top, p.sigma_vb[k], colp);
+        const real pvb_k = p.PVTFVB[q], pott = p.POTT[q];
+        const real pvtf = canon_pvtf(pvb_kp1, pk1, pvb_k, pk, rcol, p.rdsigma[k]);
+        phivb_kp1 = canon_phivb(canon_phi(phivb_kp1, pott, pvtf, pvb_kp1), pott, pvb_k, pvtf);
+        if (k % PHIVB_STRIDE == 0) p.PHIVB[q] = phivb_kp1;
+        pk1 = pk; pvb_kp1 = pvb_k;
     }
 }
 __global__ __launch_bounds__(TI *TJ) void k_derive_phivb(Geo g, Ptrs p)

@@ -28,7 +28,7 @@ print(json.dumps({'res': res, 'finite': bool(np.isfinite(u[1:-2, 1:-1]).all()), 
 
 def main():
     args = sys.argv[1:]
-    d, nz, steps, rounds = 0.25, 64, 6, 3
+    d, nz, steps, rounds, reps = 0.25, 64, 6, 3, 1
     libs = []
     i = 0
     while i < len(args):
@@ -36,8 +36,9 @@ def main():
         elif args[i] == '--nz': nz = int(args[i+1]); i += 2
         elif args[i] == '--steps': steps = int(args[i+1]); i += 2
         elif args[i] == '--rounds': rounds = int(args[i+1]); i += 2
+        elif args[i] == '--reps': reps = int(args[i+1]); i += 2        # the whole list again, in the same order (A B C A B C): drift between processes shows
         else: libs.append(args[i]); i += 1
-    for lib in libs:
+    for lib in libs * reps:
         env = dict(os.environ)
         name = lib
         if '=' in lib:                      # NAME=path[,ENV=VAL...]

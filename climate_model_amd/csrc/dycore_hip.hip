@@ -620,16 +620,27 @@ int do_momentum_fused(dycore *h, const Ptrs &p, const real *u_old, const real *v
         const bool cur = (u_old == p.UWIND);
         const bool fw = flux_from_winds(h) && (h->fw_mask & 2);
         // ring depth: two levels in flight for the production (dry / moist, fluxes from the winds) instances
-#define MOM_LAUNCH_P(CUR_, TJ_, FW_, TB_, DP_, PL_) hipLaunchKernelGGL((k_momentum_dma<CUR_, TJ_, FW_, TB_, DP_, PL_>), gr2, blk, dma_lds_bytes(TJ_, FW_, CUR_, DP_, PL_), h->stream, h->g, p, gbx, plan, jv_lo, u_old, v_old, u_out, v_out, dt, TempArgs{nullptr, nullptr, nullptr, nullptr})
+#define MOM_LAUNCH_P(CUR_, TJ_, FW_, TB_, DP_, PL_) hipLaunchKernelGGL((k_momentum_dma<CUR_, TJ_, FW_, TB_, DP_, PL_>), gr2, blk, dma_lds_bytes(TJ_, FW_, CUR_, DP_, PL_, false, TB_), h->stream, h->g, p, gbx, plan, jv_lo, u_old, v_old, u_out, v_out, dt, TempArgs{nullptr, nullptr, nullptr, nullptr})
 #define MOM_LAUNCH_T(CUR_, TJ_, FW_, TB_, DP_) MOM_LAUNCH_P(CUR_, TJ_, FW_, TB_, DP_, false)
 #define MOM_LAUNCH(CUR_, FW_, TB_, DP_) MOM_LAUNCH_T(CUR_, FTJ, FW_, TB_, DP_)
         const bool pl = phi_on_demand(h);
         if (half && pl) { int rc = ensure_planes(h); if (rc) return rc; }       // (step_begin has done it; a caller of the parts may not have)
+#ifdef DYCORE_AB_SWITCHES
         if (half && pl) { if (!cur) MOM_LAUNCH_P(false, 4, true, false, 1, true); else if (h->mom_depth == 2) MOM_LAUNCH_P(true, 4, true, false, 2, true); else MOM_LAUNCH_P(true, 4, true, false, 1, true); }
         else if (half) { if (!cur) MOM_LAUNCH_T(false, 4, true, false, 1); else if (h->mom_depth == 2) MOM_LAUNCH_T(true, 4, true, false, 2); else MOM_LAUNCH_T(true, 4, true, false, 1); }
-        else if (h->g.i_turb) { if (cur) MOM_LAUNCH(true, true, true, 1); else MOM_LAUNCH(false, true, true, 1); }
+        else if (h->g.i_turb) { if (cur) MOM_LAUNCH(true, true, true, 2); else MOM_LAUNCH(false, true, true, 1); }
         else if (cur) { if (!fw) MOM_LAUNCH(true, false, false, 1); else if (h->mom_depth == 2) MOM_LAUNCH(true, true, false, 2); else MOM_LAUNCH(true, true, false, 1); }
         else { if (!fw) MOM_LAUNCH(false, false, false, 1); else if (h->mom_depth == 2) MOM_LAUNCH(false, true, false, 2); else MOM_LAUNCH(false, true, false, 1); }
+#else
+        // the shipped instances: 64 x 4 tiles with PHI in the thread (production), with PHI staged (DYCORE_LAZY_PHI=0), 64 x 8
+        // turbulence-coupled, 64 x 8 on stored mass fluxes (level counts the register continuity kernel has no instance for)
+        (void)fw;
+        if (half && pl) { if (!cur) MOM_LAUNCH_P(false, 4, true, false, 1, true); else MOM_LAUNCH_P(true, 4, true, false, 2, true); }
+        else if (half) { if (!cur) MOM_LAUNCH_T(false, 4, true, false, 1); else MOM_LAUNCH_T(true, 4, true, false, 2); }
+        else if (h->g.i_turb) { if (cur) MOM_LAUNCH(true, true, true, 2); else MOM_LAUNCH(false, true, true, 1); }
+        else if (cur) MOM_LAUNCH(true, false, false, 1);
+        else MOM_LAUNCH(false, false, false, 1);
+#endif
 #undef MOM_LAUNCH
 #undef MOM_LAUNCH_T
 #undef MOM_LAUNCH_P
@@ -702,11 +713,18 @@ int do_pott_fused(dycore *h, const Ptrs &p, const real *pott_old, real *pott_out
             h->planes_valid = true;     // ... and of the halo rows once their owner's rows have arrived (a band's exchange)
         }
         else if (pvtf_on_demand(h)) { POTT_LAUNCH(false, true, false, false); h->stale_pvtf = true; }
+#ifdef DYCORE_AB_SWITCHES
         else if (flux_from_winds(h) && (h->fw_mask & 4)) POTT_LAUNCH(false, true, false, true);
+#endif
         else POTT_LAUNCH(false, false, false, true);
         h->stale_phivb = true;
-    } else
+    } else {
+#ifdef DYCORE_AB_SWITCHES
         POTT_LAUNCH(true, false, false, true);
+#else
+        return fail(DYCORE_ESTATE, "the fused step without on-demand fields is an experiment build's (DYCORE_AB_SWITCHES)");
+#endif
+    }
 #undef POTT_LAUNCH
 #undef POTT_LAUNCH_P
     return launch_check("k_pott_fused");
@@ -929,22 +947,28 @@ int dycore_create(const DycoreConfig *cfg, dycore_t **out)
     g.i_moist_clip = cfg->i_moist_clip != 0;
     g.pair_top = cfg->pair_top;
     memset(&h->p, 0, sizeof h->p);
-    if (const char *e = getenv("DYCORE_FUSED")) h->fused = atoi(e) != 0;
+    // Switches of the shipped library ("Switches"): the documented fallback and what the parity tests
+    // compare the production step with.  None of them changes a result beyond rounding.
+    if (const char *e = getenv("DYCORE_FUSED")) h->fused = atoi(e) != 0;                    // 0: stage kernels for everything (the fallback)
+    if (const char *e = getenv("DYCORE_FUSED_TURB")) h->fused_turb = atoi(e) != 0;          // 0: stage kernels for turbulence-coupled handles
+    if (const char *e = getenv("DYCORE_STEP_FUSED")) h->step_fused = atoi(e) != 0;          // 0: momentum and temperature as two kernels on one GPU too (what a band runs)
+    if (const char *e = getenv("DYCORE_LAZY_PHI")) h->lazy_phi = atoi(e) != 0;              // 0: PHI and POTTVB stored and staged (round 2's data flow)
+    if (const char *e = getenv("DYCORE_MOM_KS")) h->mom_ks = atoi(e);                       // level chunks per tile forced (work-list tests)
+    if (const char *e = getenv("DYCORE_MOM_SPLIT")) h->mom_split = atoi(e);                 // 0: no second work-list segment
+    if (const char *e = getenv("DYCORE_CELL_LINEAR")) h->cell_lin = atoi(e);                // launch shape of the column kernels (bitwise-neutral, tested)
+#ifdef DYCORE_AB_SWITCHES
+    // A/B switches of experiment builds (-DDYCORE_AB_SWITCHES: tools/experiments/build_variant.sh): older data flows and tile
+    // shapes whose kernel instances the shipped library does not contain
     if (const char *e = getenv("DYCORE_MOM_DMA")) h->mom_dma = atoi(e);
     if (const char *e = getenv("DYCORE_LAZY")) h->lazy = atoi(e) != 0;
     if (const char *e = getenv("DYCORE_LAZY_FLX")) h->lazy_flx = atoi(e) != 0;
     if (const char *e = getenv("DYCORE_LAZY_PVTF")) h->lazy_pvtf = atoi(e) != 0;
-    if (const char *e = getenv("DYCORE_LAZY_PHI")) h->lazy_phi = atoi(e) != 0;
-    if (const char *e = getenv("DYCORE_FUSED_TURB")) h->fused_turb = atoi(e) != 0;
     if (const char *e = getenv("DYCORE_FW_MASK")) h->fw_mask = atoi(e);
-    if (const char *e = getenv("DYCORE_MOM_KS")) h->mom_ks = atoi(e);
     if (const char *e = getenv("DYCORE_MOM_PATCH")) h->mom_patch = atoi(e) > 1 ? atoi(e) : 1;
     if (const char *e = getenv("DYCORE_MOM_TJ")) h->mom_tj = atoi(e) == 4 ? 4 : 8;
-    if (const char *e = getenv("DYCORE_STEP_FUSED")) h->step_fused = atoi(e) != 0;
     if (const char *e = getenv("DYCORE_MOM_DEPTH")) h->mom_depth = atoi(e) == 1 ? 1 : 2;
-    if (const char *e = getenv("DYCORE_MOM_SPLIT")) h->mom_split = atoi(e);
     if (const char *e = getenv("DYCORE_MOM_PRO")) h->mom_pro = atof(e);
-    if (const char *e = getenv("DYCORE_CELL_LINEAR")) h->cell_lin = atoi(e);
+#endif
     {
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, cfg->device) == hipSuccess && prop.multiProcessorCount > 0) h->n_cu = prop.multiProcessorCount;
@@ -953,10 +977,13 @@ int dycore_create(const DycoreConfig *cfg, dycore_t **out)
         bool ok_plain = true, ok_fw = true, ok_deep = true, ok_half = true;
 #define MOM_ATTR_P(CUR_, TJ_, FW_, TB_, DP_, PL_, FLAG_)                                                              \
         if (hipFuncSetAttribute((const void *)k_momentum_dma<CUR_, TJ_, FW_, TB_, DP_, PL_>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                (int)dma_lds_bytes(TJ_, FW_, CUR_, DP_, PL_)) != hipSuccess) { (void)hipGetLastError(); FLAG_ = false; }
+                                (int)dma_lds_bytes(TJ_, FW_, CUR_, DP_, PL_, false, TB_)) != hipSuccess) { (void)hipGetLastError(); FLAG_ = false; }
 #define MOM_ATTR_T(CUR_, TJ_, FW_, TB_, DP_, FLAG_) MOM_ATTR_P(CUR_, TJ_, FW_, TB_, DP_, false, FLAG_)
         bool ok_pl = true;
-        MOM_ATTR_P(true, 4, true, false, 1, true, ok_pl) MOM_ATTR_P(true, 4, true, false, 2, true, ok_pl) MOM_ATTR_P(false, 4, true, false, 1, true, ok_pl)
+#ifdef DYCORE_AB_SWITCHES
+        MOM_ATTR_P(true, 4, true, false, 1, true, ok_pl)
+#endif
+        MOM_ATTR_P(true, 4, true, false, 2, true, ok_pl) MOM_ATTR_P(false, 4, true, false, 1, true, ok_pl)
         if (!ok_pl) h->lazy_phi = false;
         bool ok_wt = true;
         if (hipFuncSetAttribute((const void *)k_momentum_dma<true, 4, true, false, 2, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -965,18 +992,26 @@ int dycore_create(const DycoreConfig *cfg, dycore_t **out)
                                 (int)dma_lds_bytes(4, true, false, 2, true, true)) != hipSuccess) { (void)hipGetLastError(); ok_wt = false; }
         if (!ok_wt) h->step_fused = false;
 #define MOM_ATTR(CUR_, FW_, TB_, DP_, FLAG_) MOM_ATTR_T(CUR_, FTJ, FW_, TB_, DP_, FLAG_)
-        MOM_ATTR_T(true, 4, true, false, 1, ok_half) MOM_ATTR_T(true, 4, true, false, 2, ok_half) MOM_ATTR_T(false, 4, true, false, 1, ok_half)
-        MOM_ATTR(true, false, false, 1, ok_plain) MOM_ATTR(false, false, false, 1, ok_plain)
+#ifdef DYCORE_AB_SWITCHES
+        MOM_ATTR_T(true, 4, true, false, 1, ok_half)
         MOM_ATTR(true, true, false, 1, ok_fw) MOM_ATTR(false, true, false, 1, ok_fw)
-        MOM_ATTR(true, true, true, 1, ok_fw) MOM_ATTR(false, true, true, 1, ok_fw)
         MOM_ATTR(true, true, false, 2, ok_deep) MOM_ATTR(false, true, false, 2, ok_deep)
+#endif
+        MOM_ATTR_T(true, 4, true, false, 2, ok_half) MOM_ATTR_T(false, 4, true, false, 1, ok_half)
+        MOM_ATTR(true, false, false, 1, ok_plain) MOM_ATTR(false, false, false, 1, ok_plain)
+        MOM_ATTR(true, true, true, 2, ok_fw) MOM_ATTR(false, true, true, 1, ok_fw)
 #undef MOM_ATTR
 #undef MOM_ATTR_T
 #undef MOM_ATTR_P
         if (!ok_plain) h->mom_dma = 0;
         if (!ok_fw) h->lazy_flx = false;
+#ifdef DYCORE_AB_SWITCHES
         if (!ok_deep) h->mom_depth = 1;
         if (!ok_half) h->mom_tj = 8;
+#else
+        (void)ok_deep;
+        if (!ok_half) h->fused = false;     // (never seen: the 64 x 4 instances need the least LDS) -> stage kernels
+#endif
     }
     if (cfg->stream) h->stream = (hipStream_t)cfg->stream;
     else {

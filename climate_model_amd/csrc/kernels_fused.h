@@ -371,13 +371,13 @@ constexpr int mom_off(int f, int tj, bool fw, bool pl = false, bool wt = false) 
     return o;
 }
 // own-cell tiles behind the staged ones (FTI wide): the step-start winds of the corrector; WITH_TEMP: + the step-start POTT of the corrector, + dPOTTdt_RAD
-constexpr int mom_own_tiles(bool cur, bool wt) { return (cur ? 0 : 2) + (wt ? (cur ? 0 : 1) + 1 : 0); }       // (+ 1: the radiative heating rate, staged only on a handle with i_radiation)
-constexpr int mom_dma_slot(int tj, bool fw, bool cur, bool pl = false, bool wt = false) { return mom_off(FNF, tj, fw, pl, wt) + mom_own_tiles(cur, wt) * FTI * tj; }
+constexpr int mom_own_tiles(bool cur, bool wt, bool tb = false) { return (cur ? 0 : 2) + (wt ? (cur ? 0 : 1) + 1 : 0) + (tb ? 2 : 0); }       // `tb`: + TURB_U, TURB_V (turbulence-coupled instances)       // (+ 1: the radiative heating rate, staged only on a handle with i_radiation)
+constexpr int mom_dma_slot(int tj, bool fw, bool cur, bool pl = false, bool wt = false, bool tb = false) { return mom_off(FNF, tj, fw, pl, wt) + mom_own_tiles(cur, wt, tb) * FTI * tj; }
 constexpr int mom_flux_slot(int tj, bool fw) { return fw ? (2 * tj + 5) * FTW : 0; }
 // ... then (fw) two factor tiles, dyis (tj+2 rows) and dxjs (tj+3 rows), shaped like the UFLX / VFLX tiles
-constexpr size_t dma_lds_bytes(int tj, bool fw, bool cur, int depth, bool pl = false, bool wt = false)
+constexpr size_t dma_lds_bytes(int tj, bool fw, bool cur, int depth, bool pl = false, bool wt = false, bool tb = false)
 {
-    return ((size_t)(depth + 1) * mom_dma_slot(tj, fw, cur, pl, wt) + 3 * (size_t)mom_flux_slot(tj, fw)) * sizeof(real);
+    return ((size_t)(depth + 1) * mom_dma_slot(tj, fw, cur, pl, wt, tb) + 3 * (size_t)mom_flux_slot(tj, fw)) * sizeof(real);
 }
 
 #ifndef DYC_DMA_AUX
@@ -550,7 +550,7 @@ __global__ __launch_bounds__(FTI *TJ *(WITH_TEMP ? 2 : 1), ((TJ <= 4 && !WITH_TE
 {
     static_assert(!WITH_TEMP || (FROM_WINDS && !TURB && PHI_LOCAL && DEPTH == 2), "the temperature wavefronts read the re-formed flux tiles; nobody stores PHI for the momentum wavefronts");
     static_assert(DEPTH == 1 || DEPTH == 2, "ring of 2 or 3 slots");
-    static_assert(!(TURB && DEPTH != 1), "the turbulence-coupled variant keeps vector loads in the loop");
+    static_assert(!TURB || (TJ == 8 && !WITH_TEMP), "the turbulent tendencies travel as own-cell tiles of the two step-start wavefronts (64 x 8 tiles)");
     static_assert(!PHI_LOCAL || FROM_WINDS, "PHI in the thread needs PVTF in the thread");
 #define MROWS(f) mom_rows(f, TJ, FROM_WINDS, PHI_LOCAL, WITH_TEMP)
 #define MOFF(f) mom_off(f, TJ, FROM_WINDS, PHI_LOCAL, WITH_TEMP)
@@ -568,10 +568,13 @@ __global__ __launch_bounds__(FTI *TJ *(WITH_TEMP ? 2 : 1), ((TJ <= 4 && !WITH_TE
     // temperature wavefront is the slower of the two on a SIMD, profiles/r02_notes.md)
     constexpr int AHEAD = DEPTH;
     constexpr int NS = AHEAD + 1;
-    constexpr int DSLOT = mom_dma_slot(TJ, FROM_WINDS, OLD_IS_CUR, PHI_LOCAL, WITH_TEMP), FSLOT = mom_flux_slot(TJ, FROM_WINDS);
+    constexpr int DSLOT = mom_dma_slot(TJ, FROM_WINDS, OLD_IS_CUR, PHI_LOCAL, WITH_TEMP, TURB), FSLOT = mom_flux_slot(TJ, FROM_WINDS);
     constexpr int OFF_OLD = MOFF(FNF);
     // the step-start tiles: two wavefronts of their own (8 rows), or one slice more for the first 2 ONSL wavefronts (4 rows)
     constexpr bool OLD_SHARED = NSL + 2 > TJ;
+    static_assert(!(TURB && OLD_SHARED), "TURB_U / TURB_V ride with the two wavefronts that move the step-start tiles");
+    // own-cell tiles behind the staged ones: [u_old, v_old (corrector)] [TURB_U, TURB_V (turbulence-coupled)]; OFF_TB = the latter
+    constexpr int OFF_TB = OFF_OLD + (OLD_IS_CUR ? 0 : 2) * ON;
     static_assert(NSL <= TJ && 2 * ONSL <= TJ, "not enough wavefronts for the DMA slices");
     extern __shared__ __attribute__((aligned(16))) real dsm[];
     // workgroup -> (tile, level chunk): `ksplit` chunks of the k range per tile give a small
@@ -624,7 +627,7 @@ __global__ __launch_bounds__(FTI *TJ *(WITH_TEMP ? 2 : 1), ((TJ <= 4 && !WITH_TE
         if (role_t)
             for (int s5 = wave - TJ; s5 < nown * ONSL; s5 += TJ) n_issue++;
     } else {
-        if (!OLD_IS_CUR && !OLD_SHARED && wave >= TJ - 2) n_issue = ONSL;
+        if (!OLD_SHARED && wave >= TJ - 2) n_issue = ONSL * ((OLD_IS_CUR ? 0 : 1) + (TURB ? 1 : 0));
         if (!OLD_IS_CUR && OLD_SHARED && wave < 2 * ONSL) n_issue++;
     }
     const real *src[FNF] = {p.UFLX, p.VFLX, p.UWIND, p.VWIND, p.WWIND, p.PHI, p.POTT, p.PVTF, p.PVTFVB};
@@ -659,12 +662,23 @@ __global__ __launch_bounds__(FTI *TJ *(WITH_TEMP ? 2 : 1), ((TJ <= 4 && !WITH_TE
                 const real *gp = osrc + (size_t)k * g.plane + min(j0 + VW * (wave % ONSL) + orow, g.NJ - 1) * P + ocol;
                 lds_dma16(gp, buf + OFF_OLD + wave * 64 * VW);
             }
-        } else if (!OLD_IS_CUR && wave >= TJ - 2) {
-            real *ob = buf + OFF_OLD + (wave - (TJ - 2)) * ON;
+        } else if ((!OLD_IS_CUR || TURB) && wave >= TJ - 2) {
+            if (!OLD_IS_CUR) {
+                real *ob = buf + OFF_OLD + (wave - (TJ - 2)) * ON;
 #pragma unroll
-            for (int s5 = 0; s5 < ONSL; s5++) {
-                const real *gp = osrc + (size_t)k * g.plane + min(j0 + VW * s5 + orow, g.NJ - 1) * P + ocol;
-                lds_dma16(gp, ob + s5 * 64 * VW);
+                for (int s5 = 0; s5 < ONSL; s5++) {
+                    const real *gp = osrc + (size_t)k * g.plane + min(j0 + VW * s5 + orow, g.NJ - 1) * P + ocol;
+                    lds_dma16(gp, ob + s5 * 64 * VW);
+                }
+            }
+            if (TURB) {     // the turbulent tendencies of k_turb_tendencies, own cell: no vector load left in the level loop
+                real *ob = buf + OFF_TB + (wave - (TJ - 2)) * ON;
+                const real *tsrc = (wave == TJ - 2) ? p.TURB_U : p.TURB_V;
+#pragma unroll
+                for (int s5 = 0; s5 < ONSL; s5++) {
+                    const real *gp = tsrc + (size_t)k * g.plane + min(j0 + VW * s5 + orow, g.NJ - 1) * P + ocol;
+                    lds_dma16(gp, ob + s5 * 64 * VW);
+                }
             }
         }
     };
@@ -973,8 +987,6 @@ __global__ __launch_bounds__(FTI *TJ *(WITH_TEMP ? 2 : 1), ((TJ <= 4 && !WITH_TE
     issue(k1 - 1, 0);
     if (AHEAD >= 2 && k1 - 2 >= k0) issue(k1 - 2, 1);
     if (AHEAD >= 3 && k1 - 3 >= k0) issue(k1 - 3, 2);
-    real tbu_nx = 0.0, tbv_nx = 0.0;  // turbulent tendencies of the next level
-    if (TURB) { tbu_nx = p.TURB_U[c + (size_t)(k1 - 1) * g.plane]; tbv_nx = v_on ? p.TURB_V[c + (size_t)(k1 - 1) * g.plane] : 0.0; }
     if (n_issue > 0) wait_vmcnt((AHEAD >= 2 && k1 - AHEAD >= k0) ? n_issue : 0);        // everything but the last level issued has landed
     flux_own(0, (k1 - 1) & 1);
     lds_barrier();
@@ -988,8 +1000,6 @@ __global__ __launch_bounds__(FTI *TJ *(WITH_TEMP ? 2 : 1), ((TJ <= 4 && !WITH_TE
         // end of the iteration means exactly "level k-1 has landed"
         if (DEPTH == 1 && k - 1 >= k0 && DYC_MOM_MODE != 2) issue(k - 1, slot1);
         if (WITH_TEMP) TRACE_PT(k, 0);
-        const real tbu = tbu_nx, tbv = tbv_nx;
-        if (TURB && k - 1 >= k0) { tbu_nx = p.TURB_U[c + (size_t)(k - 1) * g.plane]; tbv_nx = v_on ? p.TURB_V[c + (size_t)(k - 1) * g.plane] : 0.0; }
         const real *db = dsm + slot * DSLOT;
         const real *fb = dsm + NS * DSLOT + (k & 1) * FSLOT;
         (void)fb;
@@ -1130,7 +1140,7 @@ __global__ __launch_bounds__(FTI *TJ *(WITH_TEMP ? 2 : 1), ((TJ <= 4 && !WITH_TE
                          pgu_b * ((pott_im1 * rds) * (svb1 * (pvb_im1_kp1 - pvtf_im1) + svb * (pvtf_im1 - pvb_im1_k)) +
                                   prs * own));
                 t = t + dif * lap_u;      // dif >= 0; 0 adds nothing
-                if (TURB) t = t + tbu;
+                if (TURB) t = t + db[OFF_TB + ty * FTI + tx];
                 tu_kp1 = t;
             }
             // =============================== dVFLXdt ===============================
@@ -1154,7 +1164,7 @@ __global__ __launch_bounds__(FTI *TJ *(WITH_TEMP ? 2 : 1), ((TJ <= 4 && !WITH_TE
                          pgv_b * ((pott_jm1 * rds) * (svb1 * (pvb_jm1_kp1 - pvtf_jm1) + svb * (pvtf_jm1 - pvb_jm1_k)) +
                                   prs * own));
                 t = t + dif * lap_v;
-                if (TURB) t = t + tbv;
+                if (TURB) t = t + db[OFF_TB + ON + ty * FTI + tx];
                 tv_kp1 = t;
             }
 #undef UF

@@ -35,9 +35,9 @@ def _physics_inputs(GR, F, i_turb, seed=4):
             F.host[n][...] = rng.uniform(lo, hi, F.host[n].shape)
 
 
-# level by level (golden_util.rel_level_err: scale = max|ref| of that level) on the full-size runs; observed margins in
+# level by level (golden_util.rel_level_err: scale = max|ref| of that level) on the full-size runs: 1e-9 for every field, observed <= 4.5e-11 (UWIND at the surface level, WWIND), QV / QC 1.6e-15;
 # profiles/r03_parity_margins.txt
-LEVEL_TOL = {'QC': 1e-8}
+LEVEL_TOL = {}
 LEVEL_STEP_TOL = 1e-9
 
 

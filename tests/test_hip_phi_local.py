@@ -1,8 +1,8 @@
-"""The optional PHI-in-the-thread path (DYCORE_LAZY_PHI=1: the LDS-DMA momentum kernel carries PHI up the column from
-the surface geopotential, k_pott_fused stores PHIVB at every 4th interface instead of PHI, everybody else gets PHI and
-PHIVB on demand from k_derive_phi) against the default path: the same step to rounding level -- NOT bit for bit (a level
-chunk starts from a stored PHIVB, an unchunked column carries its own), which is why it is not the default -- and the
-derived PHI / PHIVB a caller downloads are the default path's stored ones."""
+"""The production data flow (PHI carried up the column by the momentum kernel's threads from the surface geopotential,
+interface POTT formed in the temperature kernel's threads, PHIVB stored at every 4th interface only, PHI / PHIVB / PVTF /
+POTTVB derived on demand with the canonical forms of kernels_stage.h) against round 2's, which stores and stages PHI and
+POTTVB (DYCORE_LAZY_PHI=0): the same step to rounding level, and the on-demand fields a caller downloads are the stored
+ones to rounding level."""
 import os
 import subprocess
 import sys
@@ -39,9 +39,9 @@ def _run(tmp_path, tag, nx, ny, nz, steps, **env):
 
 @pytest.mark.parametrize('nx,ny,nz,steps', [(90, 45, 8, 3), (360, 180, 32, 2), (720, 360, 64, 2)])
 def test_phi_in_thread_equals_stored_phi_to_rounding(tmp_path, nx, ny, nz, steps):
-    # both on the two-kernel step: the whole-substep kernel reads the stored PHI by construction
-    ref = _run(tmp_path, 'stored', nx, ny, nz, steps, DYCORE_STEP_FUSED=0)
-    got = _run(tmp_path, 'local', nx, ny, nz, steps, DYCORE_STEP_FUSED=0, DYCORE_LAZY_PHI=1)
+    # both on the two-kernel step (the whole-substep kernel exists for the production data flow only)
+    ref = _run(tmp_path, 'stored', nx, ny, nz, steps, DYCORE_STEP_FUSED=0, DYCORE_LAZY_PHI=0)
+    got = _run(tmp_path, 'local', nx, ny, nz, steps, DYCORE_STEP_FUSED=0)
     for n in ref.files:
         a, b = ref[n], got[n]
         m = np.isfinite(a)

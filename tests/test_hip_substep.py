@@ -67,7 +67,7 @@ def test_fused_substep_equals_separate_kernels(tmp_path, nx, ny, nz, steps, mois
     assert info['same_ptr']
 
 
-@pytest.mark.skipif(any(k in os.environ for k in ('DYCORE_STEP_FUSED', 'DYCORE_MOM_TJ', 'DYCORE_LAZY_PHI', 'DYCORE_LAZY_PVTF', 'DYCORE_FUSED')),
+@pytest.mark.skipif(any(k in os.environ for k in ('DYCORE_STEP_FUSED', 'DYCORE_LAZY_PHI', 'DYCORE_FUSED')),
                     reason='an A/B switch of the library is set in the environment')
 def test_fused_substep_is_what_a_single_gpu_step_runs():
     from climate_model_amd import Namelist, Grid, ModelFields, HipDycore

@@ -5,8 +5,9 @@ The loop keeps one or two levels of DMA in flight and counts them itself (wait_v
 k_momentum_dma this prints, inside the innermost loop: the vmcnt waits that are not the kernel's own switch
 ladder, scratch accesses, and writes of M0 outside the DMA sequence.
 
-usage: python tools/check_mom_isa.py [extra hipcc flags, e.g. -DDYCORE_FLOAT32]      exit code 1 on a finding in a
-production instance (fluxes from the winds, no turbulence)."""
+usage: python tools/check_mom_isa.py [extra hipcc flags, e.g. -DDYCORE_FLOAT32]      exit code 1 on a finding in ANY
+instance the build contains (the shipped library holds only instances it can launch; an experiment build,
+-DDYCORE_AB_SWITCHES, also the older tile shapes and data flows)."""
 import os, re, subprocess, sys, tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -54,7 +55,7 @@ def main():
             ndma += sum('global_load_lds' in l for l in body[lo:hi])
         lo, hi = (min(a for a, b in spans), max(b for a, b in spans)) if spans else (0, 0)
         tag = 'predictor' if cur == '1' else 'corrector'
-        prod = fw == '1' and turb == '0'
+        prod = True
         print('%-9s TJ=%s fw=%s turb=%s depth=%s phi_local=%s with_temp=%s: %d level loop(s), %d DMA instructions, findings: %s' % (
             tag, tj, fw, turb, depth, pl, wt, len(spans), ndma, found or 'none'))
         if found and prod: bad = 1

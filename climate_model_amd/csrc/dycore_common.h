@@ -44,6 +44,7 @@ struct Geo {
     int pole_s, pole_n;    // this band touches the south / north wall
     int i_turb, i_rad, i_moist;
     int i_moist_clip;      // QV, QC < 0 -> 0 after the Euler step (dyn_timestep.py:145-154, the reference's accelerator path)
+    int term_off;          // DYCORE_TERM_* bits: tendency terms switched off (namelist.py:62-88); 0 on every fused path
     real pair_top;
 };
 

@@ -928,6 +928,7 @@ int dycore_create(const DycoreConfig *cfg, dycore_t **out)
         return fail(DYCORE_EINVAL, "band [%d,%d] outside the global grid of %d rows", cfg->j_offset + 1, cfg->j_offset + cfg->ny, cfg->ny_global);
     if ((double)(((cfg->nx + 3 + 63) / 64) * 64) * (cfg->ny + 3) * (cfg->nz + 1) * sizeof(real) >= 4294967296.0)
         return fail(DYCORE_EINVAL, "a field of %d x %d x %d cells is 4 GiB or more: cut the grid into latitude bands", cfg->nx, cfg->ny, cfg->nz);
+    if (cfg->term_off & ~DYCORE_TERM_ALL) return fail(DYCORE_EINVAL, "term_off = 0x%x has bits outside DYCORE_TERM_ALL", cfg->term_off);
     int ndev = 0;
     HIP_TRY(hipGetDeviceCount(&ndev));
     if (cfg->device < 0 || cfg->device >= ndev) return fail(DYCORE_EINVAL, "device %d not present (%d visible)", cfg->device, ndev);
@@ -945,11 +946,13 @@ int dycore_create(const DycoreConfig *cfg, dycore_t **out)
     g.pole_n = (cfg->j_offset + cfg->ny == cfg->ny_global);
     g.i_turb = cfg->i_turb != 0; g.i_rad = cfg->i_radiation != 0; g.i_moist = cfg->i_moist != 0;
     g.i_moist_clip = cfg->i_moist_clip != 0;
+    g.term_off = cfg->term_off;
     g.pair_top = cfg->pair_top;
     memset(&h->p, 0, sizeof h->p);
     // Switches of the shipped library ("Switches"): the documented fallback and what the parity tests
     // compare the production step with.  None of them changes a result beyond rounding.
     if (const char *e = getenv("DYCORE_FUSED")) h->fused = atoi(e) != 0;                    // 0: stage kernels for everything (the fallback)
+    if (g.term_off) h->fused = false;       // a tendency term switched off (namelist.py:62-88): the stage kernels carry the switches
     if (const char *e = getenv("DYCORE_FUSED_TURB")) h->fused_turb = atoi(e) != 0;          // 0: stage kernels for turbulence-coupled handles
     if (const char *e = getenv("DYCORE_STEP_FUSED")) h->step_fused = atoi(e) != 0;          // 0: momentum and temperature as two kernels on one GPU too (what a band runs)
     if (const char *e = getenv("DYCORE_LAZY_PHI")) h->lazy_phi = atoi(e) != 0;              // 0: PHI and POTTVB stored and staged (round 2's data flow)

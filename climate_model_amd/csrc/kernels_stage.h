@@ -57,6 +57,9 @@ __device__ __forceinline__ bool owned_cell(const Geo &g, int lin, int &i, int &j
     return i <= g.nx && j <= g.ny;
 }
 
+// a tendency term of namelist.py:62-88 is on unless its DYCORE_TERM_* bit is set (wave-uniform: g is a kernel argument)
+__device__ __forceinline__ bool term_on(const Geo &g, int bit) { return (g.term_off & bit) == 0; }
+
 // ------------------------------------------------------------------------------------
 // continuity: dyn_continuity.py:170-232.  Owned cells i in [1,nx], j in [1,ny]; the lateral
 // halo of UFLX, VFLX, WWIND, COLP_NEW (dyn_org_discretizations.py:107-117) is refreshed by
@@ -88,7 +91,7 @@ __global__ __launch_bounds__(TI *TJ) void k_continuity(Geo g, Ptrs p, real dt)
         p.FLXDIV[q] = div;
         sum += div;
     }
-    const real dcolpdt = -sum;
+    const real dcolpdt = term_on(g, DYCORE_TERM_COLP_MAIN) ? -sum : (real)0.0;       // dyn_continuity.py:211-214
     const real colp_new = p.COLP_OLD[c] + dt * dcolpdt;
     p.dCOLPdt[c] = dcolpdt;
     p.COLP_NEW[at(g, i, j, 0)] = colp_new;
@@ -115,8 +118,11 @@ __global__ __launch_bounds__(TI *TJ) void k_prepare(Geo g, Ptrs p)
     if (i > g.nx + 1 || j > g.ny + 1) return;
     const int P = g.P;
     const size_t c = at2(g, i, j);
+    // dyn_UVFLX_prepare.py:260 / :299 / :356: each group of outputs only with its term (a field that is not computed keeps
+    // what it held, as in the reference)
+    const bool vadv = term_on(g, DYCORE_TERM_UVFLX_VERT_ADV), hadv = term_on(g, DYCORE_TERM_UVFLX_HOR_ADV);
     if (j == 0) {
-        if (g.pole_s || i > g.nx + 1) return;
+        if (g.pole_s || i > g.nx + 1 || !hadv) return;
         for (int k = 0; k < g.nz; k++) {
             const size_t q = c + (size_t)k * g.plane;
             const real vs = p.VFLX[q - 1] + p.VFLX[q + P - 1] + p.VFLX[q] + p.VFLX[q + P];
@@ -143,8 +149,8 @@ __global__ __launch_bounds__(TI *TJ) void k_prepare(Geo g, Ptrs p)
             const bool in = (ii <= g.nx + 1) && (jj <= g.ny + 1);
             ca[b][a] = in ? p.COLP_NEW[at2(g, ii, jj)] * p.A[at2(g, ii, jj)] : 0.0;
         }
-    if (u_ok) { p.WWIND_UWIND[c] = 0.0; p.WWIND_UWIND[c + (size_t)g.nz * g.plane] = 0.0; }
-    if (v_ok) { p.WWIND_VWIND[c] = 0.0; p.WWIND_VWIND[c + (size_t)g.nz * g.plane] = 0.0; }
+    if (u_ok && vadv) { p.WWIND_UWIND[c] = 0.0; p.WWIND_UWIND[c + (size_t)g.nz * g.plane] = 0.0; }
+    if (v_ok && vadv) { p.WWIND_VWIND[c] = 0.0; p.WWIND_VWIND[c + (size_t)g.nz * g.plane] = 0.0; }
     if (TURB) {
         // k = 0 and k = nz: never consumed (dyn_UFLX.py:158-167); the reference returns an
         // unassigned local there (dyn_functions.py:310/377) -> 0
@@ -163,7 +169,7 @@ __global__ __launch_bounds__(TI *TJ) void k_prepare(Geo g, Ptrs p)
             // W(a,b) = COLP_NEW*A*WWIND at (i+a-1, j+b-1)
 #define WT(a, b) (ca[b][a] * p.WWIND[q + ((b) - 1) * P + ((a) - 1)])
 #define WT2(a, b) (2.0 * ca[b][a] * p.WWIND[q + ((b) - 1) * P + ((a) - 1)])
-            if (u_ok) {   // dyn_functions.py:211-270, d = i, p = j, rigid wall at the poles
+            if (u_ok && vadv) {   // dyn_functions.py:211-270, d = i, p = j, rigid wall at the poles
                 real s;
                 if (lo) s = 0.25 * (WT(0, 2) + WT(1, 2) + WT(0, 1) + WT(1, 1));
                 else if (hi) s = 0.25 * (WT(0, 1) + WT(1, 1) + WT(0, 0) + WT(1, 0));
@@ -171,7 +177,7 @@ __global__ __launch_bounds__(TI *TJ) void k_prepare(Geo g, Ptrs p)
                 const real u_ks = (ds * u_km1 + ds_km1 * u_k) / (ds + ds_km1);
                 p.WWIND_UWIND[q] = s * u_ks;
             }
-            if (v_ok) {   // d = j, p = i, no wall
+            if (v_ok && vadv) {   // d = j, p = i, no wall
                 const real s = 0.125 * (WT(2, 0) + WT(2, 1) + WT2(1, 0) + WT2(1, 1) + WT(0, 0) + WT(0, 1));
                 const real v_ks = (ds * v_km1 + ds_km1 * v_k) / (ds + ds_km1);
                 p.WWIND_VWIND[q] = s * v_ks;
@@ -214,6 +220,7 @@ __global__ __launch_bounds__(TI *TJ) void k_prepare(Geo g, Ptrs p)
         }
         u_km1 = u_k;
         v_km1 = v_k;
+        if (!hadv) continue;
         // ---- the eight Arakawa-C fluxes (dyn_functions.py:429-536) ----
         // UF/VF(a,b) at (i+a-1, j+b-1); loads outside a field's extent are not issued
 #define UF(a, b) p.UFLX[q + ((b) - 1) * P + ((a) - 1)]
@@ -299,12 +306,13 @@ __global__ __launch_bounds__(TI *TJ) void k_uflx_tendency(Geo g, Ptrs p)
 #define V(a, b) p.VWIND[q + (b) * P + (a)]
         const real u = U(0, 0), u_im1 = U(-1, 0), u_ip1 = U(1, 0);
         real t = 0.0;
+        if (term_on(g, DYCORE_TERM_UVFLX_HOR_ADV))
         t = t + (+bflx_im1 * (u_im1 + u) / 2.0 - bflx * (u + u_ip1) / 2.0
                  + cflx * (U(0, -1) + u) / 2.0 - cflx_jp1 * (u + U(0, 1)) / 2.0
                  + dflx_im1 * (U(-1, -1) + u) / 2.0 - dflx_jp1 * (u + U(1, 1)) / 2.0
                  + 1.0 * (+eflx * (U(1, -1) + u) / 2.0 - eflx_im1_jp1 * (u + U(-1, 1)) / 2.0));
         const real wu_kp1 = p.WWIND_UWIND[q + g.plane];
-        t = t + (wu_k - wu_kp1) / p.dsigma[k];
+        if (term_on(g, DYCORE_TERM_UVFLX_VERT_ADV)) t = t + (wu_k - wu_kp1) / p.dsigma[k];
         wu_k = wu_kp1;
         if (TURB) {
 #define PV(a, b, kk) p.PHIVB[q + (size_t)(kk) * g.plane + (b) * P + (a)]
@@ -323,19 +331,21 @@ __global__ __launch_bounds__(TI *TJ) void k_uflx_tendency(Geo g, Ptrs p)
 #undef RH
         }
         // Coriolis + metric: dyn_UFLX.py:39-66
+        if (term_on(g, DYCORE_TERM_UVFLX_CORIOLIS))
         t = t + CON_RE * dlon * dlat / 2.0 *
                     (colp_im1 * (V(-1, 0) + V(-1, 1)) / 2.0 * (corf * CON_RE * coslat + (u_im1 + u) / 2.0 * sinlat) +
                      colp * (V(0, 0) + V(0, 1)) / 2.0 * (corf * CON_RE * coslat + (u + u_ip1) / 2.0 * sinlat));
         const real pvb_kp1 = p.PVTFVB[q + g.plane], pvb_im1_kp1 = p.PVTFVB[q + g.plane - 1];
+        if (term_on(g, DYCORE_TERM_UVFLX_PRE_GRAD))
         t = t + pre_grad(p.PHI[q], p.PHI[q - 1], colp, colp_im1, p.POTT[q], p.POTT[q - 1],
                          p.PVTF[q], p.PVTF[q - 1], pvb_k, pvb_im1_k, pvb_im1_kp1, pvb_kp1,
                          p.dsigma[k], p.sigma_vb[k], p.sigma_vb[k + 1], dyis);
         pvb_k = pvb_kp1;
         pvb_im1_k = pvb_im1_kp1;
         const real dif = p.UVFLX_dif_coef[k];
-        if (dif > 0.0)
+        if (dif > 0.0 && term_on(g, DYCORE_TERM_UVFLX_NUM_DIF))
             t = t + dif * (p.UFLX[q - 1] + p.UFLX[q + 1] + p.UFLX[q - P] + p.UFLX[q + P] - 4.0 * p.UFLX[q]);
-        p.dUFLXdt[q] = t;
+        p.dUFLXdt[q] = term_on(g, DYCORE_TERM_UVFLX_MAIN) ? t : (real)0.0;       // dyn_UFLX.py:115-117
 #undef U
 #undef V
     }
@@ -373,12 +383,13 @@ __global__ __launch_bounds__(TI *TJ) void k_vflx_tendency(Geo g, Ptrs p, int jlo
 #define V(a, b) p.VWIND[q + (b) * P + (a)]
         const real v = V(0, 0);
         real t = 0.0;
+        if (term_on(g, DYCORE_TERM_UVFLX_HOR_ADV))
         t = t + (+rflx_jm1 * (V(0, -1) + v) / 2.0 - rflx * (v + V(0, 1)) / 2.0
                  + qflx * (V(-1, 0) + v) / 2.0 - qflx_ip1 * (v + V(1, 0)) / 2.0
                  + sflx_jm1 * (V(-1, -1) + v) / 2.0 - sflx_ip1 * (v + V(1, 1)) / 2.0
                  + -1.0 * (+tflx * (V(-1, 1) + v) / 2.0 - tflx_ip1_jm1 * (v + V(1, -1)) / 2.0));
         const real wv_kp1 = p.WWIND_VWIND[q + g.plane];
-        t = t + (wv_k - wv_kp1) / p.dsigma[k];
+        if (term_on(g, DYCORE_TERM_UVFLX_VERT_ADV)) t = t + (wv_k - wv_kp1) / p.dsigma[k];
         wv_k = wv_kp1;
         if (TURB) {
 #define PV(a, b, kk) p.PHIVB[q + (size_t)(kk) * g.plane + (b) * P + (a)]
@@ -398,19 +409,21 @@ __global__ __launch_bounds__(TI *TJ) void k_vflx_tendency(Geo g, Ptrs p, int jlo
         }
         // Coriolis + metric: dyn_VFLX.py:39-64
         const real ub_jm1 = (U(0, -1) + U(1, -1)) / 2.0, ub = (U(0, 0) + U(1, 0)) / 2.0;
+        if (term_on(g, DYCORE_TERM_UVFLX_CORIOLIS))
         t = t + -CON_RE * dlon * dlat / 2.0 *
                     (colp_jm1 * ub_jm1 * (corf_jm1 * CON_RE * coslat_jm1 + ub_jm1 * sinlat_jm1) +
                      colp * ub * (corf * CON_RE * coslat + ub * sinlat));
         const real pvb_kp1 = p.PVTFVB[q + g.plane], pvb_jm1_kp1 = p.PVTFVB[q + g.plane - P];
+        if (term_on(g, DYCORE_TERM_UVFLX_PRE_GRAD))
         t = t + pre_grad(p.PHI[q], p.PHI[q - P], colp, colp_jm1, p.POTT[q], p.POTT[q - P],
                          p.PVTF[q], p.PVTF[q - P], pvb_k, pvb_jm1_k, pvb_jm1_kp1, pvb_kp1,
                          p.dsigma[k], p.sigma_vb[k], p.sigma_vb[k + 1], dxjs);
         pvb_k = pvb_kp1;
         pvb_jm1_k = pvb_jm1_kp1;
         const real dif = p.UVFLX_dif_coef[k];
-        if (dif > 0.0)
+        if (dif > 0.0 && term_on(g, DYCORE_TERM_UVFLX_NUM_DIF))
             t = t + dif * (p.VFLX[q - 1] + p.VFLX[q + 1] + p.VFLX[q - P] + p.VFLX[q + P] - 4.0 * p.VFLX[q]);
-        p.dVFLXdt[q] = t;
+        p.dVFLXdt[q] = term_on(g, DYCORE_TERM_UVFLX_MAIN) ? t : (real)0.0;
 #undef U
 #undef V
     }
@@ -437,10 +450,12 @@ __global__ __launch_bounds__(TI *TJ) void k_pott_tendency(Geo g, Ptrs p)
         const real pt = p.POTT[q];
         const real p_im1 = p.POTT[q - 1], p_ip1 = p.POTT[q + 1], p_jm1 = p.POTT[q - P], p_jp1 = p.POTT[q + P];
         real t = 0.0;
+        if (term_on(g, DYCORE_TERM_POTT_HOR_ADV))
         t = t + (+p.UFLX[q] * (p_im1 + pt) / 2.0 - p.UFLX[q + 1] * (pt + p_ip1) / 2.0
                  + p.VFLX[q] * (p_jm1 + pt) / 2.0 - p.VFLX[q + P] * (pt + p_jp1) / 2.0) / area;
         const real w_kp1 = p.WWIND[q + g.plane], pvb_kp1 = p.POTTVB[q + g.plane];
-        if (k == 0) t = t + colp_new * (-w_kp1 * pvb_kp1) / p.dsigma[k];
+        if (!term_on(g, DYCORE_TERM_POTT_VERT_ADV)) { }
+        else if (k == 0) t = t + colp_new * (-w_kp1 * pvb_kp1) / p.dsigma[k];
         else t = t + colp_new * (+w_k * pvb_k - w_kp1 * pvb_kp1) / p.dsigma[k];
         w_k = w_kp1;
         pvb_k = pvb_kp1;
@@ -470,10 +485,10 @@ __global__ __launch_bounds__(TI *TJ) void k_pott_tendency(Geo g, Ptrs p)
         }
         pott_km1 = pt;
         const real dif = p.POTT_dif_coef[k];
-        if (dif > 0.0)
+        if (dif > 0.0 && term_on(g, DYCORE_TERM_POTT_NUM_DIF))
             t = t + dif * (c_im1 * p_im1 + c_ip1 * p_ip1 + c_jm1 * p_jm1 + c_jp1 * p_jp1 - 4.0 * colp * pt);
         if (g.i_rad) t = t + p.dPOTTdt_RAD[q] * colp;
-        p.dPOTTdt[q] = t;
+        p.dPOTTdt[q] = term_on(g, DYCORE_TERM_POTT_MAIN) ? t : (real)0.0;        // dyn_POTT.py:70-72
     }
 }
 
@@ -616,8 +631,11 @@ __global__ __launch_bounds__(TI *TJ) void k_moist(Geo g, Ptrs p, const real *qv_
             const real adv = (+uflx * (x_im1 + x) / 2.0 - uflx_ip1 * (x + x_ip1) / 2.0
                                 + vflx * (x_jm1 + x) / 2.0 - vflx_jp1 * (x + x_jp1) / 2.0);
             // fused step (EULER): per-column / per-level divisors as reciprocals, as in k_pott_fused
-            d = d + (EULER ? adv * r_area : adv / area);
-            if (k == 0) d = d + (EULER ? colp_new * (-f_kp1) * rds : colp_new * (-f_kp1) / ds);
+            // (the per-term switches of dyn_moist.py:70-115 are consulted by the stage instances only: a handle with a
+            // term switched off never takes the fused step)
+            if (EULER || term_on(g, DYCORE_TERM_MOIST_HOR_ADV)) d = d + (EULER ? adv * r_area : adv / area);
+            if (!EULER && !term_on(g, DYCORE_TERM_MOIST_VERT_ADV)) { }
+            else if (k == 0) d = d + (EULER ? colp_new * (-f_kp1) * rds : colp_new * (-f_kp1) / ds);
             else d = d + (EULER ? colp_new * (+f_k - f_kp1) * rds : colp_new * (+f_k - f_kp1) / ds);
             if (TURB) {
                 const real tb = turb_flux(p.PHI[q], last ? 0.0 : p.PHI[q + g.plane], phi_km1, p.PHIVB[q], p.PHIVB[q + g.plane],
@@ -628,7 +646,7 @@ __global__ __launch_bounds__(TI *TJ) void k_moist(Geo g, Ptrs p, const real *qv_
                 if (s == 0 && !EULER) p.dQVdt_TURB[q] = tb;
             }
             if (TURB_PRE) d = d + (s == 0 ? p.TURB_QV[q] : p.TURB_QC[q]);
-            if (dif > 0.0)
+            if (dif > 0.0 && (EULER || term_on(g, DYCORE_TERM_MOIST_NUM_DIF)))
                 d = d + dif * (c_im1 * x_im1 + c_ip1 * x_ip1 + c_jm1 * x_jm1 + c_jp1 * x_jp1 - 4.0 * colp * x);
             tq[s] = d;
         }

@@ -22,7 +22,7 @@ class DycoreConfig(C.Structure):
     _fields_ = [('abi_version', C.c_int32), ('nx', C.c_int32), ('ny', C.c_int32), ('nz', C.c_int32),
                 ('ny_global', C.c_int32), ('j_offset', C.c_int32), ('device', C.c_int32),
                 ('i_turb', C.c_int32), ('i_radiation', C.c_int32), ('i_moist', C.c_int32), ('i_moist_clip', C.c_int32),
-                ('reserved', C.c_int32 * 5),
+                ('term_off', C.c_int32), ('reserved', C.c_int32 * 4),
                 ('pair_top', C.c_double), ('stream', C.c_void_p)]
 
 
@@ -166,7 +166,7 @@ class HipDycore:
     """One dycore handle = one GPU (or one latitude band of a decomposed grid)."""
 
     def __init__(self, nx, ny, nz, pair_top=10000., i_turb=0, i_radiation=0, device=0,
-                 ny_global=None, j_offset=0, stream=None, i_moist=0, i_moist_clip=0, dtype=np.float64):
+                 ny_global=None, j_offset=0, stream=None, i_moist=0, i_moist_clip=0, dtype=np.float64, term_off=0):
         self.dtype = np.dtype(dtype)
         if self.dtype not in (np.dtype(np.float64), np.dtype(np.float32)):
             raise ValueError("working precision is 'float64' or 'float32' (io_read_namelist.py:47-53)")
@@ -183,6 +183,7 @@ class HipDycore:
         cfg.i_radiation = int(bool(i_radiation))
         cfg.i_moist = int(bool(i_moist))
         cfg.i_moist_clip = int(bool(i_moist_clip))
+        cfg.term_off = int(term_off)        # DYCORE_TERM_* bits (namelist.TERM_BITS): tendency terms switched off
         cfg.pair_top = float(pair_top)
         cfg.stream = C.c_void_p(stream) if stream else None
         self._h = C.c_void_p()
@@ -190,6 +191,17 @@ class HipDycore:
         self.i_turb = bool(i_turb)
         self.i_moist = bool(i_moist)
         self.i_radiation = bool(i_radiation)
+        self.term_off = int(term_off)
+
+    @classmethod
+    def from_namelist(cls, GR, **kw):
+        """A handle configured the way the reference's kernels are by `namelist.py`: extents from the grid, the coupling
+        and per-term switches (namelist.py:62-88), pair_top and the working precision from GR.nl."""
+        nl = GR.nl
+        args = dict(pair_top=nl.pair_top, i_turb=nl.i_turb, i_radiation=nl.i_POTT_radiation, i_moist=nl.i_moist_main_switch,
+                    i_moist_clip=nl.i_moist_clip, term_off=nl.term_off, dtype=nl.wp)
+        args.update(kw)
+        return cls(GR.nx, kw.pop('ny', GR.ny) if 'ny' in kw else GR.ny, GR.nz, **{k: v for k, v in args.items() if k != 'ny'})
 
     # ---- plumbing ----
     def _check(self, rc):

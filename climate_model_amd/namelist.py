@@ -24,6 +24,16 @@ def uvflx_dif_coef_for(dlat_deg):
     return c * 2.0
 
 
+# include/dycore.h DYCORE_TERM_*: bit of DycoreConfig.term_off <- the namelist entry that, set to 0, switches the term off
+TERM_BITS = {
+    'i_COLP_main_switch': 1 << 0,
+    'i_UVFLX_main_switch': 1 << 1, 'i_UVFLX_hor_adv': 1 << 2, 'i_UVFLX_vert_adv': 1 << 3, 'i_UVFLX_coriolis': 1 << 4,
+    'i_UVFLX_pre_grad': 1 << 5, 'i_UVFLX_num_dif': 1 << 6,
+    'i_POTT_main_switch': 1 << 7, 'i_POTT_hor_adv': 1 << 8, 'i_POTT_vert_adv': 1 << 9, 'i_POTT_num_dif': 1 << 10,
+    'i_moist_hor_adv': 1 << 11, 'i_moist_vert_adv': 1 << 12, 'i_moist_num_dif': 1 << 13,
+}
+
+
 @dataclass
 class Namelist:
     # grid (namelist.py:30-40, 243-278)
@@ -40,6 +50,23 @@ class Namelist:
     # turbulence/radiation couplings off (their inputs are identically zero).
     i_UVFLX_vert_turb: int = 0
     i_POTT_vert_turb: int = 0
+    # per-term switches (namelist.py:62-88, all 1 in the reference's shipped file).  A run with any of them at 0 steps on
+    # the stage kernels, where the reference consumes them (dyn_UFLX.py:117-193, dyn_VFLX.py:115-192, dyn_POTT.py:72-108,
+    # dyn_moist.py:68-115, dyn_continuity.py:211, dyn_UVFLX_prepare.py:260-356); they travel as DycoreConfig.term_off
+    i_COLP_main_switch: int = 1
+    i_UVFLX_main_switch: int = 1
+    i_UVFLX_hor_adv: int = 1
+    i_UVFLX_vert_adv: int = 1
+    i_UVFLX_coriolis: int = 1
+    i_UVFLX_num_dif: int = 1
+    i_UVFLX_pre_grad: int = 1
+    i_POTT_main_switch: int = 1
+    i_POTT_hor_adv: int = 1
+    i_POTT_vert_adv: int = 1
+    i_POTT_num_dif: int = 1
+    i_moist_hor_adv: int = 1
+    i_moist_vert_adv: int = 1
+    i_moist_num_dif: int = 1
     i_POTT_radiation: int = 0
     i_moist_main_switch: int = 0        # dyn_moist: QV/QC advection (namelist.py:80)
     # QV, QC < 0 -> 0 after every Euler step: what the reference's accelerator kernel does (dyn_timestep.py:145-154,
@@ -85,6 +112,15 @@ class Namelist:
         when they are handed to a float32 handle."""
         import numpy as np
         return np.dtype(self.working_precision)
+
+    @property
+    def term_off(self):
+        """DycoreConfig.term_off: one bit per namelist entry of TERM_BITS that is 0."""
+        m = 0
+        for name, bit in TERM_BITS.items():
+            if not getattr(self, name):
+                m |= bit
+        return m
 
     @property
     def i_turb(self):

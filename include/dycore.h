@@ -57,6 +57,26 @@ typedef double dycore_real_t;
 #endif
 int dycore_real_bytes(void);
 
+/* Per-term dynamics switches (namelist.py:62-88), consumed where the reference consumes them: dyn_continuity.py:211,
+ * dyn_UVFLX_prepare.py:260-356 and dyn_org_discretizations.py:144, dyn_UFLX.py:117-193, dyn_VFLX.py:115-192,
+ * dyn_POTT.py:72-108, dyn_moist.py:68-115.  A set bit means "that namelist entry is 0".  The vertical-turbulence entries
+ * travel as DycoreConfig.i_turb, i_POTT_radiation as i_radiation, i_moist_main_switch as i_moist. */
+#define DYCORE_TERM_COLP_MAIN       (1 << 0)
+#define DYCORE_TERM_UVFLX_MAIN      (1 << 1)
+#define DYCORE_TERM_UVFLX_HOR_ADV   (1 << 2)
+#define DYCORE_TERM_UVFLX_VERT_ADV  (1 << 3)
+#define DYCORE_TERM_UVFLX_CORIOLIS  (1 << 4)
+#define DYCORE_TERM_UVFLX_PRE_GRAD  (1 << 5)
+#define DYCORE_TERM_UVFLX_NUM_DIF   (1 << 6)
+#define DYCORE_TERM_POTT_MAIN       (1 << 7)
+#define DYCORE_TERM_POTT_HOR_ADV    (1 << 8)
+#define DYCORE_TERM_POTT_VERT_ADV   (1 << 9)
+#define DYCORE_TERM_POTT_NUM_DIF    (1 << 10)
+#define DYCORE_TERM_MOIST_HOR_ADV   (1 << 11)
+#define DYCORE_TERM_MOIST_VERT_ADV  (1 << 12)
+#define DYCORE_TERM_MOIST_NUM_DIF   (1 << 13)
+#define DYCORE_TERM_ALL             ((1 << 14) - 1)
+
 /* Replaces the module-level globals the reference freezes into its kernels:
  * main_grid.py:42-51 (extents), namelist.py:62-88 (switches), pair_top. */
 typedef struct DycoreConfig {
@@ -73,7 +93,10 @@ typedef struct DycoreConfig {
     int32_t i_moist_clip;  /* != 0: QV, QC < 0 -> 0 after every Euler step, the rule of the reference's accelerator
                             * kernel (dyn_timestep.py:145-154); 0 = its CPU kernel (:291-296), which does not clip
                             * and which the parity fixtures follow */
-    int32_t reserved[5];
+    int32_t term_off;      /* bit mask of DYCORE_TERM_*: tendency terms switched OFF (namelist.py:62-88: the i_*_main_switch /
+                            * _hor_adv / _vert_adv / _coriolis / _pre_grad / _num_dif entries set to 0).  0 = the reference's
+                            * default, every term on.  A handle with any bit set steps on the stage kernels. */
+    int32_t reserved[4];
     double  pair_top;      /* model-top pressure [Pa] (namelist.py:37)                  */
     void   *stream;        /* hipStream_t to issue work on; NULL = handle creates one   */
 } DycoreConfig;

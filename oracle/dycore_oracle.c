@@ -84,6 +84,7 @@ void oracle_exchange_bc(const oracle_cfg *c, real *F, int stgx, int stgy, int nk
 
 /* ------------------------------------------------------------------------- */
 /* dyn_continuity.py:40-47 (formulae), :170-232 (loops) */
+#define TERM_ON(c, bit) (((c)->term_off & (bit)) == 0)
 void oracle_continuity(const oracle_cfg *c, const oracle_grid *g, oracle_fields *f, double dt)
 {
     const int nx = c->nx, ny = c->ny, nz = c->nz, nzs = nz + 1;
@@ -110,7 +111,7 @@ void oracle_continuity(const oracle_cfg *c, const oracle_grid *g, oracle_fields 
                 AT(f->FLXDIV, i, j, k, 0, nz) = div;
                 sum += div;
             }
-            const real dcolpdt = -sum;                               /* :212 */
+            const real dcolpdt = TERM_ON(c, ORACLE_TERM_COLP_MAIN) ? -sum : (real)0.0;   /* :211-214 */
             const real colp_new = A2(f->COLP_OLD, i, j) + dt * dcolpdt; /* :218 */
             A2(f->dCOLPdt, i, j) = dcolpdt;
             A2(f->COLP_NEW, i, j) = colp_new;
@@ -132,8 +133,9 @@ void oracle_uvflx_prepare(const oracle_cfg *c, const oracle_grid *g, oracle_fiel
     const int nthr = nthreads_of(c);
     (void)nthr;
     /* ---- WWIND_UWIND (:262-280), rigid wall at j = 1 and j = ny ---- */
+    const int vadv = TERM_ON(c, ORACLE_TERM_UVFLX_VERT_ADV), hadv = TERM_ON(c, ORACLE_TERM_UVFLX_HOR_ADV);   /* :260, :356 */
     PAR_FOR
-    for (int i = 1; i < nx + 2; i++)
+    for (int i = 1; i < (vadv ? nx + 2 : 0); i++)
         for (int j = 1; j < ny + 1; j++) {
             AT(f->WWIND_UWIND, i, j, 0, 0, nzs) = 0.0;
             AT(f->WWIND_UWIND, i, j, nz, 0, nzs) = 0.0;
@@ -163,7 +165,7 @@ void oracle_uvflx_prepare(const oracle_cfg *c, const oracle_grid *g, oracle_fiel
         }
     /* ---- WWIND_VWIND (:282-300), no wall variant ---- */
     PAR_FOR
-    for (int i = 1; i < nx + 1; i++)
+    for (int i = 1; i < (vadv ? nx + 1 : 0); i++)
         for (int j = 1; j < ny + 2; j++) {
             AT(f->WWIND_VWIND, i, j, 0, 1, nzs) = 0.0;
             AT(f->WWIND_VWIND, i, j, nz, 1, nzs) = 0.0;
@@ -234,7 +236,7 @@ void oracle_uvflx_prepare(const oracle_cfg *c, const oracle_grid *g, oracle_fiel
 #define UF(ii, jj) AT(f->UFLX, ii, jj, k, 0, nz)
 #define VF(ii, jj) AT(f->VFLX, ii, jj, k, 1, nz)
     PAR_FOR
-    for (int i = 1; i < nx + 2; i++)
+    for (int i = 1; i < (hadv ? nx + 2 : 0); i++)
         for (int j = 1; j < ny + 2; j++)
             for (int k = 0; k < nz; k++) {
                 /* (is,js): CFLX, QFLX */
@@ -319,11 +321,13 @@ void oracle_uflx_tendency(const oracle_cfg *c, const oracle_grid *g, oracle_fiel
                 const real u = U(i, j);
                 real t = 0.0;
                 /* horizontal advection, dyn_functions.py:541-572, sign +1 */
+                if (TERM_ON(c, ORACLE_TERM_UVFLX_HOR_ADV))
                 t = t + (+bflx_im1 * (U(i - 1, j) + u) / 2.0 - bflx * (u + U(i + 1, j)) / 2.0
                          + cflx * (U(i, j - 1) + u) / 2.0 - cflx_jp1 * (u + U(i, j + 1)) / 2.0
                          + dflx_im1 * (U(i - 1, j - 1) + u) / 2.0 - dflx_jp1 * (u + U(i + 1, j + 1)) / 2.0
                          + 1.0 * (+eflx * (U(i + 1, j - 1) + u) / 2.0 - eflx_im1_jp1 * (u + U(i - 1, j + 1)) / 2.0));
                 /* vertical advection */
+                if (TERM_ON(c, ORACLE_TERM_UVFLX_VERT_ADV))
                 t = t + (AT(f->WWIND_UWIND, i, j, k, 0, nzs) - AT(f->WWIND_UWIND, i, j, k + 1, 0, nzs)) / g->dsigma[k];
                 /* vertical turbulent transport (:137-170); interp_VAR_ds already divides by g,
                  * ALTVB is divided by g a second time, RHO and SMOMXFLX once (reference quirk) */
@@ -344,12 +348,14 @@ void oracle_uflx_tendency(const oracle_cfg *c, const oracle_grid *g, oracle_fiel
 #undef RH
                 }
                 /* Coriolis + spherical metric, dyn_UFLX.py:39-66 */
+                if (TERM_ON(c, ORACLE_TERM_UVFLX_CORIOLIS))
                 t = t + CON_RE * dlon * dlat / 2.0 *
                             (colp_im1 * (V(i - 1, j) + V(i - 1, j + 1)) / 2.0 *
                                  (corf * CON_RE * cos(lat) + (U(i - 1, j) + u) / 2.0 * sin(lat)) +
                              colp * (V(i, j) + V(i, j + 1)) / 2.0 *
                                  (corf * CON_RE * cos(lat) + (u + U(i + 1, j)) / 2.0 * sin(lat)));
                 /* pressure gradient */
+                if (TERM_ON(c, ORACLE_TERM_UVFLX_PRE_GRAD))
                 t = t + pre_grad(AT(f->PHI, i, j, k, 0, nz), AT(f->PHI, i - 1, j, k, 0, nz), colp, colp_im1,
                                  AT(f->POTT, i, j, k, 0, nz), AT(f->POTT, i - 1, j, k, 0, nz),
                                  AT(f->PVTF, i, j, k, 0, nz), AT(f->PVTF, i - 1, j, k, 0, nz),
@@ -357,12 +363,12 @@ void oracle_uflx_tendency(const oracle_cfg *c, const oracle_grid *g, oracle_fiel
                                  AT(f->PVTFVB, i - 1, j, k + 1, 0, nzs), AT(f->PVTFVB, i, j, k + 1, 0, nzs),
                                  g->dsigma[k], g->sigma_vb[k], g->sigma_vb[k + 1], dyis);
                 /* horizontal diffusion, dyn_functions.py:158-170 */
-                if (g->UVFLX_dif_coef[k] > 0.0)
+                if (g->UVFLX_dif_coef[k] > 0.0 && TERM_ON(c, ORACLE_TERM_UVFLX_NUM_DIF))
                     t = t + g->UVFLX_dif_coef[k] *
                                 (AT(f->UFLX, i - 1, j, k, 0, nz) + AT(f->UFLX, i + 1, j, k, 0, nz) +
                                  AT(f->UFLX, i, j - 1, k, 0, nz) + AT(f->UFLX, i, j + 1, k, 0, nz) -
                                  4.0 * AT(f->UFLX, i, j, k, 0, nz));
-                AT(f->dUFLXdt, i, j, k, 0, nz) = t;
+                AT(f->dUFLXdt, i, j, k, 0, nz) = TERM_ON(c, ORACLE_TERM_UVFLX_MAIN) ? t : (real)0.0;   /* dyn_UFLX.py:115-117 */
             }
         }
     }
@@ -401,10 +407,12 @@ void oracle_vflx_tendency(const oracle_cfg *c, const oracle_grid *g, oracle_fiel
                 const real v = V(i, j);
                 real t = 0.0;
                 /* horizontal advection, sign -1 on the T term */
+                if (TERM_ON(c, ORACLE_TERM_UVFLX_HOR_ADV))
                 t = t + (+rflx_jm1 * (V(i, j - 1) + v) / 2.0 - rflx * (v + V(i, j + 1)) / 2.0
                          + qflx * (V(i - 1, j) + v) / 2.0 - qflx_ip1 * (v + V(i + 1, j)) / 2.0
                          + sflx_jm1 * (V(i - 1, j - 1) + v) / 2.0 - sflx_ip1 * (v + V(i + 1, j + 1)) / 2.0
                          + -1.0 * (+tflx * (V(i - 1, j + 1) + v) / 2.0 - tflx_ip1_jm1 * (v + V(i + 1, j - 1)) / 2.0));
+                if (TERM_ON(c, ORACLE_TERM_UVFLX_VERT_ADV))
                 t = t + (AT(f->WWIND_VWIND, i, j, k, 1, nzs) - AT(f->WWIND_VWIND, i, j, k + 1, 1, nzs)) / g->dsigma[k];
                 if (c->i_turb) {
 #define PV(ii, jj, kk) AT(f->PHIVB, ii, jj, kk, 0, nzs)
@@ -423,23 +431,25 @@ void oracle_vflx_tendency(const oracle_cfg *c, const oracle_grid *g, oracle_fiel
 #undef RH
                 }
                 /* Coriolis + metric, dyn_VFLX.py:39-64 */
+                if (TERM_ON(c, ORACLE_TERM_UVFLX_CORIOLIS))
                 t = t + -CON_RE * dlon * dlat / 2.0 *
                             (colp_jm1 * (U(i, j - 1) + U(i + 1, j - 1)) / 2.0 *
                                  (corf_jm1 * CON_RE * cos(lat_jm1) + (U(i, j - 1) + U(i + 1, j - 1)) / 2.0 * sin(lat_jm1)) +
                              colp * (U(i, j) + U(i + 1, j)) / 2.0 *
                                  (corf * CON_RE * cos(lat) + (U(i, j) + U(i + 1, j)) / 2.0 * sin(lat)));
+                if (TERM_ON(c, ORACLE_TERM_UVFLX_PRE_GRAD))
                 t = t + pre_grad(AT(f->PHI, i, j, k, 0, nz), AT(f->PHI, i, j - 1, k, 0, nz), colp, colp_jm1,
                                  AT(f->POTT, i, j, k, 0, nz), AT(f->POTT, i, j - 1, k, 0, nz),
                                  AT(f->PVTF, i, j, k, 0, nz), AT(f->PVTF, i, j - 1, k, 0, nz),
                                  AT(f->PVTFVB, i, j, k, 0, nzs), AT(f->PVTFVB, i, j - 1, k, 0, nzs),
                                  AT(f->PVTFVB, i, j - 1, k + 1, 0, nzs), AT(f->PVTFVB, i, j, k + 1, 0, nzs),
                                  g->dsigma[k], g->sigma_vb[k], g->sigma_vb[k + 1], dxjs);
-                if (g->UVFLX_dif_coef[k] > 0.0)
+                if (g->UVFLX_dif_coef[k] > 0.0 && TERM_ON(c, ORACLE_TERM_UVFLX_NUM_DIF))
                     t = t + g->UVFLX_dif_coef[k] *
                                 (AT(f->VFLX, i - 1, j, k, 1, nz) + AT(f->VFLX, i + 1, j, k, 1, nz) +
                                  AT(f->VFLX, i, j - 1, k, 1, nz) + AT(f->VFLX, i, j + 1, k, 1, nz) -
                                  4.0 * AT(f->VFLX, i, j, k, 1, nz));
-                AT(f->dVFLXdt, i, j, k, 1, nz) = t;
+                AT(f->dVFLXdt, i, j, k, 1, nz) = TERM_ON(c, ORACLE_TERM_UVFLX_MAIN) ? t : (real)0.0;
             }
         }
     }
@@ -466,12 +476,13 @@ void oracle_pott_tendency(const oracle_cfg *c, const oracle_grid *g, oracle_fiel
                 const real p = P(i, j, k);
                 real t = 0.0;
                 /* hor_adv_py, dyn_functions.py:105-114 */
+                if (TERM_ON(c, ORACLE_TERM_POTT_HOR_ADV))
                 t = t + (+AT(f->UFLX, i, j, k, 0, nz) * (P(i - 1, j, k) + p) / 2.0
                          - AT(f->UFLX, i + 1, j, k, 0, nz) * (p + P(i + 1, j, k)) / 2.0
                          + AT(f->VFLX, i, j, k, 1, nz) * (P(i, j - 1, k) + p) / 2.0
                          - AT(f->VFLX, i, j + 1, k, 1, nz) * (p + P(i, j + 1, k)) / 2.0) / area;
                 /* vert_adv_py, dyn_functions.py:118-138 */
-                {
+                if (TERM_ON(c, ORACLE_TERM_POTT_VERT_ADV)) {
                     const real w_kp1 = AT(f->WWIND, i, j, k + 1, 0, nzs), pvb_kp1 = AT(f->POTTVB, i, j, k + 1, 0, nzs);
                     if (k == 0)
                         t = t + colp_new * (-w_kp1 * pvb_kp1) / g->dsigma[k];
@@ -504,11 +515,11 @@ void oracle_pott_tendency(const oracle_cfg *c, const oracle_grid *g, oracle_fiel
                     AT(f->dPOTTdt_TURB, i, j, k, 0, nz) = turb / colp * 3600.0;   /* dyn_POTT.py:93-94 */
                 }
                 /* num_dif_pw_py, dyn_functions.py:142-155 */
-                if (g->POTT_dif_coef[k] > 0.0)
+                if (g->POTT_dif_coef[k] > 0.0 && TERM_ON(c, ORACLE_TERM_POTT_NUM_DIF))
                     t = t + g->POTT_dif_coef[k] * (+c_im1 * P(i - 1, j, k) + c_ip1 * P(i + 1, j, k) + c_jm1 * P(i, j - 1, k) + c_jp1 * P(i, j + 1, k) - 4.0 * colp * p);
                 if (c->i_radiation)
                     t = t + AT(f->dPOTTdt_RAD, i, j, k, 0, nz) * colp;
-                AT(f->dPOTTdt, i, j, k, 0, nz) = t;
+                AT(f->dPOTTdt, i, j, k, 0, nz) = TERM_ON(c, ORACLE_TERM_POTT_MAIN) ? t : (real)0.0;   /* dyn_POTT.py:70-72 */
             }
         }
 #undef P
@@ -575,10 +586,11 @@ void oracle_moist_tendency(const oracle_cfg *c, const oracle_grid *g, oracle_fie
                     const real q_im1 = QA(i - 1, j, k), q_ip1 = QA(i + 1, j, k), q_jm1 = QA(i, j - 1, k), q_jp1 = QA(i, j + 1, k);
                     real d = 0.0;
                     /* hor_adv_py */
+                    if (TERM_ON(c, ORACLE_TERM_MOIST_HOR_ADV))
                     d = d + (+uflx * (q_im1 + q) / 2.0 - uflx_ip1 * (q + q_ip1) / 2.0
                              + vflx * (q_jm1 + q) / 2.0 - vflx_jp1 * (q + q_jp1) / 2.0) / area;
                     /* vertical advection with log-interpolated interface values */
-                    {
+                    if (TERM_ON(c, ORACLE_TERM_MOIST_VERT_ADV)) {
                         real flux_kp1 = 0.0;                           /* W[nz] * (unchecked read) = 0 */
                         if (k < nz - 1) flux_kp1 = w_kp1 * varvb_log(QA(i, j, k + 1), q);
                         if (k == 0)
@@ -599,7 +611,7 @@ void oracle_moist_tendency(const oracle_cfg *c, const oracle_grid *g, oracle_fie
                         d = d + tb;
                         if (s == 0) turb_qv = tb;
                     }
-                    if (dif > 0.0)
+                    if (dif > 0.0 && TERM_ON(c, ORACLE_TERM_MOIST_NUM_DIF))
                         d = d + dif * (+c_im1 * q_im1 + c_ip1 * q_ip1 + c_jm1 * q_jm1 + c_jp1 * q_jp1 - 4.0 * colp * q);
                     t[s] = d;
 #undef QA

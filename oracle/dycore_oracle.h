@@ -42,7 +42,18 @@ typedef struct {
     int i_moist;       /* i_moist_main_switch (namelist.py:80): QV/QC advection     */
     int i_moist_clip;  /* QV, QC < 0 -> 0 after the Euler step: the rule of the reference's GPU kernel
                           (dyn_timestep.py:145-154); its CPU kernel (:291-296) does not clip       */
+    int term_off;      /* ORACLE_TERM_* bits: namelist.py:62-88 entries set to 0 (same bits as DYCORE_TERM_* of
+                          include/dycore.h, restated here: the oracle shares no header with the product)  */
 } oracle_cfg;
+
+enum {
+    ORACLE_TERM_COLP_MAIN = 1 << 0,
+    ORACLE_TERM_UVFLX_MAIN = 1 << 1, ORACLE_TERM_UVFLX_HOR_ADV = 1 << 2, ORACLE_TERM_UVFLX_VERT_ADV = 1 << 3,
+    ORACLE_TERM_UVFLX_CORIOLIS = 1 << 4, ORACLE_TERM_UVFLX_PRE_GRAD = 1 << 5, ORACLE_TERM_UVFLX_NUM_DIF = 1 << 6,
+    ORACLE_TERM_POTT_MAIN = 1 << 7, ORACLE_TERM_POTT_HOR_ADV = 1 << 8, ORACLE_TERM_POTT_VERT_ADV = 1 << 9,
+    ORACLE_TERM_POTT_NUM_DIF = 1 << 10,
+    ORACLE_TERM_MOIST_HOR_ADV = 1 << 11, ORACLE_TERM_MOIST_VERT_ADV = 1 << 12, ORACLE_TERM_MOIST_NUM_DIF = 1 << 13
+};
 
 /* grid constants: main_grid.py:299-314 (GRF dict) */
 typedef struct {

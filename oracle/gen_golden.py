@@ -68,6 +68,17 @@ CASES = {
     # history every 8 h; turbulence + radiation + moisture on, surface scheme / microphysics off (their
     # products SOILTEMP, albedos, surface fluxes, QC sources are fixed inputs).  Runs the loop of solver.py:82-226
     # up to the second history file (out0002 = the file testsuite.py compares).
+    # per-term dynamics switches of namelist.py:62-88 set to 0 (consumed at dyn_UFLX.py:117-193, dyn_VFLX.py:115-192,
+    # dyn_POTT.py:72-108, dyn_moist.py:68-115, dyn_UVFLX_prepare.py:260-356): between the two cases every switch that
+    # travels in DycoreConfig.term_off is off once
+    'g10x4_termsA': dict(d=10, nz=4, steps=3, snaps=(1, 3), stages=True, turb=False,
+                         terms=dict(i_UVFLX_hor_adv=0, i_UVFLX_num_dif=0, i_POTT_vert_adv=0, i_POTT_num_dif=0, i_moist_hor_adv=0)),
+    'g10x4_termsB': dict(d=10, nz=4, steps=3, snaps=(1, 3), stages=True, turb=False,
+                         terms=dict(i_UVFLX_vert_adv=0, i_UVFLX_coriolis=0, i_UVFLX_pre_grad=0, i_POTT_hor_adv=0,
+                                    i_moist_vert_adv=0, i_moist_num_dif=0)),
+    # no column-pressure tendency (dyn_continuity.py:211-214).  i_UVFLX_main_switch = 0 / i_POTT_main_switch = 0 cannot be
+    # generated: the reference's add_up_tendencies then returns a local it never assigned (dyn_UFLX.py:198, dyn_POTT.py:110)
+    'g10x4_termsC': dict(d=10, nz=4, steps=2, snaps=(1, 2), stages=True, turb=False, terms=dict(i_COLP_main_switch=0)),
     'g5x8_preset': dict(preset=True, d=5, nz=8, lat0=-80, lat1=80, sim_n_days=0.72, out_nth_hour=8),
 }
 
@@ -170,7 +181,7 @@ UVFLX_dif_coef *= 2.0
 '''
 
 
-def _install_shims(tmp, d, nz, wp, turbulence=0, radiation=0, lat0=-90, lat1=90, sim_n_days=1, out_nth_hour=1):
+def _install_shims(tmp, d, nz, wp, turbulence=0, radiation=0, lat0=-90, lat1=90, sim_n_days=1, out_nth_hour=1, terms=None):
     os.makedirs(os.path.join(tmp, 'numba'))
     with open(os.path.join(tmp, 'numba', '__init__.py'), 'w') as f:
         f.write(NUMBA_SHIM)
@@ -185,6 +196,8 @@ def _install_shims(tmp, d, nz, wp, turbulence=0, radiation=0, lat0=-90, lat1=90,
     with open(os.path.join(tmp, 'namelist.py'), 'w') as f:
         f.write(NAMELIST_SHIM % dict(ref=REF, d=d, nz=nz, wp=wp, turbulence=int(turbulence), radiation=int(radiation),
                                      lat0=lat0, lat1=lat1, sim_n_days=sim_n_days, out_nth_hour=out_nth_hour))
+        for k, v in (terms or {}).items():       # per-term switches of namelist.py:62-88
+            f.write('%s = %d\n' % (k, v))
 
     # scipy.interpolate.interp2d (removed in SciPy >= 1.14): bilinear, nearest outside.
     import scipy.interpolate as si
@@ -314,7 +327,7 @@ def run_case(name):
         return run_preset_case(name)
     sys.dont_write_bytecode = True
     tmp = tempfile.mkdtemp(prefix='golden_shims_')
-    _install_shims(tmp, cfg['d'], cfg['nz'], cfg.get('wp', 'float64'), cfg.get('turbulence', False))
+    _install_shims(tmp, cfg['d'], cfg['nz'], cfg.get('wp', 'float64'), cfg.get('turbulence', False), terms=cfg.get('terms'))
     sys.path.insert(0, REF)
     sys.path.insert(0, tmp)
     os.chdir(REF)            # the reference opens data/... relative to cwd
@@ -369,6 +382,8 @@ def run_case(name):
     out['meta/dt'] = np.int64(GR.dt)
     out['meta/pair_top'] = np.float64(pair_top)
     out['meta/dlat_deg'] = np.float64(cfg['d'])
+    if cfg.get('terms'):        # the namelist entries this case sets to 0
+        out['meta/terms_off'] = np.array(sorted(k for k, v in cfg['terms'].items() if not v))
     for n in GRID_CONSTS:
         out['grid/' + n] = np.array(GR.GRF[CPU][n])
     out['ic/HSURF'] = F.host['HSURF'].copy()

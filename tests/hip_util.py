@@ -14,8 +14,8 @@ def grid_from_golden(z, i_turb=0, i_moist=0):
                             pair_top=float(z['meta/pair_top']), i_turb=i_turb, i_moist=i_moist)
 
 
-def make_core(GR, i_turb=0, i_moist=0, dtype=np.float64):
-    core = HipDycore(GR.nx, GR.ny, GR.nz, pair_top=GR.nl.pair_top, i_turb=i_turb, i_moist=i_moist, dtype=dtype)
+def make_core(GR, i_turb=0, i_moist=0, dtype=np.float64, term_off=0):
+    core = HipDycore(GR.nx, GR.ny, GR.nz, pair_top=GR.nl.pair_top, i_turb=i_turb, i_moist=i_moist, dtype=dtype, term_off=term_off)
     core.set_grid(GR.GRF['HIP'])
     return core
 

@@ -23,7 +23,7 @@ _fp = C.POINTER(C.c_float)
 class OracleCfg(C.Structure):
     _fields_ = [('nx', C.c_int), ('ny', C.c_int), ('nz', C.c_int),
                 ('i_turb', C.c_int), ('i_radiation', C.c_int), ('nthreads', C.c_int),
-                ('pair_top', C.c_double), ('i_moist', C.c_int), ('i_moist_clip', C.c_int)]
+                ('pair_top', C.c_double), ('i_moist', C.c_int), ('i_moist_clip', C.c_int), ('term_off', C.c_int)]
 
 
 GRID_2D = ['A', 'dxjs', 'dyis', 'corf', 'corf_is', 'lat_rad', 'lat_is_rad', 'dlon_rad', 'dlat_rad']
@@ -97,14 +97,14 @@ class Oracle:
     """The CPU restatement bound to one set of numpy arrays (reference layout)."""
 
     def __init__(self, nx, ny, nz, grid, fields=None, pair_top=10000., i_turb=1,
-                 i_radiation=0, nthreads=0, fill_nan=True, i_moist=0, i_moist_clip=0, dtype=np.float64):
+                 i_radiation=0, nthreads=0, fill_nan=True, i_moist=0, i_moist_clip=0, dtype=np.float64, term_off=0):
         self.dtype = np.dtype(dtype)
         self.lib = load_oracle(self.dtype)
         self.nx, self.ny, self.nz = int(nx), int(ny), int(nz)
         if not nthreads:        # a GPU box shows every core of its host; its share is 16
             nthreads = min(16, len(os.sched_getaffinity(0)))
         self.cfg = OracleCfg(self.nx, self.ny, self.nz, int(i_turb), int(i_radiation),
-                             int(nthreads), float(pair_top), int(i_moist), int(i_moist_clip))
+                             int(nthreads), float(pair_top), int(i_moist), int(i_moist_clip), int(term_off))
         self.G = {}
         self.grid = OracleGrid()
         for n in GRID_2D + GRID_1D:
@@ -170,7 +170,7 @@ class Oracle:
         self.lib.oracle_step_matsuno(c, g, f, float(dt), int(nsteps), int(bool(with_rho)))
 
 
-def oracle_from_golden(z, tag=None, i_turb=1, i_moist=0, dtype=np.float64):
+def oracle_from_golden(z, tag=None, i_turb=1, i_moist=0, dtype=np.float64, term_off=0):
     """Build an Oracle from a golden .npz: grid constants + either the initial
     conditions (tag None) or the full captured state `tag` (e.g. 'st00_pre')."""
     nx, ny, nz = int(z['meta/nx']), int(z['meta/ny']), int(z['meta/nz'])
@@ -180,7 +180,7 @@ def oracle_from_golden(z, tag=None, i_turb=1, i_moist=0, dtype=np.float64):
     for n in ORACLE_FIELDS:
         if prefix + n in z:
             fields[n] = z[prefix + n]
-    o = Oracle(nx, ny, nz, grid, fields, pair_top=float(z['meta/pair_top']), i_turb=i_turb, i_moist=i_moist, dtype=dtype)
+    o = Oracle(nx, ny, nz, grid, fields, pair_top=float(z['meta/pair_top']), i_turb=i_turb, i_moist=i_moist, dtype=dtype, term_off=term_off)
     return o
 
 

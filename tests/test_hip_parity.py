@@ -5,7 +5,7 @@ import os
 import numpy as np
 import pytest
 
-from golden_util import load_golden, stage_tags, fields_of, rel_max_err
+from golden_util import load_golden, stage_tags, fields_of, rel_max_err, term_off_of
 from oracle_binding import oracle_from_golden, ORACLE_FIELDS
 from hip_util import grid_from_golden, make_core, fields_from
 
@@ -27,12 +27,15 @@ STEP_TOL = 1e-10
 PROGNOSTIC = ['COLP', 'UWIND', 'VWIND', 'POTT']
 
 
-@pytest.mark.parametrize('case,i_turb,i_moist', [('g10x4_dry', 0, 0), ('g10x4_dry', 0, 1), ('g10x4_dry', 1, 1), ('g10x4_turb', 1, 1)])
+# g10x4_terms*: reference runs with per-term switches of namelist.py:62-88 at 0 (DycoreConfig.term_off; between the three
+# cases every switch the reference can run without is off once)
+@pytest.mark.parametrize('case,i_turb,i_moist', [('g10x4_dry', 0, 0), ('g10x4_dry', 0, 1), ('g10x4_dry', 1, 1), ('g10x4_turb', 1, 1),
+                                                 ('g10x4_termsA', 0, 1), ('g10x4_termsB', 1, 1), ('g10x4_termsC', 0, 1)])
 def test_stage_by_stage_vs_golden(case, i_turb, i_moist):
     z = load_golden(case)
     nx, ny = int(z['meta/nx']), int(z['meta/ny'])
     GR = grid_from_golden(z, i_turb, i_moist)
-    core = make_core(GR, i_turb, i_moist)
+    core = make_core(GR, i_turb, i_moist, term_off=term_off_of(z))
     F = fields_from(GR, core, fields_of(z, 'st00_pre'))
     tags = stage_tags(z)
     checked = 0
@@ -105,6 +108,75 @@ def test_whole_steps_vs_golden(case, steps, driver, i_moist):
             # amplifies last-bit differences of log(): looser bound
             lim = 1e-9 if name == 'QC' else STEP_TOL
             assert err <= lim, '%s %s step %d %s: rel err %.3e' % (case, driver, s, name, err)
+
+
+@pytest.mark.parametrize('case,steps', [('g10x4_termsA', (1, 3)), ('g10x4_termsB', (1, 3)), ('g10x4_termsC', (1, 2))])
+@pytest.mark.parametrize('driver', ['staged', 'library'])
+def test_term_switches_whole_steps_vs_golden(case, steps, driver):
+    """namelist.py:62-88 per-term switches at 0: the reference's own runs (fixtures g10x4_terms*), reproduced by the
+    factory-driven step and by dycore_step_matsuno -- which a handle with term_off != 0 runs on the stage kernels."""
+    z = load_golden(case)
+    nx, ny = int(z['meta/nx']), int(z['meta/ny'])
+    toff = term_off_of(z)
+    assert toff != 0
+    GR = grid_from_golden(z, 0, 1)
+    core = make_core(GR, 0, 1, term_off=toff)
+    ic = {k[3:]: z[k] for k in z.files if k.startswith('ic/')}
+    F = fields_from(GR, core, ic)
+    core.primary_diag()
+    done = 0
+    for s in steps:
+        if driver == 'library':
+            step_matsuno_fused(GR, F, s - done)
+        else:
+            for _ in range(s - done):
+                step_matsuno(GR, F)
+        done = s
+        for name in PROGNOSTIC + ['QV', 'QC']:
+            got = core.download(name)
+            ref = z['step%03d/%s' % (s, name)]
+            err, ncmp, bad = rel_max_err(got, ref, name, nx, ny)
+            assert bad == 0 and ncmp > 0
+            lim = 1e-9 if name == 'QC' else STEP_TOL
+            assert err <= lim, '%s %s step %d %s: rel err %.3e' % (case, driver, s, name, err)
+    # the same run with every term on differs (the switches are consulted): UWIND or POTT moves by far more than rounding
+    core2 = make_core(GR, 0, 1)
+    F2 = fields_from(GR, core2, ic)
+    core2.primary_diag()
+    step_matsuno_fused(GR, F2, steps[-1])
+    dev = 0.0       # (plain numpy: rel_max_err would enter this deliberate difference into the session's parity margins)
+    for n in ('COLP', 'UWIND', 'POTT'):
+        a, b = core2.download(n)[1:nx + 1, 1:ny + 1], core.download(n)[1:nx + 1, 1:ny + 1]
+        dev = max(dev, float(np.max(np.abs(a - b)) / np.max(np.abs(b))))
+    assert dev > 1e-8, dev
+    core.close(); core2.close()
+
+
+def test_main_switches_zero_the_tendencies():
+    """i_UVFLX_main_switch / i_POTT_main_switch = 0 (dyn_UFLX.py:115-117, dyn_POTT.py:70-72): the tendencies are zero.
+    Parity unpinned by a reference run -- the reference's own add_up_tendencies then returns a local it never assigned
+    (oracle/gen_golden.py) --, so HIP is compared with the oracle carrying the same switches."""
+    from golden_util import TERM_BITS
+    z = load_golden('g10x4_dry')
+    nx, ny = int(z['meta/nx']), int(z['meta/ny'])
+    toff = TERM_BITS['i_UVFLX_main_switch'] | TERM_BITS['i_POTT_main_switch']
+    GR = grid_from_golden(z, 0, 0)
+    core = make_core(GR, 0, 0, term_off=toff)
+    ic = {k[3:]: z[k] for k in z.files if k.startswith('ic/')}
+    F = fields_from(GR, core, ic)
+    core.primary_diag()
+    o = oracle_from_golden(z, None, i_turb=0, term_off=toff)
+    o.primary_diag()
+    dt = float(z['meta/dt'])
+    core.step_matsuno(dt, 2)
+    o.step_matsuno(dt, 2, with_rho=False)
+    for name in ('dUFLXdt', 'dPOTTdt'):
+        got = core.download(name)
+        assert np.all(got[1:nx + 1, 1:ny + 1] == 0.0), name
+    for name in PROGNOSTIC:
+        err, ncmp, bad = rel_max_err(core.download(name), o.F[name], name, nx, ny)
+        assert bad == 0 and err <= STEP_TOL, (name, err)
+    core.close()
 
 
 def test_turb_whole_step_vs_oracle():

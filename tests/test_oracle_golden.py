@@ -3,7 +3,7 @@ reference's own Python functions (oracle/gen_golden.py).  CPU only."""
 import numpy as np
 import pytest
 
-from golden_util import load_golden, stage_tags, fields_of, rel_max_err
+from golden_util import load_golden, stage_tags, fields_of, rel_max_err, term_off_of
 from oracle_binding import oracle_from_golden, ORACLE_FIELDS
 
 # per-stage tolerance: reference formulae in IEEE fp64; the restatement keeps the
@@ -13,12 +13,13 @@ PROGNOSTIC = ['COLP', 'UWIND', 'VWIND', 'POTT']
 MOIST = ['QV', 'QC']
 
 
-@pytest.mark.parametrize('case', ['g10x4_dry', 'g10x4_turb'])
+# g10x4_terms*: reference runs with per-term switches of namelist.py:62-88 at 0 (between them every switch once)
+@pytest.mark.parametrize('case', ['g10x4_dry', 'g10x4_turb', 'g10x4_termsA', 'g10x4_termsB', 'g10x4_termsC'])
 def test_stage_by_stage(case):
     z = load_golden(case)
     nx, ny = int(z['meta/nx']), int(z['meta/ny'])
     dt = float(z['meta/dt'])
-    o = oracle_from_golden(z, 'st00_pre', i_turb=1, i_moist=1)
+    o = oracle_from_golden(z, 'st00_pre', i_turb=1, i_moist=1, term_off=term_off_of(z))
     tags = stage_tags(z)
     assert tags[0] == 'st00_pre'
     worst = {}
@@ -57,12 +58,15 @@ def test_stage_by_stage(case):
 @pytest.mark.parametrize('case,steps,tol', [
     ('g10x4_dry', (1, 2, 10), 1e-11),
     ('g4x8_dry', (1, 10), 1e-11),
+    ('g10x4_termsA', (1, 3), 1e-11),
+    ('g10x4_termsB', (1, 3), 1e-11),
+    ('g10x4_termsC', (1, 2), 1e-11),
 ])
 def test_whole_steps(case, steps, tol):
     z = load_golden(case)
     nx, ny = int(z['meta/nx']), int(z['meta/ny'])
     dt = float(z['meta/dt'])
-    o = oracle_from_golden(z, None, i_turb=1, i_moist=1)
+    o = oracle_from_golden(z, None, i_turb=1, i_moist=1, term_off=term_off_of(z))
     o.primary_diag()                 # solver.py:70-73
     done = 0
     for s in steps:

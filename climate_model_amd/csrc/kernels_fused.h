@@ -1506,14 +1506,30 @@ __global__ __launch_bounds__(TI *TJ) void k_phivb_rows(Geo g, Ptrs p, int j_lo, 
     real phivb_kp1 = p.HSURF[c] * CON_G;
     double pk1 = canon_pk(g.pair_top, p.sigma_vb[nz], colp);
     real pvb_kp1 = p.PVTFVB[c + (size_t)nz * g.plane];
-    for (int k = nz - 1; k >= 1; k--) {
-        const size_t q = c + (size_t)k * g.plane;
-        const double pk = canon_pk(g.pair_top, p.sigma_vb[k], colp);
-        const real pvb_k = p.PVTFVB[q], pott = p.POTT[q];
-        const real pvtf = canon_pvtf(pvb_kp1, pk1, pvb_k, pk, rcol, p.rdsigma[k]);
-        phivb_kp1 = canon_phivb(canon_phi(phivb_kp1, pott, pvtf, pvb_kp1), pott, pvb_k, pvtf);
-        if (k % PHIVB_STRIDE == 0) p.PHIVB[q] = phivb_kp1;
-        pk1 = pk; pvb_kp1 = pvb_k;
+    // Batches of NB levels with all their loads issued first: the integration is a chain of four multiply-adds per level,
+    // the launch a few hundred wavefronts -- left as one load pair per iteration the kernel waits nz times for HBM
+    // (36 us per launch at 0.25 deg x 64, 2 % of the substep it precedes; 8 us in batches)
+    constexpr int NB = 16;
+    for (int kb = nz - 1; kb >= 1; kb -= NB) {
+        real pvb_[NB], pott_[NB];
+#pragma unroll
+        for (int d = 0; d < NB; d++) {
+            const int k = max(kb - d, 1);
+            const size_t q = c + (size_t)k * g.plane;
+            pvb_[d] = p.PVTFVB[q]; pott_[d] = p.POTT[q];
+        }
+#pragma unroll
+        for (int d = 0; d < NB; d++) {
+            const int k = kb - d;
+            if (k >= 1) {
+                const double pk = canon_pk(g.pair_top, p.sigma_vb[k], colp);
+                const real pvb_k = pvb_[d], pott = pott_[d];
+                const real pvtf = canon_pvtf(pvb_kp1, pk1, pvb_k, pk, rcol, p.rdsigma[k]);
+                phivb_kp1 = canon_phivb(canon_phi(phivb_kp1, pott, pvtf, pvb_kp1), pott, pvb_k, pvtf);
+                if (k % PHIVB_STRIDE == 0) p.PHIVB[c + (size_t)k * g.plane] = phivb_kp1;
+                pk1 = pk; pvb_kp1 = pvb_k;
+            }
+        }
     }
 }
 __global__ __launch_bounds__(TI *TJ) void k_derive_phivb(Geo g, Ptrs p)

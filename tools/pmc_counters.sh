@@ -1,6 +1,7 @@
 #!/bin/bash
 # usage: tools/pmc_counters.sh <tag> "<COUNTER ...>" ["<COUNTER ...>" ...]   one rocprofv3 --pmc pass per quoted group over a short bench run;
-# prints per kernel (continuity / momentum / substep / temp / moist) the counter sums per launch.  Env switches (DYCORE_LIB ...) are inherited.
+# prints per kernel (continuity / momentum / substep / temp / moist / turb) the counter sums per launch.  Env switches (DYCORE_LIB ...) are inherited.
+# PMC_PROG="tools/experiments/exp_turb.py 0.25": another program (path relative to the repo root + arguments) instead of the bench run.
 set -e
 tag=$1; shift
 cd /tmp; export TMPDIR=/tmp
@@ -9,7 +10,7 @@ n=0
 for grp in "$@"; do
   n=$((n+1))
   rm -rf $R/gpurun_out/pmc_c_${tag}_$n
-  rocprofv3 --pmc $grp -d $R/gpurun_out/pmc_c_${tag}_$n -o s --output-format csv -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
+  rocprofv3 --pmc $grp -d $R/gpurun_out/pmc_c_${tag}_$n -o s --output-format csv -- python3 $R/${PMC_PROG:-bench.py --steps 3 --warmup 1 --no-cpu-baseline} > /dev/null 2>&1
 done
 python3 - <<PY
 import csv, glob, collections

@@ -35,6 +35,8 @@ constexpr real CON_CP = 1005.0;
 constexpr real CON_KAPPA = CON_RD / CON_CP;
 constexpr real CON_LH = 2264E3;       // io_constants.py:24
 
+constexpr int PHIVB_STRIDE = 4;       // PHIVB is kept at every 4th interface when PHI is not stored (the level chunks of the momentum kernel start there)
+
 struct Geo {
     int nx, ny, nz;        // local extents (ny = band height)
     int P;                 // i-pitch in elements (multiple of 64)

@@ -146,6 +146,8 @@ struct dycore {
     // the temperature kernel stores PHIVB at every 4th interface for the level chunks of the momentum kernel, evaluated with
     // the same canonical forms (kernels_stage.h), so that results do not depend on the work list or the band decomposition
     bool lazy_phi = true;
+    bool colp_old_ready = false;    // COLP_OLD already holds COLP (second destination of the copy rider that closed the previous step)
+    bool rows_ready = false;        // the PHIVB planes of the rows the next whole-substep launch cuts into chunks are current (rider of the halo launch behind the continuity kernel)
     bool planes_valid = false;      // the PHIVB planes at every PHIVB_STRIDE-th interface hold the canonical integration of the current state (k_temp_canon keeps them)
     bool lazy_pvtf = true;          // ... nor PVTF (DYCORE_LAZY_PVTF=0: store it); only where the momentum kernel forms its own (flux_from_winds, no i_turb)
     const real *flx_u = nullptr, *flx_v = nullptr;   // winds the last fused continuity evaluated on
@@ -253,7 +255,7 @@ int ready_join(dycore *h, int need = LAZY_ALL)
 {
     int rc = check_ready(h);
     if (rc) return rc;
-    h->planes_valid = false;        // a stage call may rewrite what the stored PHIVB planes were integrated from
+    h->planes_valid = false; h->rows_ready = false; h->colp_old_ready = false;        // a stage call may rewrite what the stored PHIVB planes were integrated from
     return refresh_lazy(h, need);
 }
 
@@ -266,16 +268,19 @@ int launch_check(const char *what)
 
 // lateral halo (misc_boundaries.py:22-42) of up to 12 fields in one launch
 struct HaloSpec { real *ptr; int stgx, stgy, nk; };
-int do_halo_noscope(dycore *h, const std::vector<HaloSpec> &fields, real *copy_dst = nullptr, const real *copy_src = nullptr, size_t copy_n = 0);
-int do_halo(dycore *h, const std::vector<HaloSpec> &fields, real *copy_dst = nullptr, const real *copy_src = nullptr, size_t copy_n = 0)
+int do_halo_noscope(dycore *h, const std::vector<HaloSpec> &fields, real *copy_dst = nullptr, const real *copy_src = nullptr, size_t copy_n = 0, const PlaneRows *rows = nullptr, real *copy_dst2 = nullptr);
+int do_halo(dycore *h, const std::vector<HaloSpec> &fields, real *copy_dst = nullptr, const real *copy_src = nullptr, size_t copy_n = 0, const PlaneRows *rows = nullptr, real *copy_dst2 = nullptr)
 {
     Scope s(h, K_HALO_MULTI);
-    return do_halo_noscope(h, fields, copy_dst, copy_src, copy_n);
+    return do_halo_noscope(h, fields, copy_dst, copy_src, copy_n, rows, copy_dst2);
 }
-int do_halo_noscope(dycore *h, const std::vector<HaloSpec> &fields, real *copy_dst, const real *copy_src, size_t copy_n)
+int do_halo_noscope(dycore *h, const std::vector<HaloSpec> &fields, real *copy_dst, const real *copy_src, size_t copy_n, const PlaneRows *rows, real *copy_dst2)
 {
     HaloList l;
-    l.copy_dst = copy_dst; l.copy_src = copy_src; l.copy_n = (long long)copy_n;
+    l.copy_dst = copy_dst; l.copy_src = copy_src; l.copy_n = (long long)copy_n; l.copy_dst2 = copy_dst ? copy_dst2 : nullptr;
+    if (rows) l.rows = *rows;
+    else { memset(&l.rows, 0, sizeof l.rows); l.rows.j_lo = 1; l.rows.j_hi = 0; }
+    const bool with_rows = l.rows.j_hi >= l.rows.j_lo;
     l.n = 0;
     int maxk = 1, maxcells = 0;
     for (const HaloSpec &f : fields) {
@@ -286,7 +291,12 @@ int do_halo_noscope(dycore *h, const std::vector<HaloSpec> &fields, real *copy_d
         if (cells > maxcells) maxcells = cells;
     }
     if (!l.n) return 0;
-    hipLaunchKernelGGL(k_halo_multi, dim3((maxcells + 255) / 256, maxk, l.n + (copy_dst ? 1 : 0)), dim3(256), 0, h->stream, h->g, l);
+    int gx = (maxcells + 255) / 256;
+    if (with_rows) {        // the rider's slice covers (nx + 2) x rows columns
+        const long long need = (long long)(h->g.nx + 2) * (l.rows.j_hi - l.rows.j_lo + 1);
+        gx = std::max(gx, (int)((need + 256LL * maxk - 1) / (256LL * maxk)));
+    }
+    hipLaunchKernelGGL(k_halo_multi, dim3(gx, maxk, l.n + (copy_dst ? 1 : 0) + (with_rows ? 1 : 0)), dim3(256), 0, h->stream, h->g, l);
     return launch_check("k_halo_multi");
 }
 
@@ -410,7 +420,7 @@ bool pvtf_on_demand(const dycore *h)
 // ... and PHI: the same momentum kernel carries it up the column from the surface geopotential (its level chunks start
 // from the PHIVB planes k_pott_fused stores at every PHIVB_STRIDE-th interface)
 bool phi_on_demand(const dycore *h) { return pvtf_on_demand(h) && h->lazy_phi && h->mom_tj == 4; }      // (the 64 x 8 tiles have no registers left for it)
-int do_continuity_fused(dycore *h, const Ptrs &p, real dt)
+int do_continuity_fused(dycore *h, const Ptrs &p, real dt, const PlaneRows *rows = nullptr)
 {
     const int nz = h->g.nz;
     if (!h->lazy || !(nz == 8 || nz == 16 || nz == 32 || nz == 64)) return do_continuity(h, p, dt);
@@ -444,7 +454,9 @@ int do_continuity_fused(dycore *h, const Ptrs &p, real dt)
     if (fw) {
         h->stale_uvflx = true;
         h->flx_u = p.UWIND; h->flx_v = p.VWIND;
-        return do_halo(h, {{p.UCOL, 1, 0, 1}, {p.VCOL, 0, 1, 1}, {p.WWIND, 0, 0, nz + 1}, {p.COLP_NEW, 0, 0, 1}});
+        int rc = do_halo(h, {{p.UCOL, 1, 0, 1}, {p.VCOL, 0, 1, 1}, {p.WWIND, 0, 0, nz + 1}, {p.COLP_NEW, 0, 0, 1}}, nullptr, nullptr, 0, rows);
+        if (!rc && rows) h->rows_ready = true;
+        return rc;
     }
     return do_halo(h, {{p.UFLX, 1, 0, nz}, {p.VFLX, 0, 1, nz}, {p.WWIND, 0, 0, nz + 1}, {p.COLP_NEW, 0, 0, 1}});
 }
@@ -655,27 +667,49 @@ bool substep_fused(const dycore *h)
 {
     return h->step_fused && h->pvb_alt && h->g.pole_s && h->g.pole_n && phi_on_demand(h) && h->g.nz >= 2;
 }
-int do_substep_fused(dycore *h, const Ptrs &p, const real *u_old, const real *v_old, const real *pott_old,
-                     real *u_out, real *v_out, real *pott_out, real dt)
+// work list of the whole-substep launch: one workgroup of eight wavefronts per CU; the tile rows beyond the last full round
+// are cut into level chunks
+MomPlan substep_plan(const dycore *h)
 {
-    Scope s(h, K_SUBSTEP);
     constexpr int tj = 4;
     const int gbx = (h->g.nx + FTI - 1) / FTI, gby = (h->g.ny + tj - 1) / tj;
-    // one workgroup of eight wavefronts per CU; the tile rows beyond the last full round are cut into level chunks
-    const MomPlan plan = make_mom_plan(h, gbx, RowSet{0, gby, gby, 0}, h->n_cu);
-    const dim3 gr(plan.nblk_a + 8 * ((gbx * plan.b.n * plan.ks_b + 7) / 8)), blk(FTI, 2 * tj);
-    const bool cur = (u_old == p.UWIND);
-    // the PHIVB planes the chunks' momentum wavefronts start from (own row, southern neighbour), of the state `p` this launch
-    // evaluates on -- nobody else keeps them on this path
+    return make_mom_plan(h, gbx, RowSet{0, gby, gby, 0}, h->n_cu);
+}
+// the rows whose PHIVB planes that launch needs (the chunks' momentum wavefronts start from them: own row, southern
+// neighbour), of the state `p` it evaluates on -- nobody else keeps them on this path.  At most one segment of a plan is cut.
+bool substep_plane_rows(const dycore *h, const Ptrs &p, PlaneRows &r)
+{
+    constexpr int tj = 4;
+    const MomPlan plan = substep_plan(h);
+    r = PlaneRows{p.COLP, p.HSURF, p.PVTFVB, p.POTT, p.sigma_vb, p.rdsigma, p.PHIVB, 1, 0};
     for (int seg = 0; seg < 2; seg++) {
         const RowSet &rs = seg ? plan.b : plan.a;
         const int ks = seg ? plan.ks_b : plan.ks_a;
         if (rs.n <= 0 || ks <= 1) continue;
         const int j_lo = std::max(0, rs.first * tj), j_hi = std::min(h->g.ny + 1, (rs.first + rs.n) * tj);
-        hipLaunchKernelGGL(k_phivb_rows, dim3((h->g.nx + 2 + TI - 1) / TI, (j_hi - j_lo + 1 + TJ - 1) / TJ), dim3(TI, TJ), 0, h->stream, h->g, p, j_lo, j_hi);
+        if (r.j_hi < r.j_lo) { r.j_lo = j_lo; r.j_hi = j_hi; }
+        else { r.j_lo = std::min(r.j_lo, j_lo); r.j_hi = std::max(r.j_hi, j_hi); }
+    }
+    return r.j_hi >= r.j_lo;
+}
+int do_substep_fused(dycore *h, const Ptrs &p, const real *u_old, const real *v_old, const real *pott_old,
+                     real *u_out, real *v_out, real *pott_out, real dt)
+{
+    Scope s(h, K_SUBSTEP);
+    constexpr int tj = 4;
+    const int gbx = (h->g.nx + FTI - 1) / FTI;
+    const MomPlan plan = substep_plan(h);
+    const dim3 gr(plan.nblk_a + 8 * ((gbx * plan.b.n * plan.ks_b + 7) / 8)), blk(FTI, 2 * tj);
+    const bool cur = (u_old == p.UWIND);
+    // the PHIVB planes of the rows that are cut: as a rider of the halo launch behind the continuity kernel (substep_part),
+    // or -- a caller that ran something in between -- by a launch of their own
+    PlaneRows pr;
+    if (!h->rows_ready && substep_plane_rows(h, p, pr)) {
+        hipLaunchKernelGGL(k_phivb_rows, dim3((h->g.nx + 2 + TI - 1) / TI, (pr.j_hi - pr.j_lo + 1 + TJ - 1) / TJ), dim3(TI, TJ), 0, h->stream, h->g, pr);
         int rc = launch_check("k_phivb_rows");
         if (rc) return rc;
     }
+    h->rows_ready = false;
 #ifdef DYC_TRACE
     static long long *trace_buf = nullptr;
     if (!trace_buf && hipMalloc((void **)&trace_buf, 8 * 256 * 8 * sizeof(long long)) == hipSuccess) (void)hipMemset(trace_buf, 0, 8 * 256 * 8 * sizeof(long long));
@@ -694,7 +728,7 @@ int do_substep_fused(dycore *h, const Ptrs &p, const real *u_old, const real *v_
     if (rc) return rc;
     std::swap(h->p.PVTFVB, h->pvb_alt);
     h->stale_pvtf = true; h->stale_phi = true; h->stale_phivb = true; h->stale_pottvb = true;
-    h->planes_valid = false;        // whole columns: this launch neither reads nor writes the planes
+    h->planes_valid = false; h->rows_ready = false; h->colp_old_ready = false;        // whole columns: this launch neither reads nor writes the planes
     return 0;
 }
 int do_pott_fused(dycore *h, const Ptrs &p, const real *pott_old, real *pott_out, real dt)
@@ -809,6 +843,7 @@ int step_begin(dycore *h, int with_rho)
             if ((rc = do_exchange(h, p.SMOMXFLX, 0, 0, 1))) return rc;
             if ((rc = do_exchange(h, p.SMOMYFLX, 0, 0, 1))) return rc;
         }
+        if (h->colp_old_ready) return 0;        // (filled by the launch that closed the previous step; nothing has touched the handle since)
         return do_copy(h, p.COLP_OLD, p.COLP, (size_t)h->g.plane);
     }
     std::swap(p.UWIND, p.UWIND_OLD);
@@ -840,8 +875,11 @@ int substep_part(dycore *h, real dt, int sub, int part)
         real *v_out = sub == 0 ? p.VWIND_EST : p.VWIND;
         real *t_out = sub == 0 ? p.POTT_EST : p.POTT;
         switch (part) {
-        case 0:                     // -> UFLX, VFLX, WWIND, COLP_NEW halo rows
-            return do_continuity_fused(h, q, dt);
+        case 0: {                   // -> UFLX, VFLX, WWIND, COLP_NEW halo rows
+            PlaneRows pr;           // (+ the PHIVB planes the whole-substep launch of part 1 starts its level chunks from)
+            const bool rider = substep_fused(h) && substep_plane_rows(h, q, pr);
+            return do_continuity_fused(h, q, dt, rider ? &pr : nullptr);
+        }
         case DYCORE_PART_MOM_INNER:     // turbulence-coupled: the turbulent tendencies of the same rows first
             if (h->g.i_turb && (rc = do_turb_tendencies(h, q, ROWS_INNER))) return rc;
             return do_momentum_fused(h, q, p.UWIND, p.VWIND, u_out, v_out, dt, ROWS_INNER);
@@ -872,7 +910,11 @@ int substep_part(dycore *h, real dt, int sub, int part)
             hl.push_back({u_out, 1, 0, nz});   // owned rows and pole rows only: rows in flight from a neighbour are not touched
             hl.push_back({v_out, 0, 1, nz});
             // + COLP <- COLP_NEW (dyn_matsuno.py:64-67) as a rider of the same launch  -> winds, POTT halo rows
-            return do_halo(h, hl, p.COLP, p.COLP_NEW, (size_t)h->g.plane);
+            // (the corrector's also fills COLP_OLD: the next step begins with COLP_OLD <- COLP, a launch of its own otherwise --
+            // one of nine per step, which is what a coarse grid's step is made of)
+            rc = do_halo(h, hl, p.COLP, p.COLP_NEW, (size_t)h->g.plane, nullptr, sub == 1 ? p.COLP_OLD : nullptr);
+            if (!rc && sub == 1) h->colp_old_ready = true;
+            return rc;
         }
         case 2:             // nothing: the diagnostics of a band's halo rows arrive from their owner with the POTT rows
             return 0;       // (dycore_band_row_fields), like the rows themselves -- same bits as the single-domain run
@@ -1221,7 +1263,7 @@ int dycore_set_grid(dycore_t *h, const char *name, const real *host, int32_t n0,
         HIP_TRY(hipStreamSynchronize(h->stream));
     }
     h->grid_set |= 1 << it->second;
-    h->planes_valid = false;
+    h->planes_valid = false; h->rows_ready = false; h->colp_old_ready = false;
     return 0;
 }
 
@@ -1261,7 +1303,7 @@ int dycore_upload(dycore_t *h, const char *name, const real *host)
     if (rc) return rc;
     if (!host) return fail(DYCORE_EINVAL, "null host pointer");
     if (d->member == &Ptrs::UWIND || d->member == &Ptrs::VWIND) h->winds_bc_dirty = true;
-    h->planes_valid = false;
+    h->planes_valid = false; h->rows_ready = false; h->colp_old_ready = false;
     if (d->member == &Ptrs::UFLX || d->member == &Ptrs::VFLX || d->member == &Ptrs::FLXDIV || d->member == &Ptrs::PHIVB || d->member == &Ptrs::PVTF || d->member == &Ptrs::PHI || d->member == &Ptrs::POTTVB)
         if ((rc = refresh_lazy(h))) return rc;      // a caller's value must not be overwritten by a later derivation
     const Geo &g = h->g;
@@ -1311,7 +1353,7 @@ int dycore_field_ptr(dycore_t *h, const char *name, void **dev, int64_t *pitch, 
     int rc = find_field(h, name, &d);
     if (rc) return rc;
     if ((rc = refresh_lazy(h, lazy_need(d)))) return rc;
-    h->planes_valid = false;        // the caller may write through the pointer
+    h->planes_valid = false; h->rows_ready = false; h->colp_old_ready = false;        // the caller may write through the pointer
     if (dev) *dev = h->p.*(d->member);
     if (pitch) *pitch = h->g.P;
     if (rows) *rows = h->g.NJ;
@@ -1326,7 +1368,7 @@ int dycore_copy_field(dycore_t *h, const char *dst, const char *src)
     if ((rc = find_field(h, dst, &a)) || (rc = find_field(h, src, &b))) return rc;
     if (a->stgx != b->stgx || a->stgy != b->stgy || a->nk != b->nk)
         return fail(DYCORE_EINVAL, "copy_field: '%s' and '%s' differ in shape", dst, src);
-    h->planes_valid = false;
+    h->planes_valid = false; h->rows_ready = false; h->colp_old_ready = false;
     if ((rc = refresh_lazy(h, lazy_need(a) | lazy_need(b)))) return rc;
     return do_copy(h, h->p.*(a->member), h->p.*(b->member), h->field_elems(a->nk));
 }
@@ -1439,6 +1481,7 @@ static int rows_op(dycore_t *h, int32_t n, const char *const *names, const int32
                 return fail(DYCORE_EINVAL, "row %d outside field '%s'", rows[done], names[done]);
             const int e = rl.n++;
             rl.base[e] = q.*(d->member);
+            if (unpack && dev_buf && (d->member == &Ptrs::COLP || d->member == &Ptrs::COLP_OLD)) h->colp_old_ready = false;
             rl.row[e] = rows[done];
             rl.nk[e] = h->nk_of(d->nk);
             rl.k0[e] = 0; rl.kstep[e] = 1;

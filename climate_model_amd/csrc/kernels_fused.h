@@ -338,7 +338,6 @@ __global__ __launch_bounds__(FNT) void k_momentum_fused(Geo g, Ptrs p, int gbx, 
 // `s_waitcnt vmcnt(n)` with n = the instructions this wave issued for level k+2 means "my part of level k+1
 // has landed" while level k+2 stays in flight.  The two stores of an iteration are issued BEFORE that
 // iteration's DMA, so they are older than it and the count is exact.
-constexpr int PHIVB_STRIDE = 4;                  // k_pott_fused stores PHIVB at every 4th interface when PHI is not stored (chunks of the momentum kernel start there)
 constexpr int DMAXZ = 160;                        // levels up to which the LDS-DMA kernel is used (beyond: k_momentum_fused)
 
 // Tile rows a staged field needs from row j0-1 on: UFLX, UWIND, WWIND j-1..j+1 (TJ+2 rows), VFLX (and VWIND
@@ -1490,46 +1489,6 @@ __global__ __launch_bounds__(TI *TJ) void k_derive_phi(Geo g, Ptrs p, int canon)
         p.PHI[q] = dl.phi;
         p.PHIVB[q] = dl.phivb;
         p_kp12 = dl.p_km12; pvb_kp1 = dl.pvb_k; phivb_kp1 = dl.phivb;
-    }
-}
-// The PHIVB planes of rows j_lo .. j_hi (columns 0 .. nx+1): PHIVB at every PHIVB_STRIDE-th interface, integrated from the
-// surface with the canonical forms -- what the momentum wavefronts of a level chunk start from.  The whole-substep kernel
-// does not keep the planes (its temperature wavefronts do not integrate PHI); its launch cuts only the tile rows beyond
-// the last full round of workgroups into chunks, and this kernel serves those rows (a few of 720) just before it.
-__global__ __launch_bounds__(TI *TJ) void k_phivb_rows(Geo g, Ptrs p, int j_lo, int j_hi)
-{
-    const int i = blockIdx.x * TI + threadIdx.x, j = j_lo + blockIdx.y * TJ + threadIdx.y;
-    if (i > g.nx + 1 || j > j_hi) return;
-    const size_t c = at2(g, i, j);
-    const int nz = g.nz;
-    const real colp = p.COLP[c], rcol = canon_rcol(colp);
-    real phivb_kp1 = p.HSURF[c] * CON_G;
-    double pk1 = canon_pk(g.pair_top, p.sigma_vb[nz], colp);
-    real pvb_kp1 = p.PVTFVB[c + (size_t)nz * g.plane];
-    // Batches of NB levels with all their loads issued first: the integration is a chain of four multiply-adds per level,
-    // the launch a few hundred wavefronts -- left as one load pair per iteration the kernel waits nz times for HBM
-    // (36 us per launch at 0.25 deg x 64, 2 % of the substep it precedes; 8 us in batches)
-    constexpr int NB = 16;
-    for (int kb = nz - 1; kb >= 1; kb -= NB) {
-        real pvb_[NB], pott_[NB];
-#pragma unroll
-        for (int d = 0; d < NB; d++) {
-            const int k = max(kb - d, 1);
-            const size_t q = c + (size_t)k * g.plane;
-            pvb_[d] = p.PVTFVB[q]; pott_[d] = p.POTT[q];
-        }
-#pragma unroll
-        for (int d = 0; d < NB; d++) {
-            const int k = kb - d;
-            if (k >= 1) {
-                const double pk = canon_pk(g.pair_top, p.sigma_vb[k], colp);
-                const real pvb_k = pvb_[d], pott = pott_[d];
-                const real pvtf = canon_pvtf(pvb_kp1, pk1, pvb_k, pk, rcol, p.rdsigma[k]);
-                phivb_kp1 = canon_phivb(canon_phi(phivb_kp1, pott, pvtf, pvb_kp1), pott, pvb_k, pvtf);
-                if (k % PHIVB_STRIDE == 0) p.PHIVB[c + (size_t)k * g.plane] = phivb_kp1;
-                pk1 = pk; pvb_kp1 = pvb_k;
-            }
-        }
     }
 }
 __global__ __launch_bounds__(TI *TJ) void k_derive_phivb(Geo g, Ptrs p)

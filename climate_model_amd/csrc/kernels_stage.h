@@ -1038,6 +1038,57 @@ __global__ void k_exchange_bc(Geo g, real *F, int stgx, int stgy, int nk)
 // refreshes the lateral halo of everything it produced).  Part A = wall rows (all columns),
 // part B = the periodic columns of the interior rows.  Rows that belong to a neighbouring
 // latitude band are left alone: they arrive by message, periodic columns included.
+// The PHIVB planes of rows j_lo .. j_hi (columns 0 .. nx+1): PHIVB at every PHIVB_STRIDE-th interface, integrated from the
+// surface with the canonical forms -- what the momentum wavefronts of a level chunk of the whole-substep kernel start from
+// (that kernel keeps no planes: its temperature wavefronts do not integrate PHI; its work list cuts only the tile rows beyond
+// the last full round of workgroups into chunks, a few rows of 720).  Evaluated by k_phivb_rows, or as a rider of the
+// k_halo_multi launch that precedes the whole-substep launch anyway (one launch less per substep: on a 1 deg grid a
+// launch gap is 3 % of the step).  j_hi < j_lo: no rows.
+struct PlaneRows {
+    const real *colp, *hsurf, *pvtfvb, *pott, *sigma_vb, *rdsigma;
+    real *phivb;
+    int j_lo, j_hi;
+};
+__device__ __forceinline__ void phivb_planes_column(const Geo &g, const PlaneRows &r, int i, int j)
+{
+    const size_t c = at2(g, i, j);
+    const int nz = g.nz;
+    const real colp = r.colp[c], rcol = canon_rcol(colp);
+    real phivb_kp1 = r.hsurf[c] * CON_G;
+    double pk1 = canon_pk(g.pair_top, r.sigma_vb[nz], colp);
+    real pvb_kp1 = r.pvtfvb[c + (size_t)nz * g.plane];
+    // Batches of NB levels with all their loads issued first: the integration is a chain of four multiply-adds per level,
+    // the launch a few hundred wavefronts -- left as one load pair per iteration the kernel waits nz times for HBM
+    constexpr int NB = 16;
+    for (int kb = nz - 1; kb >= 1; kb -= NB) {
+        real pvb_[NB], pott_[NB];
+#pragma unroll
+        for (int d = 0; d < NB; d++) {
+            const int k = max(kb - d, 1);
+            const size_t q = c + (size_t)k * g.plane;
+            pvb_[d] = r.pvtfvb[q]; pott_[d] = r.pott[q];
+        }
+#pragma unroll
+        for (int d = 0; d < NB; d++) {
+            const int k = kb - d;
+            if (k >= 1) {
+                const double pk = canon_pk(g.pair_top, r.sigma_vb[k], colp);
+                const real pvb_k = pvb_[d], pott = pott_[d];
+                const real pvtf = canon_pvtf(pvb_kp1, pk1, pvb_k, pk, rcol, r.rdsigma[k]);
+                phivb_kp1 = canon_phivb(canon_phi(phivb_kp1, pott, pvtf, pvb_kp1), pott, pvb_k, pvtf);
+                if (k % PHIVB_STRIDE == 0) r.phivb[c + (size_t)k * g.plane] = phivb_kp1;
+                pk1 = pk; pvb_kp1 = pvb_k;
+            }
+        }
+    }
+}
+__global__ __launch_bounds__(TI *TJ) void k_phivb_rows(Geo g, PlaneRows r)
+{
+    const int i = blockIdx.x * TI + threadIdx.x, j = r.j_lo + blockIdx.y * TJ + threadIdx.y;
+    if (i > g.nx + 1 || j > r.j_hi) return;
+    phivb_planes_column(g, r, i, j);
+}
+
 struct HaloList {
     int n;
     real *base[12];
@@ -1045,17 +1096,29 @@ struct HaloList {
     // optional rider: a plain copy of one 2-D plane (COLP <- COLP_NEW of dyn_matsuno.py:64-67) on the
     // z-slice after the last field, so that the step does not pay a launch for it
     const real *copy_src;
-    real *copy_dst;
-    long long copy_n;
+    real *copy_dst, *copy_dst2;     // (copy_dst2: a second destination of the same plane -- COLP_OLD of the NEXT step, which
+    long long copy_n;               //  begins with COLP_OLD <- COLP, dyn_matsuno.py:34-41 -- or null)
+    // optional rider: the PHIVB planes of a few rows (PlaneRows) on the z-slice after that
+    PlaneRows rows;
 };
 __global__ void k_halo_multi(Geo g, HaloList l)
 {
     const int e = blockIdx.z, k = blockIdx.y;
-    if (e == l.n) {
-        if (l.copy_dst) {
+    if (e >= l.n) {
+        const int e_copy = l.copy_dst ? l.n : -1, e_rows = l.n + (l.copy_dst ? 1 : 0);
+        if (e == e_copy) {
             const long long stride = (long long)gridDim.x * gridDim.y * blockDim.x;
             for (long long t = ((long long)k * gridDim.x + blockIdx.x) * blockDim.x + threadIdx.x; t < l.copy_n; t += stride)
-                l.copy_dst[t] = l.copy_src[t];
+            {
+                const real v = l.copy_src[t];
+                l.copy_dst[t] = v;
+                if (l.copy_dst2) l.copy_dst2[t] = v;
+            }
+        } else if (e == e_rows && l.rows.j_hi >= l.rows.j_lo) {      // (the launch has at least (nx + 2) * rows threads per slice)
+            const long long t = ((long long)k * gridDim.x + blockIdx.x) * blockDim.x + threadIdx.x;
+            const int nxx = g.nx + 2;
+            const int j = l.rows.j_lo + (int)(t / nxx), i = (int)(t - (long long)(t / nxx) * nxx);
+            if (j <= l.rows.j_hi) phivb_planes_column(g, l.rows, i, j);
         }
         return;
     }

@@ -295,8 +295,8 @@ def main():
     roof = None
     if dom:
         per_launch_bytes = KERNEL_PASSES[dom] * band_cells * esize
-        # a band runs the kernel as two launches per substep (inner rows behind the exchange, edge
-        # rows after it): price the pair as the one pass over the band it is
+        # a band runs the kernel as two or three launches per substep (inner rows behind the exchanges, edge
+        # rows between them): price them as the one pass over the band they are
         if world > 1:
             dom_n = 2 * args.steps
         avg_s = dom_ms / dom_n / 1e3
@@ -309,8 +309,8 @@ def main():
                 continue
             nl_ = launches_per_step[k]
             gb = KERNEL_PASSES[k] * band_cells * esize / 1e9
-            if world > 1 and k in ('k_momentum_dma',):
-                nl_ = nl_ / 2.0         # inner + edge launch = one pass over the band
+            if world > 1 and k in ('k_momentum_dma', 'k_substep_fused'):
+                nl_ = 2.0               # the pieces of a substep (inner tile rows in one or two launches, edge rows) = one pass over the band
             step_bytes += gb * nl_
             kern[k] = {'ms_per_step': ms, 'launches_per_step': launches_per_step[k], 'compulsory_GB_per_pass': gb,
                        'achieved_GBs': gb * nl_ / (ms * 1e-3), 'frac': gb * nl_ / (ms * 1e-3) / HBM_PEAK_GBS}

@@ -6,6 +6,9 @@
 //
 //   main:  |B1  continuity ---- momentum inner tiles - |AB2 - momentum edge tiles ---- temperature(+moisture)
 //   comm:                  AB2: pack, transport, unpack                              B1: pack, transport, unpack
+// and, on a handle whose momentum and temperature kernels are one launch (the whole-substep kernel, round 3):
+//   main:  |B1  continuity ---- first half of the inner tiles - |AB2 - edge tiles ---- second half of the inner tiles
+//   comm:                  AB2: pack, transport, unpack                             B1: pack, transport, unpack
 //
 //   AB2 = 2-D column pressures at the u- / v-points, WWIND, COLP_NEW of this substep + the POTT (QV, QC) rows of the
 //         state it evaluates on and the rows of that state's diagnostics as their owner computed them (PVTFVB and the
@@ -428,10 +431,13 @@ int dycore_bands_step_matsuno(dycore_bands_t *B, double dt, int32_t nsteps, int3
             if ((rc = bands_wait(B, PH_B1)) || (rc = bands_wait(B, PH_B2))) return rc;
             ALL(substep_part(h, dt, sub, 0))
             if ((rc = bands_exchange(B, PH_AB2, sub, dt))) return rc;
-            ALL(substep_part(h, dt, sub, DYCORE_PART_MOM_INNER))
+            // (whole-substep kernel: INNER_A / INNER_B are the two halves of the inner tile rows, part TEMP holds no kernel;
+            // two kernels: INNER_A is the whole inner piece, INNER_B nothing, part TEMP the temperature kernel)
+            ALL(substep_part(h, dt, sub, DYCORE_PART_MOM_INNER_A))
             if ((rc = bands_wait(B, PH_AB2))) return rc;
             ALL(substep_part(h, dt, sub, DYCORE_PART_MOM_EDGE))
             if ((rc = bands_exchange(B, PH_B1, sub, dt))) return rc;
+            ALL(substep_part(h, dt, sub, DYCORE_PART_MOM_INNER_B))
             ALL(substep_part(h, dt, sub, DYCORE_PART_TEMP))
         }
         if (turb && s < nsteps - 1 && (rc = bands_exchange(B, PH_B2, 1, dt))) return rc;

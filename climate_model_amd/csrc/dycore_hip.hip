@@ -146,6 +146,7 @@ struct dycore {
     // the temperature kernel stores PHIVB at every 4th interface for the level chunks of the momentum kernel, evaluated with
     // the same canonical forms (kernels_stage.h), so that results do not depend on the work list or the band decomposition
     bool lazy_phi = true;
+    int step_fused_bands = -1;      // a latitude band on the whole-substep kernel: -1 when it is large enough (substep_fused), DYCORE_BANDS_STEP_FUSED=1 / 0 always / never
     bool colp_old_ready = false;    // COLP_OLD already holds COLP (second destination of the copy rider that closed the previous step)
     bool rows_ready = false;        // the PHIVB planes of the rows the next whole-substep launch cuts into chunks are current (rider of the halo launch behind the continuity kernel)
     bool planes_valid = false;      // the PHIVB planes at every PHIVB_STRIDE-th interface hold the canonical integration of the current state (k_temp_canon keeps them)
@@ -514,14 +515,17 @@ int refresh_lazy(dycore *h, int need)
 // neighbour exchange with the tiles whose stencils stay clear of the received halo rows
 // (INNER) and finishes the edge tiles (EDGE) once the rows have arrived; a band that touches a
 // pole has no neighbour on that side.  ALL = INNER + EDGE in one launch.
-enum { ROWS_ALL = 0, ROWS_INNER = 1, ROWS_EDGE = 2 };
+enum { ROWS_ALL = 0, ROWS_INNER = 1, ROWS_EDGE = 2, ROWS_INNER_A = 3, ROWS_INNER_B = 4 };      // INNER = INNER_A + INNER_B (its first / second half)
 // inner range out of [0, n-1] given how many rows at each end depend on a neighbour
 bool row_subset(int n, int dep_s, int dep_n, int mode, RowSet &rs)
 {
     int lo = dep_s, hi = n - 1 - dep_n;
     if (lo > hi) { lo = n; hi = n - 1; }              // no inner part: everything is edge
+    const int mid = lo + (hi - lo + 2) / 2;       // first row of the second half
     if (mode == ROWS_ALL) rs = {0, n, n, 0};
     else if (mode == ROWS_INNER) rs = {lo, hi - lo + 1, n, 0};
+    else if (mode == ROWS_INNER_A) rs = {lo, mid - lo, n, 0};
+    else if (mode == ROWS_INNER_B) rs = {mid, hi - mid + 1, n, 0};
     else rs = {0, n - (hi - lo + 1), lo, hi - lo + 1};
     return rs.n > 0;
 }
@@ -665,23 +669,43 @@ int do_momentum_fused(dycore *h, const Ptrs &p, const real *u_old, const real *v
 // momentum + temperature in one launch: see k_momentum_dma<..., WITH_TEMP>
 bool substep_fused(const dycore *h)
 {
-    return h->step_fused && h->pvb_alt && h->g.pole_s && h->g.pole_n && phi_on_demand(h) && h->g.nz >= 2;
+    // A latitude band takes it when it is large (DYCORE_BANDS_STEP_FUSED=1 / 0: always / never): its pieces -- inner tile
+    // rows in two halves around the edge rows, so that both exchanges stay hidden -- are launches of their own, and on a small
+    // band, where each is about one round of workgroups, their ramps cost more than the single launch gains on a whole domain
+    // (5 %): 0.25 deg x 64 in 2 / 4 / 8 emulated bands 2.49 / 1.35 / 0.815 ms per band-step against 2.585 / 1.35 / 0.727 on
+    // the two kernels (profiles/r03_notes.md).  Bitwise the same step either way.
+    bool band_ok = h->g.pole_s && h->g.pole_n;
+    if (!band_ok) {
+        const long tiles = (long)((h->g.nx + FTI - 1) / FTI) * ((h->g.ny + 3) / 4);
+        band_ok = h->step_fused_bands > 0 || (h->step_fused_bands < 0 && tiles >= 6L * h->n_cu);
+    }
+    return h->step_fused && h->pvb_alt && band_ok && phi_on_demand(h) && h->g.nz >= 2;
 }
 // work list of the whole-substep launch: one workgroup of eight wavefronts per CU; the tile rows beyond the last full round
 // are cut into level chunks
-MomPlan substep_plan(const dycore *h)
+// `mode`: the tile rows of the launch (a latitude band: those clear of the neighbours' rows, in one piece or two, and the
+// edge rows -- the dependence footprint is the momentum wavefronts', which covers the temperature wavefronts')
+bool substep_plan(const dycore *h, int mode, MomPlan &plan)
 {
     constexpr int tj = 4;
     const int gbx = (h->g.nx + FTI - 1) / FTI, gby = (h->g.ny + tj - 1) / tj;
-    return make_mom_plan(h, gbx, RowSet{0, gby, gby, 0}, h->n_cu);
+    int dep_n = 0;
+    if (!h->g.pole_n)
+        for (int by = gby - 1; by >= 0 && by * tj + 1 + tj + 1 > h->g.ny; by--) dep_n++;
+    RowSet trows;
+    if (!row_subset(gby, h->g.pole_s ? 0 : 1, dep_n, mode, trows)) return false;
+    plan = make_mom_plan(h, gbx, trows, h->n_cu);
+    return true;
 }
 // the rows whose PHIVB planes that launch needs (the chunks' momentum wavefronts start from them: own row, southern
 // neighbour), of the state `p` it evaluates on -- nobody else keeps them on this path.  At most one segment of a plan is cut.
+// (whole domain in one launch: one contiguous run of rows, the rider of the halo launch)
 bool substep_plane_rows(const dycore *h, const Ptrs &p, PlaneRows &r)
 {
     constexpr int tj = 4;
-    const MomPlan plan = substep_plan(h);
+    MomPlan plan;
     r = PlaneRows{p.COLP, p.HSURF, p.PVTFVB, p.POTT, p.sigma_vb, p.rdsigma, p.PHIVB, 1, 0};
+    if (!substep_plan(h, ROWS_ALL, plan)) return false;
     for (int seg = 0; seg < 2; seg++) {
         const RowSet &rs = seg ? plan.b : plan.a;
         const int ks = seg ? plan.ks_b : plan.ks_a;
@@ -692,24 +716,48 @@ bool substep_plane_rows(const dycore *h, const Ptrs &p, PlaneRows &r)
     }
     return r.j_hi >= r.j_lo;
 }
-int do_substep_fused(dycore *h, const Ptrs &p, const real *u_old, const real *v_old, const real *pott_old,
-                     real *u_out, real *v_out, real *pott_out, real dt)
+// the whole-substep launch has written the new PVTFVB into the alternate buffer (momentum wavefronts of neighbouring tiles,
+// and of a band's other pieces, were still reading the old one): swap it in -- once per substep, behind its last piece
+void finish_substep_fused(dycore *h)
 {
-    Scope s(h, K_SUBSTEP);
+    std::swap(h->p.PVTFVB, h->pvb_alt);
+    h->stale_pvtf = true; h->stale_phi = true; h->stale_phivb = true; h->stale_pottvb = true;
+    h->planes_valid = false;        // this launch neither reads nor writes the planes as a whole
+}
+int do_substep_fused(dycore *h, const Ptrs &p, const real *u_old, const real *v_old, const real *pott_old,
+                     real *u_out, real *v_out, real *pott_out, real dt, int mode = ROWS_ALL)
+{
     constexpr int tj = 4;
     const int gbx = (h->g.nx + FTI - 1) / FTI;
-    const MomPlan plan = substep_plan(h);
+    MomPlan plan;
+    if (!substep_plan(h, mode, plan)) return 0;
+    Scope s(h, K_SUBSTEP);
     const dim3 gr(plan.nblk_a + 8 * ((gbx * plan.b.n * plan.ks_b + 7) / 8)), blk(FTI, 2 * tj);
     const bool cur = (u_old == p.UWIND);
     // the PHIVB planes of the rows that are cut: as a rider of the halo launch behind the continuity kernel (substep_part),
     // or -- a caller that ran something in between -- by a launch of their own
-    PlaneRows pr;
-    if (!h->rows_ready && substep_plane_rows(h, p, pr)) {
-        hipLaunchKernelGGL(k_phivb_rows, dim3((h->g.nx + 2 + TI - 1) / TI, (pr.j_hi - pr.j_lo + 1 + TJ - 1) / TJ), dim3(TI, TJ), 0, h->stream, h->g, pr);
-        int rc = launch_check("k_phivb_rows");
-        if (rc) return rc;
+    if (!(mode == ROWS_ALL && h->rows_ready)) {
+        PlaneRows pr{p.COLP, p.HSURF, p.PVTFVB, p.POTT, p.sigma_vb, p.rdsigma, p.PHIVB, 1, 0};
+        for (int seg = 0; seg < 2; seg++) {
+            const RowSet &rs = seg ? plan.b : plan.a;
+            const int ks = seg ? plan.ks_b : plan.ks_a;
+            if (rs.n <= 0 || ks <= 1) continue;
+            // contiguous runs of tile rows (a band's edge piece is its first and its last tile rows); a run needs the rows of
+            // its tiles and the one south of them (a band's halo row 0: its POTT, PVTFVB rows have arrived by the time the
+            // edge piece is issued)
+            for (int r0 = 0; r0 < rs.n;) {
+                int r1 = r0;
+                while (r1 + 1 < rs.n && rowset_row(rs, r1 + 1) == rowset_row(rs, r1) + 1) r1++;
+                pr.j_lo = std::max(0, rowset_row(rs, r0) * tj);
+                pr.j_hi = std::min(h->g.ny + 1, (rowset_row(rs, r1) + 1) * tj);
+                hipLaunchKernelGGL(k_phivb_rows, dim3((h->g.nx + 2 + TI - 1) / TI, (pr.j_hi - pr.j_lo + 1 + TJ - 1) / TJ), dim3(TI, TJ), 0, h->stream, h->g, pr);
+                int rc = launch_check("k_phivb_rows");
+                if (rc) return rc;
+                r0 = r1 + 1;
+            }
+        }
     }
-    h->rows_ready = false;
+    if (mode == ROWS_ALL) h->rows_ready = false;
 #ifdef DYC_TRACE
     static long long *trace_buf = nullptr;
     if (!trace_buf && hipMalloc((void **)&trace_buf, 8 * 256 * 8 * sizeof(long long)) == hipSuccess) (void)hipMemset(trace_buf, 0, 8 * 256 * 8 * sizeof(long long));
@@ -718,18 +766,13 @@ int do_substep_fused(dycore *h, const Ptrs &p, const real *u_old, const real *v_
 #else
     const TempArgs ta = {pott_old, pott_out, h->pvb_alt, nullptr};
 #endif
-    const int jv_lo = 2;        // pole_s
+    const int jv_lo = h->g.pole_s ? 2 : 1;
     // (whole columns: PHI starts from the surface geopotential in every thread, no stored PHIVB plane is read or written)
     if (cur) hipLaunchKernelGGL((k_momentum_dma<true, tj, true, false, 2, true, true>), gr, blk, dma_lds_bytes(tj, true, true, 2, true, true), h->stream,
                                 h->g, p, gbx, plan, jv_lo, u_old, v_old, u_out, v_out, dt, ta);
     else hipLaunchKernelGGL((k_momentum_dma<false, tj, true, false, 2, true, true>), gr, blk, dma_lds_bytes(tj, true, false, 2, true, true), h->stream,
                             h->g, p, gbx, plan, jv_lo, u_old, v_old, u_out, v_out, dt, ta);
-    int rc = launch_check("k_substep_fused");
-    if (rc) return rc;
-    std::swap(h->p.PVTFVB, h->pvb_alt);
-    h->stale_pvtf = true; h->stale_phi = true; h->stale_phivb = true; h->stale_pottvb = true;
-    h->planes_valid = false; h->rows_ready = false; h->colp_old_ready = false;        // whole columns: this launch neither reads nor writes the planes
-    return 0;
+    return launch_check("k_substep_fused");
 }
 int do_pott_fused(dycore *h, const Ptrs &p, const real *pott_old, real *pott_out, real dt)
 {
@@ -881,17 +924,27 @@ int substep_part(dycore *h, real dt, int sub, int part)
             return do_continuity_fused(h, q, dt, rider ? &pr : nullptr);
         }
         case DYCORE_PART_MOM_INNER:     // turbulence-coupled: the turbulent tendencies of the same rows first
+        case DYCORE_PART_MOM_INNER_A:
+        case DYCORE_PART_MOM_INNER_B:
+            // momentum + temperature in one launch (round 3: latitude bands too): a piece writes the new winds, POTT and -- into
+            // the alternate buffer, swapped in by part TEMP -- PVTFVB of its rows
+            if (substep_fused(h))
+                return do_substep_fused(h, q, p.UWIND, p.VWIND, p.POTT, u_out, v_out, t_out, dt,
+                                        part == DYCORE_PART_MOM_INNER ? ROWS_INNER : part == DYCORE_PART_MOM_INNER_A ? ROWS_INNER_A : ROWS_INNER_B);
+            if (part == DYCORE_PART_MOM_INNER_B) return 0;      // (two kernels: INNER_A is the whole inner piece, part TEMP hides the wind rows)
             if (h->g.i_turb && (rc = do_turb_tendencies(h, q, ROWS_INNER))) return rc;
             return do_momentum_fused(h, q, p.UWIND, p.VWIND, u_out, v_out, dt, ROWS_INNER);
         case DYCORE_PART_MOM_EDGE:  // -> new winds complete: their rows can travel while part TEMP runs
+            if (substep_fused(h)) return do_substep_fused(h, q, p.UWIND, p.VWIND, p.POTT, u_out, v_out, t_out, dt, ROWS_EDGE);
             if (h->g.i_turb && (rc = do_turb_tendencies(h, q, ROWS_EDGE))) return rc;
             // the rows that leave now are packed with their periodic images (k_rows); the lateral halo of
             // the new winds is refreshed with everything else at the end of part TEMP
             return do_momentum_fused(h, q, p.UWIND, p.VWIND, u_out, v_out, dt, ROWS_EDGE);
         case 1:
         case DYCORE_PART_TEMP: {    // momentum reads the old diagnostics, so it runs first
-            if (part == 1 && substep_fused(h)) {
-                if ((rc = do_substep_fused(h, q, p.UWIND, p.VWIND, p.POTT, u_out, v_out, t_out, dt))) return rc;
+            if (substep_fused(h)) {
+                if (part == 1 && (rc = do_substep_fused(h, q, p.UWIND, p.VWIND, p.POTT, u_out, v_out, t_out, dt))) return rc;
+                finish_substep_fused(h);        // (the pieces of a split part 1 have all been issued by now)
             } else {
                 if (part == 1) {
                     if (h->g.i_turb && (rc = do_turb_tendencies(h, q))) return rc;
@@ -923,6 +976,8 @@ int substep_part(dycore *h, real dt, int sub, int part)
     }
     switch (part) {
     case DYCORE_PART_MOM_INNER:
+    case DYCORE_PART_MOM_INNER_A:
+    case DYCORE_PART_MOM_INNER_B:
     case DYCORE_PART_MOM_EDGE:
     case DYCORE_PART_TEMP:
         return fail(DYCORE_ESTATE, "split parts need the fused step (dycore_overlap_parts)");
@@ -996,6 +1051,7 @@ int dycore_create(const DycoreConfig *cfg, dycore_t **out)
     if (const char *e = getenv("DYCORE_FUSED")) h->fused = atoi(e) != 0;                    // 0: stage kernels for everything (the fallback)
     if (g.term_off) h->fused = false;       // a tendency term switched off (namelist.py:62-88): the stage kernels carry the switches
     if (const char *e = getenv("DYCORE_FUSED_TURB")) h->fused_turb = atoi(e) != 0;          // 0: stage kernels for turbulence-coupled handles
+    if (const char *e = getenv("DYCORE_BANDS_STEP_FUSED")) h->step_fused_bands = atoi(e) != 0;  // 1 / 0: latitude bands always / never on the whole-substep kernel (default: large bands, see substep_fused)
     if (const char *e = getenv("DYCORE_STEP_FUSED")) h->step_fused = atoi(e) != 0;          // 0: momentum and temperature as two kernels on one GPU too (what a band runs)
     if (const char *e = getenv("DYCORE_LAZY_PHI")) h->lazy_phi = atoi(e) != 0;              // 0: PHI and POTTVB stored and staged (round 2's data flow)
     if (const char *e = getenv("DYCORE_MOM_KS")) h->mom_ks = atoi(e);                       // level chunks per tile forced (work-list tests)
@@ -1118,7 +1174,7 @@ int dycore_create(const DycoreConfig *cfg, dycore_t **out)
         rc = alloc((size_t)(5 * (g.nz + 2)), &d);
         h->p.mom_c = d;
     }
-    if (!rc && h->step_fused && g.pole_s && g.pole_n && !g.i_turb) {       // (substep_fused: the other conditions can change with the grid)
+    if (!rc && h->step_fused && !g.i_turb) {       // (substep_fused: the other conditions can change with the grid)
         rc = alloc(h->field_elems(-1), &h->pvb_alt);         // nz + 1 planes
     }
     if (!rc) {
@@ -1159,6 +1215,7 @@ static void band_row_fields(const dycore *h, std::vector<const char *> &out)
 {
     if (!fused_path(h)) return;                 // the staged step diagnoses the whole band, halo rows included (part 2)
     out.push_back("PVTFVB");
+    if (substep_fused(h)) return;               // the whole-substep kernel keeps nothing else: PHI is carried in its threads
     if (!h->g.i_turb && phi_on_demand(h)) { out.push_back("PHIVB"); return; }       // (the planes the level chunks start from)
     out.push_back("PHI"); out.push_back("POTTVB");
     if (!pvtf_on_demand(h)) out.push_back("PVTF");

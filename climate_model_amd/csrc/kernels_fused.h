@@ -52,7 +52,7 @@ __device__ __forceinline__ bool xcd_tile(int gbx, int gby, int &bx, int &by)
 // once r has reached rs.split -- one contiguous range (gap 0) or the two edge ranges of a
 // latitude band (the tile rows whose stencils touch rows received from the neighbours).
 struct RowSet { int first, n, split, gap; };
-__device__ __forceinline__ int rowset_row(const RowSet &rs, int r) { return rs.first + r + (r >= rs.split ? rs.gap : 0); }
+__host__ __device__ __forceinline__ int rowset_row(const RowSet &rs, int r) { return rs.first + r + (r >= rs.split ? rs.gap : 0); }
 
 // Work list of one k_momentum_dma launch: up to two segments of (tile rows, level chunks per tile).
 // With one workgroup per CU, T equal tiles take ceil(T / CUs) rounds; the tiles beyond the last full

@@ -210,7 +210,13 @@ int dycore_step_begin(dycore_t *h, int32_t with_rho);
 /* name of the registered field that holds `name` (UWIND, VWIND or POTT) right after part 1 of
  * the given substep: the fused step writes the predictor state into *_EST scratch fields */
 const char *dycore_substep_field(dycore_t *h, int32_t substep, const char *name);
-enum { DYCORE_PART_MOM_INNER = 10, DYCORE_PART_MOM_EDGE = 11, DYCORE_PART_TEMP = 12 };
+enum { DYCORE_PART_MOM_INNER = 10, DYCORE_PART_MOM_EDGE = 11, DYCORE_PART_TEMP = 12,
+       /* MOM_INNER in two halves (first / second half of its tile rows), for a schedule that puts the edge piece between
+        * them: INNER_A - wait for the rows - EDGE - send the new wind rows - INNER_B.  On a handle whose momentum and
+        * temperature kernels are one launch (the whole-substep kernel; round 3: latitude bands too) part TEMP no longer
+        * holds a kernel that could hide the wind rows' journey -- INNER_B does.  Other handles: INNER_A = MOM_INNER,
+        * INNER_B = nothing. */
+       DYCORE_PART_MOM_INNER_A = 13, DYCORE_PART_MOM_INNER_B = 14 };
 int dycore_overlap_parts(dycore_t *h);
 /* != 0: the fused step does not store UFLX / VFLX (its kernels re-form them from the winds and the
  * 2-D column pressures UCOL, VCOL at the u- / v-points; dycore_download still returns them, derived on

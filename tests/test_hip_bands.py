@@ -60,6 +60,21 @@ def test_local_bands_bitwise_equal_single(nbands, i_turb, i_moist, overlap):
     """overlap=True: the exchanges run on a second stream behind the inner rows (the schedule of
     the multi-GPU run); overlap=False: plain part / exchange sequence with host synchronisation;
     'native': the same overlapped schedule issued by the library itself (dycore_bands_step_matsuno)."""
+    _local_bands_vs_single(nbands, i_turb, i_moist, overlap)
+
+
+@pytest.mark.parametrize('overlap', [False, True, 'native'])
+@pytest.mark.parametrize('nbands,i_moist', [(2, 0), (3, 1), (5, 0)])
+def test_local_bands_on_the_whole_substep_kernel(nbands, i_moist, overlap, monkeypatch):
+    """DYCORE_BANDS_STEP_FUSED=1: a band's momentum and temperature kernels are one launch too (k_momentum_dma<..., WITH_TEMP>
+    in pieces: inner tile rows in two halves around the edge rows; by default only bands of six rounds of tiles and more --
+    slower on small bands, profiles/r03_notes.md).  Same bits as the single domain; the handles really launch that kernel."""
+    monkeypatch.setenv('DYCORE_BANDS_STEP_FUSED', '1')
+    stats = _local_bands_vs_single(nbands, 0, i_moist, overlap, want_stats=True)
+    assert all(st.get('k_substep_fused', (0, 0))[0] > 0 and st.get('k_temp_canon', (0, 0))[0] == 0 for st in stats), stats
+
+
+def _local_bands_vs_single(nbands, i_turb, i_moist, overlap, want_stats=False):
     native = overlap == 'native'
     overlap = bool(overlap)
     import torch
@@ -81,12 +96,17 @@ def test_local_bands_bitwise_equal_single(nbands, i_turb, i_moist, overlap):
     assert lb.overlap == overlap        # the split parts exist for the turbulence-coupled fused step too
     assert (lb.native is not None) == native
     lb.step_matsuno(GR.dt, 2)
+    if want_stats:
+        for c in cores:
+            c.profile(True)
     lb.step_matsuno(GR.dt, 1)          # a second call continues from halo rows the first one left in place
+    stats = [c.kernel_stats() for c in cores] if want_stats else None
     for n in check:
         got = gather_global(L, [c.download(n) for c in cores], n)
         np.testing.assert_array_equal(got, ref[n], err_msg='%s incl. halos (%d bands)' % (n, nbands))
     for c in cores:
         c.close()
+    return stats
 
 
 @pytest.mark.parametrize('nproc', [2, 4])

@@ -200,8 +200,9 @@ class HipDycore:
         nl = GR.nl
         args = dict(pair_top=nl.pair_top, i_turb=nl.i_turb, i_radiation=nl.i_POTT_radiation, i_moist=nl.i_moist_main_switch,
                     i_moist_clip=nl.i_moist_clip, term_off=nl.term_off, dtype=nl.wp)
+        ny = kw.pop('ny', GR.ny)            # a latitude band passes its own height (+ ny_global, j_offset)
         args.update(kw)
-        return cls(GR.nx, kw.pop('ny', GR.ny) if 'ny' in kw else GR.ny, GR.nz, **{k: v for k, v in args.items() if k != 'ny'})
+        return cls(GR.nx, ny, GR.nz, **args)
 
     # ---- plumbing ----
     def _check(self, rc):

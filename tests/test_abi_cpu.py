@@ -160,3 +160,28 @@ def test_momentum_level_loop_has_no_compiler_inserted_drain():
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if 'fw=1 turb=0' in l]
     assert len(lines) >= 6 and all('findings: none' in l for l in lines), r.stdout
+
+
+def test_term_switch_tables_agree():
+    """The per-term switches of namelist.py:62-88 travel as one bit mask: the bits in include/dycore.h (DYCORE_TERM_*), in
+    oracle/dycore_oracle.h (ORACLE_TERM_*), in climate_model_amd.namelist.TERM_BITS and in the tests' own table are the same,
+    the ctypes mirror of DycoreConfig has the header's layout, and Namelist.term_off sets exactly the bits of the entries at 0."""
+    import ctypes as C
+    from climate_model_amd.namelist import TERM_BITS, Namelist
+    from climate_model_amd.hip_backend import DycoreConfig
+    from golden_util import TERM_BITS as TEST_BITS
+    assert TERM_BITS == TEST_BITS
+    hdr = open(os.path.join(ROOT, 'include', 'dycore.h')).read()
+    c_bits = {m.group(1): 1 << int(m.group(2)) for m in re.finditer(r'#define DYCORE_TERM_(\w+)\s+\(1 << (\d+)\)', hdr)}
+    ohdr = open(os.path.join(ROOT, 'oracle', 'dycore_oracle.h')).read()
+    o_bits = {m.group(1): 1 << int(m.group(2)) for m in re.finditer(r'ORACLE_TERM_(\w+) = 1 << (\d+)', ohdr)}
+    assert c_bits == o_bits and len(c_bits) == len(TERM_BITS) == 14
+    for name, bit in TERM_BITS.items():         # i_UVFLX_hor_adv -> UVFLX_HOR_ADV, i_COLP_main_switch -> COLP_MAIN
+        key = name[2:].upper().replace('_MAIN_SWITCH', '_MAIN')
+        assert c_bits[key] == bit, name
+    assert Namelist().term_off == 0
+    assert Namelist(i_UVFLX_coriolis=0, i_moist_num_dif=0).term_off == TERM_BITS['i_UVFLX_coriolis'] | TERM_BITS['i_moist_num_dif']
+    # struct layout: 11 int32 + term_off + 4 reserved int32 (= 16 x 4 bytes), then the double and the pointer
+    names = [f[0] for f in DycoreConfig._fields_]
+    assert names.index('term_off') == names.index('i_moist_clip') + 1 and DycoreConfig.term_off.offset == 44
+    assert DycoreConfig.pair_top.offset == 64 and C.sizeof(DycoreConfig) == 80

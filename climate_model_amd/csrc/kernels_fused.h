@@ -391,6 +391,9 @@ constexpr size_t dma_lds_bytes(int tj, bool fw, bool cur, int depth, bool pl = f
 #ifndef DYC_WT_SKIP
 #define DYC_WT_SKIP 0       // experiment builds only (wrong results): WITH_TEMP without the temperature (1) / momentum (2) arithmetic
 #endif
+#ifndef DYC_EARLY_DMA
+#define DYC_EARLY_DMA 1     // the first DMA levels of a workgroup ahead of its prologue (k_momentum_dma)
+#endif
 #ifndef DYC_MOM_MODE
 #define DYC_MOM_MODE 0      // experiment builds only: 1 = data movement without the arithmetic, 2 = arithmetic without the data movement
 #endif
@@ -682,6 +685,13 @@ __global__ __launch_bounds__(FTI *TJ *(WITH_TEMP ? 2 : 1), ((TJ <= 4 && !WITH_TE
         }
     };
 
+    // The first levels go out HERE, ahead of the workgroup's 2-D loads, factor tiles and per-column arithmetic (sines, cosines,
+    // reciprocals: ~4 levels' worth of time), so that their latency lies under that prologue instead of behind it: what a
+    // workgroup pays once matters where a column is 32 levels or a chunk 4 (-DDYC_EARLY_DMA=0: issued behind the prologue)
+#if DYC_EARLY_DMA
+    issue(k1 - 1, 0);
+    if (AHEAD >= 2 && k1 - 2 >= k0) issue(k1 - 2, 1);
+#endif
     // per-level constants (p.mom_c, stride nz + 2): weights c_wa[k], c_wb[k] of the winds of levels k-1 and k in the
     // dsigma-weighted mean at interface k (dyn_functions.py:236-241), dsigma[k] / (dsigma[k] + dsigma[k-1]) and
     // dsigma[k-1] / (...); c_rds = 1 / dsigma; sigma_vb; UVFLX_dif_coef
@@ -789,8 +799,10 @@ __global__ __launch_bounds__(FTI *TJ *(WITH_TEMP ? 2 : 1), ((TJ <= 4 && !WITH_TE
         }
         constexpr int OWN_PO = OFF_OLD + 2 * ON, OWN_RAD = OFF_OLD + (NOWN - 1) * ON;
         const bool has_rad = g.i_rad;
+#if !DYC_EARLY_DMA
         issue(k1 - 1, 0);
         if (k1 - 2 >= k0) issue(k1 - 2, 1);
+#endif
         wait_vmcnt(k1 - 2 >= k0 ? n_issue : 0);
         if (FLUX_T) flux_own(0, (k1 - 1) & 1);
         lds_barrier();          // (the flux tiles of level k1-1: whichever role moves the winds)
@@ -983,8 +995,10 @@ __global__ __launch_bounds__(FTI *TJ *(WITH_TEMP ? 2 : 1), ((TJ <= 4 && !WITH_TE
     // their first use, inside the loop, where a vector-memory wait drains the DMA levels in flight
     asm volatile("" : "+v"(su_kp1), "+v"(sv_kp1), "+v"(u_kp1), "+v"(v_kp1), "+v"(pvb_kp1), "+v"(pvb_im1_kp1), "+v"(pvb_jm1_kp1), "+v"(phivb_c), "+v"(phivb_w), "+v"(phivb_s));
     // ---- prologue: the first DEPTH levels go out; level k1-1 lands and its flux tiles are formed ----
+#if !DYC_EARLY_DMA
     issue(k1 - 1, 0);
     if (AHEAD >= 2 && k1 - 2 >= k0) issue(k1 - 2, 1);
+#endif
     if (AHEAD >= 3 && k1 - 3 >= k0) issue(k1 - 3, 2);
     if (n_issue > 0) wait_vmcnt((AHEAD >= 2 && k1 - AHEAD >= k0) ? n_issue : 0);        // everything but the last level issued has landed
     flux_own(0, (k1 - 1) & 1);

@@ -605,3 +605,28 @@ def test_moisture_clip_matches_the_accelerator_rule(fused, monkeypatch):
             err, ncmp, bad = rel_max_err(core.download(n), o.F[n], n, GR.nx, GR.ny)
             assert bad == 0 and ncmp > 0 and err <= (1e-9 if n == 'QC' else STEP_TOL), (clip, n, err)
         core.close()
+
+
+def test_handle_from_namelist():
+    """HipDycore.from_namelist: the handle is configured from the Namelist the way the reference's kernels are configured by
+    the module globals of namelist.py -- extents, coupling switches, per-term switches, pair_top, working precision."""
+    from climate_model_amd import Namelist, Grid, ModelFields, HipDycore
+    from climate_model_amd.namelist import TERM_BITS
+    from climate_model_amd.synthetic import initialize_fields, initialize_moisture
+    GR = Grid(Namelist(nz=4, dlat_deg=10., dlon_deg=10., i_UVFLX_coriolis=0, i_POTT_num_dif=0, i_moist_main_switch=1))
+    core = HipDycore.from_namelist(GR)
+    assert core.term_off == TERM_BITS['i_UVFLX_coriolis'] | TERM_BITS['i_POTT_num_dif'] and core.i_moist and not core.i_turb
+    assert (core.nx, core.ny, core.nz) == (GR.nx, GR.ny, GR.nz)
+    core.set_grid(GR.GRF['HIP'])
+    F = ModelFields(GR, core)
+    initialize_fields(GR, F)
+    initialize_moisture(GR, F)
+    F.copy_host_to_device()
+    core.primary_diag()
+    core.step_matsuno(GR.dt, 2)
+    u = core.download('UWIND')
+    assert np.isfinite(u[1:GR.nx + 1, 1:GR.ny + 1]).all()
+    core.close()
+    band = HipDycore.from_namelist(GR, ny=GR.ny // 2, ny_global=GR.ny, j_offset=0)      # a latitude band of the same run
+    assert band.ny == GR.ny // 2 and band.term_off == core.term_off
+    band.close()

@@ -87,6 +87,10 @@ struct Ptrs {
     // sigma_vb, UVFLX_dif_coef): wa[k] = dsigma[k] / (dsigma[k] + dsigma[k-1]), wb[k] = dsigma[k-1] / (...) (0 at k = 0),
     // 1 / dsigma[k], sigma_vb[k] (nz + 1 entries), UVFLX_dif_coef[k]
     const real *mom_c;
+    // per-row constants of the momentum kernel, four arrays of stride NJ (formed on the device by k_row_constants whenever
+    // lat_rad / lat_is_rad / corf / corf_is are set: a latitude-longitude grid, they depend on the row only):
+    // corf_is RE cos(lat_is), sin(lat_is), corf RE cos(lat), sin(lat)
+    const real *row_c;
 };
 
 __device__ __forceinline__ size_t at(const Geo &g, int i, int j, int k)

@@ -147,6 +147,7 @@ struct dycore {
     // the same canonical forms (kernels_stage.h), so that results do not depend on the work list or the band decomposition
     bool lazy_phi = true;
     int step_fused_bands = -1;      // a latitude band on the whole-substep kernel: -1 when it is large enough (substep_fused), DYCORE_BANDS_STEP_FUSED=1 / 0 always / never
+    bool row_c_valid = false;       // Ptrs::row_c holds the per-row constants of the current lat_rad / lat_is_rad / corf / corf_is
     bool colp_old_ready = false;    // COLP_OLD already holds COLP (second destination of the copy rider that closed the previous step)
     bool rows_ready = false;        // the PHIVB planes of the rows the next whole-substep launch cuts into chunks are current (rider of the halo launch behind the continuity kernel)
     bool planes_valid = false;      // the PHIVB planes at every PHIVB_STRIDE-th interface hold the canonical integration of the current state (k_temp_canon keeps them)
@@ -547,6 +548,16 @@ int ensure_planes(dycore *h)
     h->planes_valid = true;
     return 0;
 }
+// the per-row constants of k_momentum_dma, once per set of grid arrays
+int ensure_row_constants(dycore *h)
+{
+    if (h->row_c_valid) return 0;
+    hipLaunchKernelGGL(k_row_constants, dim3((h->g.NJ + 63) / 64), dim3(64), 0, h->stream, h->g, h->p, const_cast<real *>(h->p.row_c));
+    int rc = launch_check("k_row_constants");
+    if (rc) return rc;
+    h->row_c_valid = true;
+    return 0;
+}
 // Work list of a k_momentum_dma launch (MomPlan).  With `slots` workgroups resident at a time, T tiles of nz levels take
 // ceil(T / slots) rounds; ks level chunks per tile take ceil(T * ks / slots) rounds of nz / ks levels + the chunk's
 // prologue (2-D loads, factor tiles, first DMA: ~mom_pro levels).  Candidates: the whole row set in 1 .. 16 chunks per
@@ -602,6 +613,7 @@ int do_momentum_fused(dycore *h, const Ptrs &p, const real *u_old, const real *v
         int rc = refresh_lazy(h, LAZY_PVTF | LAZY_PHI);
         if (rc) return rc;
     }
+    if (dma) { int rc = ensure_row_constants(h); if (rc) return rc; }
     Scope s(h, dma ? K_MOM_DMA : K_MOM_FUSED);      // stats under the name of the kernel that runs
     const int gbx = (h->g.nx + FTI - 1) / FTI, gby = (h->g.ny + FTJ - 1) / FTJ;
     const int nblk = gbx * gby;
@@ -731,6 +743,7 @@ int do_substep_fused(dycore *h, const Ptrs &p, const real *u_old, const real *v_
     const int gbx = (h->g.nx + FTI - 1) / FTI;
     MomPlan plan;
     if (!substep_plan(h, mode, plan)) return 0;
+    { int rc = ensure_row_constants(h); if (rc) return rc; }
     Scope s(h, K_SUBSTEP);
     const dim3 gr(plan.nblk_a + 8 * ((gbx * plan.b.n * plan.ks_b + 7) / 8)), blk(FTI, 2 * tj);
     const bool cur = (u_old == p.UWIND);
@@ -1174,6 +1187,11 @@ int dycore_create(const DycoreConfig *cfg, dycore_t **out)
         rc = alloc((size_t)(5 * (g.nz + 2)), &d);
         h->p.mom_c = d;
     }
+    if (!rc) {
+        real *d = nullptr;
+        rc = alloc((size_t)(4 * g.NJ), &d);
+        h->p.row_c = d;
+    }
     if (!rc && h->step_fused && !g.i_turb) {       // (substep_fused: the other conditions can change with the grid)
         rc = alloc(h->field_elems(-1), &h->pvb_alt);         // nz + 1 planes
     }
@@ -1312,6 +1330,7 @@ int dycore_set_grid(dycore_t *h, const char *name, const real *host, int32_t n0,
             const int bit = d.member == &Ptrs::lat_rad ? 1 : d.member == &Ptrs::lat_is_rad ? 2 : d.member == &Ptrs::corf ? 4 : 8;
             h->nonzonal = ok ? (h->nonzonal & ~bit) : (h->nonzonal | bit);
             h->zonal = h->nonzonal == 0;
+            h->row_c_valid = false;         // Ptrs::row_c is formed from these four (ensure_row_constants)
         }
         HIP_TRY(hipMemcpyAsync(h->stage, host, n * sizeof(real), hipMemcpyHostToDevice, h->stream));
         hipLaunchKernelGGL(k_to_device, dim3((n0 + 31) / 32, 1, n1), dim3(32, 8), 0, h->stream, g, h->stage, dev, n0, n1, 1);

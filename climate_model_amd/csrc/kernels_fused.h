@@ -902,11 +902,17 @@ __global__ __launch_bounds__(FTI *TJ *(WITH_TEMP ? 2 : 1), ((TJ <= 4 && !WITH_TE
     // Latitude and Coriolis parameter depend on the row only (a wavefront is one row of a latitude-longitude grid;
     // dycore_set_grid checks it and sends a handle with zonally varying arrays to the stage kernels): the six
     // Coriolis / metric factors live in scalar registers
-    const real lat_is = p.lat_is_rad[c];
-    const real kc_is = wave_uniform(p.corf_is[c] * CON_RE * cos(lat_is)), sin_is = wave_uniform(sin(lat_is));
-    const real lat = p.lat_rad[c], lat_jm1 = p.lat_rad[c - P];
-    const real kc_c = wave_uniform(p.corf[c] * CON_RE * cos(lat)), sin_c = wave_uniform(sin(lat));
-    const real kc_jm1 = wave_uniform(p.corf[c - P] * CON_RE * cos(lat_jm1)), sin_jm1 = wave_uniform(sin(lat_jm1));
+    // -- formed once per grid by k_row_constants (the same expressions, the same device functions: the same bits as when
+    // every workgroup evaluated three sines and cosines per wavefront in its prologue, ~1000 instructions of a launch's
+    // 4278 prologues) and read as scalar loads at the wavefront's row
+    real kc_is, sin_is, kc_c, sin_c, kc_jm1, sin_jm1;
+    {
+        const int jr = __builtin_amdgcn_readfirstlane((j <= g.ny) ? j : 1);       // (the row lane 0 -- always an owned column -- computes for)
+        cdouble_t *rc = (cdouble_t *)p.row_c;
+        kc_is = rc[jr]; sin_is = rc[g.NJ + jr];
+        kc_c = rc[2 * g.NJ + jr]; sin_c = rc[3 * g.NJ + jr];
+        kc_jm1 = rc[2 * g.NJ + jr - 1]; sin_jm1 = rc[3 * g.NJ + jr - 1];
+    }
     // per-column factors of the Coriolis / metric and pressure-gradient terms (formed once; the "/ 2" of the
     // reference's means are folded in exactly, the products are associated differently: <= 1 ulp each)
     const real hsin_is = 0.5 * sin_is, hsin_c = 0.5 * sin_c, hsin_jm1 = 0.5 * sin_jm1;
@@ -1225,6 +1231,19 @@ __global__ __launch_bounds__(FTI *TJ *(WITH_TEMP ? 2 : 1), ((TJ <= 4 && !WITH_TE
 //   TURB_T, TURB_QV, TURB_QC : dyn_functions.py:26-67 (turb_flux) as in k_pott_tendency<true>, k_moist<true>
 // One thread per owned column, levels top-down.  `rs`: the rows of this launch (a latitude band evaluates the rows
 // next to a neighbour once that neighbour's rows have arrived: every term reads rows j-1 .. j+1 at most).
+// the per-row Coriolis / metric constants of k_momentum_dma (Ptrs::row_c): one thread per row, column 1 (dycore_set_grid has
+// checked that the four arrays do not vary along a row)
+__global__ void k_row_constants(Geo g, Ptrs p, real *out)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= g.NJ) return;
+    const size_t c = at2(g, 1, j);
+    const real lat_is = p.lat_is_rad[c], lat = p.lat_rad[c];
+    out[j] = p.corf_is[c] * CON_RE * cos(lat_is);
+    out[g.NJ + j] = sin(lat_is);
+    out[2 * g.NJ + j] = p.corf[c] * CON_RE * cos(lat);
+    out[3 * g.NJ + j] = sin(lat);
+}
 __global__ __launch_bounds__(TI *TJ) void k_turb_tendencies(Geo g, Ptrs p, int jv_lo, int lin, RowSet rs)
 {
     int i, j;

@@ -709,15 +709,21 @@ __global__ __launch_bounds__(FTI *TJ *(WITH_TEMP ? 2 : 1), ((TJ <= 4 && !WITH_TE
 #pragma unroll
     for (int d = 0; d < VW; d++) { f_uc[d] = 0.0; f_vc[d] = 0.0; }
     real *fac = dsm + NS * DSLOT + 2 * FSLOT;
+    // The factor tiles' values are requested here and written to LDS at the END of the role's prologue (fac_publish), so that
+    // their round trip to memory lies under the role's own 2-D loads instead of in front of them
+    constexpr int NFAC = ((TJ + 3) * FTW + FTI * NTW - 1) / (FTI * NTW);
+    real fd_y[NFAC], fd_x[NFAC];
     if (FROM_WINDS) {
-        for (int e = tid; e < (TJ + 3) * FTW; e += FTI * NTW) {
+#pragma unroll
+        for (int n = 0; n < NFAC; n++) {
+            const int e = min(tid + n * FTI * NTW, (TJ + 3) * FTW - 1);
             const int r = e / FTW, cc = e - r * FTW, c2 = cc - cc % VW;
             const int gi = min(i0 - FXO + c2, P - VW) + (cc - c2);
             const int o = min(j0 - 1 + r, g.NJ - 1) * P + gi;
             // the reference never fills column nx+2 of its x-staggered grid arrays (main_grid.py:317-357):
             // take the periodic image the UFLX halo copy would have delivered
-            if (e < (TJ + 2) * FTW) fac[mom_off(S_UF, TJ, true) + e] = p.dyis[gi == g.nx + 2 ? o - g.nx : o];
-            fac[mom_off(S_VF, TJ, true) + e] = p.dxjs[o];
+            fd_y[n] = p.dyis[gi == g.nx + 2 ? o - g.nx : o];
+            fd_x[n] = p.dxjs[o];
         }
         if (flux_lane) {
 #pragma unroll
@@ -729,8 +735,18 @@ __global__ __launch_bounds__(FTI *TJ *(WITH_TEMP ? 2 : 1), ((TJ <= 4 && !WITH_TE
                 f_vc[d] = p.VCOL[o];
             }
         }
-        lds_barrier();          // the factor tiles are complete before the first flux entries are formed
     }
+    auto fac_publish = [&]() {
+        if (FROM_WINDS) {
+#pragma unroll
+            for (int n = 0; n < NFAC; n++) {
+                const int e = tid + n * FTI * NTW;
+                if (e < (TJ + 2) * FTW) fac[mom_off(S_UF, TJ, true) + e] = fd_y[n];
+                if (e < (TJ + 3) * FTW) fac[mom_off(S_VF, TJ, true) + e] = fd_x[n];
+            }
+            lds_barrier();          // the factor tiles are complete before the first flux entries are formed
+        }
+    };
     // flux tiles of a level (FROM_WINDS): every DMA lane turns the chunks IT moved into UFLX / VFLX
     // entries as soon as its own loads have landed -- no barrier between the DMA and this step, the one at
     // the end of the level publishes both
@@ -803,6 +819,7 @@ __global__ __launch_bounds__(FTI *TJ *(WITH_TEMP ? 2 : 1), ((TJ <= 4 && !WITH_TE
         issue(k1 - 1, 0);
         if (k1 - 2 >= k0) issue(k1 - 2, 1);
 #endif
+        fac_publish();
         wait_vmcnt(k1 - 2 >= k0 ? n_issue : 0);
         if (FLUX_T) flux_own(0, (k1 - 1) & 1);
         lds_barrier();          // (the flux tiles of level k1-1: whichever role moves the winds)
@@ -890,15 +907,35 @@ __global__ __launch_bounds__(FTI *TJ *(WITH_TEMP ? 2 : 1), ((TJ <= 4 && !WITH_TE
     const bool lo_u = __builtin_amdgcn_readfirstlane((int)lo) != 0, hi_u = __builtin_amdgcn_readfirstlane((int)hi) != 0;
     const real w24_lo = lo_u ? 0.0 : 1.0 / 24.0, w48_lo = lo_u ? 0.0 : 1.0 / 48.0;
     const real w24_hi = hi_u ? 0.0 : 1.0 / 24.0, w48_hi = hi_u ? 0.0 : 1.0 / 48.0;
-    real ca[3][3];
+    // Every 2-D value of the prologue is REQUESTED here, in one batch, before anything is computed from them: written where
+    // they are used, the ~45 loads went out in five groups with a wait behind each -- five round trips to memory, ~3 levels'
+    // worth of time, in each of a launch's 4278 workgroups
+    const size_t c1 = c + (size_t)k1 * g.plane;         // interface k1, the lower end of the chunk
+    real ca[3][3], a_[3][3], co[3][3];
 #pragma unroll
     for (int b = 0; b < 3; b++)
 #pragma unroll
         for (int a = 0; a < 3; a++) {
             const size_t q2 = c + (b - 1) * P + (a - 1);
-            ca[b][a] = p.COLP_NEW[q2] * p.A[q2];
+            ca[b][a] = p.COLP_NEW[q2]; a_[b][a] = p.A[q2]; co[b][a] = p.COLP_OLD[q2];
         }
     const real colp = p.COLP[c], colp_im1 = p.COLP[c - 1], colp_jm1 = p.COLP[c - P];
+    const real dlon_c = p.dlon_rad[c], dlat_c = p.dlat_rad[c], dyis_c = p.dyis[c], dxjs_c = p.dxjs[c];
+    real pvb_kp1 = p.PVTFVB[c1], pvb_im1_kp1 = p.PVTFVB[c1 - 1], pvb_jm1_kp1 = p.PVTFVB[c1 - P];
+    // PHIVB at interface k1 of the own column and its western / southern neighbour: the surface geopotential, or
+    // (chunks) what k_phivb_rows / k_temp_canon stored for every PHIVB_STRIDE-th interface.  The western neighbour of i = 1 is
+    // taken from its periodic image (misc_boundaries.py:22-31): nobody refreshes the lateral halo of those planes.
+    real phivb_c = 0.0, phivb_w = 0.0, phivb_s = 0.0;
+    if (PHI_LOCAL) {
+        const size_t cw = (active && i == 1) ? c - 1 + g.nx : c - 1;
+        if (k1 == nz) { phivb_c = p.HSURF[c]; phivb_w = p.HSURF[cw]; phivb_s = p.HSURF[c - P]; }
+        else { const size_t o = (size_t)k1 * g.plane; phivb_c = p.PHIVB[c + o]; phivb_w = p.PHIVB[cw + o]; phivb_s = p.PHIVB[c - P + o]; }
+    }
+#pragma unroll
+    for (int b = 0; b < 3; b++)
+#pragma unroll
+        for (int a = 0; a < 3; a++) { ca[b][a] = ca[b][a] * a_[b][a]; co[b][a] = co[b][a] * a_[b][a]; }
+    if (PHI_LOCAL && k1 == nz) { phivb_c = phivb_c * CON_G; phivb_w = phivb_w * CON_G; phivb_s = phivb_s * CON_G; }
     // Latitude and Coriolis parameter depend on the row only (a wavefront is one row of a latitude-longitude grid;
     // dycore_set_grid checks it and sends a handle with zonally varying arrays to the stage kernels): the six
     // Coriolis / metric factors live in scalar registers
@@ -918,8 +955,8 @@ __global__ __launch_bounds__(FTI *TJ *(WITH_TEMP ? 2 : 1), ((TJ <= 4 && !WITH_TE
     const real hsin_is = 0.5 * sin_is, hsin_c = 0.5 * sin_c, hsin_jm1 = 0.5 * sin_jm1;
     real cor_im1, cor_c, cov_jm1, cov_c, pgu_a, pgu_b, pgv_a, pgv_b;
     {
-        const real metric = CON_RE * p.dlon_rad[c] * p.dlat_rad[c] / 2.0;
-        const real dyis = p.dyis[c], dxjs = p.dxjs[c];
+        const real metric = CON_RE * dlon_c * dlat_c / 2.0;
+        const real dyis = dyis_c, dxjs = dxjs_c;
         cor_im1 = 0.5 * metric * colp_im1; cor_c = 0.5 * metric * colp;
         cov_jm1 = -0.5 * metric * colp_jm1; cov_c = -0.5 * metric * colp;
         pgu_a = -dyis * ((colp + colp_im1) / 2.0); pgu_b = -dyis * ((colp - colp_im1) * CON_CP / 2.0);
@@ -928,14 +965,6 @@ __global__ __launch_bounds__(FTI *TJ *(WITH_TEMP ? 2 : 1), ((TJ <= 4 && !WITH_TE
     real ca_is, cao_is, ca_js, cao_js;
     real wu[6], wv[6];
     {
-        real co[3][3];
-#pragma unroll
-        for (int b = 0; b < 3; b++)
-#pragma unroll
-            for (int a = 0; a < 3; a++) {
-                const size_t q2 = c + (b - 1) * P + (a - 1);
-                co[b][a] = p.COLP_OLD[q2] * p.A[q2];
-            }
 #define CA(a, b) ca[(b) + 1][(a) + 1]
 #define CO(a, b) co[(b) + 1][(a) + 1]
         if (lo) {
@@ -977,8 +1006,6 @@ __global__ __launch_bounds__(FTI *TJ *(WITH_TEMP ? 2 : 1), ((TJ <= 4 && !WITH_TE
     real wu_b = 0.0, wv_b = 0.0;          // WWIND*U, WWIND*V at interface k+2 (0 at the surface)
     real u_kp1 = 0.0, v_kp1 = 0.0, uo_kp1 = 0.0, vo_kp1 = 0.0;
     real tu_kp1 = 0.0, tv_kp1 = 0.0;      // tendencies of level k+1 without the vertical advection
-    const size_t c1 = c + (size_t)k1 * g.plane;         // interface k1, the lower end of the chunk
-    real pvb_kp1 = p.PVTFVB[c1], pvb_im1_kp1 = p.PVTFVB[c1 - 1], pvb_jm1_kp1 = p.PVTFVB[c1 - P];
     if (k1 < nz) {      // a chunk that ends inside the column: interface k1 and the winds below it
 #define WG(a, b) p.WWIND[c1 + (b) * P + (a)]
         su_kp1 = dot6(wu, WG(-1, 1), WG(0, 1), WG(-1, 0), WG(0, 0), WG(-1, -1), WG(0, -1));
@@ -986,15 +1013,6 @@ __global__ __launch_bounds__(FTI *TJ *(WITH_TEMP ? 2 : 1), ((TJ <= 4 && !WITH_TE
 #undef WG
         u_kp1 = p.UWIND[c1];
         v_kp1 = p.VWIND[c1];
-    }
-    // PHIVB at interface k1 of the own column and its western / southern neighbour: the surface geopotential, or
-    // (chunks) what k_pott_fused stored for every PHIVB_STRIDE-th interface.  The western neighbour of i = 1 is taken
-    // from its periodic image (misc_boundaries.py:22-31): nobody refreshes the lateral halo of those planes.
-    real phivb_c = 0.0, phivb_w = 0.0, phivb_s = 0.0;
-    if (PHI_LOCAL) {
-        const size_t cw = (active && i == 1) ? c - 1 + g.nx : c - 1;
-        if (k1 == nz) { phivb_c = p.HSURF[c] * CON_G; phivb_w = p.HSURF[cw] * CON_G; phivb_s = p.HSURF[c - P] * CON_G; }
-        else { const size_t o = (size_t)k1 * g.plane; phivb_c = p.PHIVB[c + o]; phivb_w = p.PHIVB[cw + o]; phivb_s = p.PHIVB[c - P + o]; }
     }
 
     // the values loaded above are complete before the level loop starts: left to itself the compiler waits for them at
@@ -1006,6 +1024,7 @@ __global__ __launch_bounds__(FTI *TJ *(WITH_TEMP ? 2 : 1), ((TJ <= 4 && !WITH_TE
     if (AHEAD >= 2 && k1 - 2 >= k0) issue(k1 - 2, 1);
 #endif
     if (AHEAD >= 3 && k1 - 3 >= k0) issue(k1 - 3, 2);
+    fac_publish();
     if (n_issue > 0) wait_vmcnt((AHEAD >= 2 && k1 - AHEAD >= k0) ? n_issue : 0);        // everything but the last level issued has landed
     flux_own(0, (k1 - 1) & 1);
     lds_barrier();

@@ -357,6 +357,11 @@ constexpr int mom_rows(int f, int tj, bool fw, bool pl = false, bool wt = false)
     if (f == S_PVTF && fw) return 0;        // formed in the thread from PVTFVB and the column pressure (below)
     if (f == S_PHI && pl) return 0;         // `pl` (PHI_LOCAL): carried up the column by the thread (below)
     if (f == S_POTT && wt) return tj + 2;   // `wt` (WITH_TEMP): the temperature wavefronts read POTT at j+1 as well
+    // (WITH_TEMP, 64 x 4: one row more of PVTFVB than anybody reads, so that every staged field has more than 3 x 64 chunks and
+    // ALL FOUR momentum wavefronts issue one DMA instruction per field and level: their count per level is then a compile-time
+    // constant and the loop's `s_waitcnt vmcnt(n)` an immediate instead of a ten-way ladder of scalar branches -- ~25 of the
+    // ~560 instructions a lone momentum wavefront issues per level, one every four clocks)
+    if (f == S_PVB && wt && tj == 4) return tj + 2;
     return f == S_UF ? tj + 2 : f == S_VF ? tj + 3 : f == S_UW ? tj + 2 : f == S_VW ? (fw ? tj + 3 : tj + 2) : f == S_W ? tj + 2 : tj + 1;
 }
 // LDS layout (doubles).  A DMA slot holds the staged fields of one level back to back (each rows x FTW), then the
@@ -370,6 +375,22 @@ constexpr int mom_off(int f, int tj, bool fw, bool pl = false, bool wt = false) 
     return o;
 }
 // own-cell tiles behind the staged ones (FTI wide): the step-start winds of the corrector; WITH_TEMP: + the step-start POTT of the corrector, + dPOTTdt_RAD
+// number of staged fields the momentum wavefronts move when each of them reaches into the last wavefront's 64-chunk slice (then
+// every momentum wavefront issues exactly that many DMA instructions per level), else 0; WITH_TEMP only -- elsewhere some
+// momentum wavefronts move the step-start tiles as well
+constexpr int mom_ni_const(int tj, bool fw, bool pl, bool wt, unsigned mv_t)
+{
+    if (!wt) return 0;
+    int n = 0;
+    for (int f = (fw ? 2 : 0); f < FNF; f++) {
+        if ((mv_t >> f) & 1u) continue;
+        const int chunks = mom_rows(f, tj, fw, pl, wt) * (FTW / VW);
+        if (chunks == 0) continue;
+        if (chunks <= (tj - 1) * 64) return 0;
+        n++;
+    }
+    return n;
+}
 constexpr int mom_own_tiles(bool cur, bool wt, bool tb = false) { return (cur ? 0 : 2) + (wt ? (cur ? 0 : 1) + 1 : 0) + (tb ? 2 : 0); }       // `tb`: + TURB_U, TURB_V (turbulence-coupled instances)       // (+ 1: the radiative heating rate, staged only on a handle with i_radiation)
 constexpr int mom_dma_slot(int tj, bool fw, bool cur, bool pl = false, bool wt = false, bool tb = false) { return mom_off(FNF, tj, fw, pl, wt) + mom_own_tiles(cur, wt, tb) * FTI * tj; }
 constexpr int mom_flux_slot(int tj, bool fw) { return fw ? (2 * tj + 5) * FTW : 0; }
@@ -633,6 +654,9 @@ __global__ __launch_bounds__(FTI *TJ *(WITH_TEMP ? 2 : 1), ((TJ <= 4 && !WITH_TE
         if (!OLD_IS_CUR && OLD_SHARED && wave < 2 * ONSL) n_issue++;
     }
     const real *src[FNF] = {p.UFLX, p.VFLX, p.UWIND, p.VWIND, p.WWIND, p.PHI, p.POTT, p.PVTF, p.PVTFVB};
+    // the momentum wavefronts' DMA instructions per level where that is the same number for all of them (WITH_TEMP: they move
+    // staged fields only, and every staged field reaches into the last wavefront's slice); 0: counted per wavefront (n_issue)
+    constexpr int NI_CONST = mom_ni_const(TJ, FROM_WINDS, PHI_LOCAL, WITH_TEMP, MV_T);
     const real *osrc = OLD_SHARED ? (wave < ONSL ? u_old : v_old) : ((wave == TJ - 2) ? u_old : v_old);
 
     auto issue = [&](int k, int slot) {
@@ -1216,7 +1240,11 @@ __global__ __launch_bounds__(FTI *TJ *(WITH_TEMP ? 2 : 1), ((TJ <= 4 && !WITH_TE
         if (WITH_TEMP) TRACE_PT(k, 2);
         // this wave's part of level k-1 has landed (the deeper prefetch stays in flight); form its flux entries
         if (k - 1 >= k0 && DYC_MOM_MODE != 2) {
-            if (n_issue > 0) wait_vmcnt((DEPTH == 2 && k - AHEAD >= k0) ? n_issue : 0);        // level k - AHEAD + 1 has landed (a wavefront that moves nothing does not wait for its stores either)
+            // level k - AHEAD + 1 has landed (a wavefront that moves nothing does not wait for its stores either)
+            if (NI_CONST > 0) {             // (every momentum wavefront issues NI_CONST instructions per level: an immediate)
+                if (DEPTH == 2 && k - AHEAD >= k0) wait_vmcnt(NI_CONST);
+                else wait_vmcnt(0);
+            } else if (n_issue > 0) wait_vmcnt((DEPTH == 2 && k - AHEAD >= k0) ? n_issue : 0);
             if (WITH_TEMP) TRACE_PT(k, 5);
             flux_own(slot1, (k - 1) & 1);
         }

@@ -437,6 +437,26 @@ __device__ __forceinline__ void lds_dma16(const void *gp, const void *lds)
 #endif
 }
 
+// The same instruction with the global address as SCALAR base + 32-bit unsigned lane offset (`saddr` form) and the LDS address as
+// scalar base + immediate: a staged field's address is (field base + k plane) -- wave-uniform -- plus the lane's chunk offset,
+// which never changes; formed as a 64-bit lane address it cost the momentum wavefront a dozen instructions per field and
+// level (scalar adds, a 64-bit vector add, shifts for the LDS address), five or six here.  A lone momentum wavefront issues one
+// instruction every four clocks, whatever its kind (profiles/r03_notes.md).
+template <unsigned LDS_IMM>
+__device__ __forceinline__ void lds_dma16s(const void *sbase_p, unsigned voff, unsigned lds_base)
+{
+    // (the base is wave-uniform by construction; spelt out so that the compiler keeps it in a scalar register pair -- a no-op
+    // where it already is one)
+    const unsigned long long sb_ = (unsigned long long)(size_t)sbase_p;
+    const unsigned lo_ = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)sb_), hi_ = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(sb_ >> 32));
+    const unsigned long long sbase = ((unsigned long long)hi_ << 32) | lo_;
+#if DYC_DMA_AUX == 2
+    asm volatile("s_add_u32 m0, %2, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 nt" ::"v"(voff), "s"(sbase), "s"(lds_base), "n"(LDS_IMM) : "memory", "m0", "scc");
+#else
+    asm volatile("s_add_u32 m0, %2, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds_base), "n"(LDS_IMM) : "memory", "m0", "scc");
+#endif
+}
+
 // a real that is the same in every lane of the wavefront, moved to scalar registers
 __device__ __forceinline__ double wave_uniform(double x)
 {
@@ -659,17 +679,23 @@ __global__ __launch_bounds__(FTI *TJ *(WITH_TEMP ? 2 : 1), ((TJ <= 4 && !WITH_TE
     constexpr int NI_CONST = mom_ni_const(TJ, FROM_WINDS, PHI_LOCAL, WITH_TEMP, MV_T);
     const real *osrc = OLD_SHARED ? (wave < ONSL ? u_old : v_old) : ((wave == TJ - 2) ? u_old : v_old);
 
+    // the lane's chunk as a byte offset from (field base + k plane - one row): tile column 0 of the first tile is longitude -1 of
+    // its row, so `goff` can be -1; biased by a row the offset is unsigned
+    const unsigned voff = (unsigned)(goff + P) * (unsigned)sizeof(real);
+    const unsigned lds0 = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(size_t)dsm);       // LDS byte address of the ring
     auto issue = [&](int k, int slot) {
         real *buf = dsm + slot * DSLOT;
         if (sl < NSL) {
             if (dma_on) {
-#pragma unroll
-                for (int f = (FROM_WINDS ? 2 : 0); f < FNF; f++) {
-                    if ((((MV_T >> f) & 1u) != 0) == role_t && ch < MROWS(f) * CPR) {
-                        const real *gp = src[f] + (size_t)k * g.plane + goff;
-                        lds_dma16(gp, buf + MOFF(f) + sl * 64 * VW);
-                    }
-                }
+                const size_t kp = (size_t)k * g.plane - (size_t)P;
+                const unsigned lds_sl = lds0 + (unsigned)((slot * DSLOT + sl * 64 * VW) * (int)sizeof(real));
+                // (spelt out per field: the field's offset inside the slot is an immediate of the instruction that sets M0)
+#define DMA_FIELD(F_)                                                                                                        \
+                if ((F_) >= (FROM_WINDS ? 2 : 0) && ((((MV_T >> (F_)) & 1u) != 0) == role_t) && ch < MROWS(F_) * CPR)             \
+                    lds_dma16s<(unsigned)(MOFF(F_) * sizeof(real))>(src[F_] + kp, voff, lds_sl);
+                DMA_FIELD(0) DMA_FIELD(1) DMA_FIELD(2) DMA_FIELD(3) DMA_FIELD(4) DMA_FIELD(5) DMA_FIELD(6) DMA_FIELD(7) DMA_FIELD(8)
+#undef DMA_FIELD
+                static_assert(FNF == 9, "DMA_FIELD list");
             }
         }
         if (WITH_TEMP) {

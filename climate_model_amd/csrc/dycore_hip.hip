@@ -933,7 +933,8 @@ int substep_part(dycore *h, real dt, int sub, int part)
         switch (part) {
         case 0: {                   // -> UFLX, VFLX, WWIND, COLP_NEW halo rows
             PlaneRows pr;           // (+ the PHIVB planes the whole-substep launch of part 1 starts its level chunks from)
-            const bool rider = substep_fused(h) && substep_plane_rows(h, q, pr);
+            // (a whole domain only: a band issues the launch in pieces, each with the planes of its own cut rows)
+            const bool rider = substep_fused(h) && h->g.pole_s && h->g.pole_n && substep_plane_rows(h, q, pr);
             return do_continuity_fused(h, q, dt, rider ? &pr : nullptr);
         }
         case DYCORE_PART_MOM_INNER:     // turbulence-coupled: the turbulent tendencies of the same rows first

@@ -257,12 +257,17 @@ def _overlapped_step(cores, streams, deliver, dt, nsteps, with_rho):
             for c in cores:
                 c.substep_part(dt, sub, 0)
             on_comm('AB2', sub)
+            # (the library's own schedule, csrc/dycore_bands.h: a handle on the whole-substep kernel hides B1 behind the second
+            # half of its inner tile rows; on two kernels INNER_A is the whole inner piece, INNER_B nothing, and part TEMP --
+            # the temperature kernel -- hides it)
             for c in cores:
-                c.substep_part(dt, sub, C0.PART_MOM_INNER)
+                c.substep_part(dt, sub, C0.PART_MOM_INNER_A)
             streams.wait('AB2')
             for c in cores:
                 c.substep_part(dt, sub, C0.PART_MOM_EDGE)
             on_comm('B1', sub)
+            for c in cores:
+                c.substep_part(dt, sub, C0.PART_MOM_INNER_B)
             for c in cores:
                 c.substep_part(dt, sub, C0.PART_TEMP)
         if turb and step < nsteps - 1:

@@ -326,6 +326,7 @@ class HipDycore:
 
     # pieces of part 1 (include/dycore.h) between which the neighbour exchanges are hidden
     PART_MOM_INNER, PART_MOM_EDGE, PART_TEMP = 10, 11, 12
+    PART_MOM_INNER_A, PART_MOM_INNER_B = 13, 14        # MOM_INNER in two halves around the edge piece (include/dycore.h)
 
     @property
     def overlap_parts(self):

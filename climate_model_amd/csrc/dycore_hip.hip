@@ -841,10 +841,11 @@ int do_moist(dycore *h, const Ptrs &p, const real *qv_old, const real *qc_old, r
     const dim3 gr = grid_cells(h), bl(TI, TJ);
     const int lin = cells_linear(h);
     if (qv_out) {
-        if (h->g.i_turb && fused_path(h)) hipLaunchKernelGGL((k_moist<false, true, true, true>), gr, bl, 0, h->stream, h->g, p, qv_old, qc_old, qv_out, qc_out, dt, lin);
+        // the fused step: k_moist_canon (the level's arithmetic in the forms the whole-substep kernel's temperature wavefronts use)
+        if (h->g.i_turb && fused_path(h)) hipLaunchKernelGGL((k_moist_canon<true, true>), gr, bl, 0, h->stream, h->g, p, qv_old, qc_old, qv_out, qc_out, dt, lin);
         else if (h->g.i_turb) hipLaunchKernelGGL((k_moist<true, true>), gr, bl, 0, h->stream, h->g, p, qv_old, qc_old, qv_out, qc_out, dt, lin);
-        else if (fused_path(h) && flux_from_winds(h) && (h->fw_mask & 4)) hipLaunchKernelGGL((k_moist<false, true, true>), gr, bl, 0, h->stream, h->g, p, qv_old, qc_old, qv_out, qc_out, dt, lin);
-        else hipLaunchKernelGGL((k_moist<false, true>), gr, bl, 0, h->stream, h->g, p, qv_old, qc_old, qv_out, qc_out, dt, lin);
+        else if (fused_path(h) && flux_from_winds(h) && (h->fw_mask & 4)) hipLaunchKernelGGL((k_moist_canon<true>), gr, bl, 0, h->stream, h->g, p, qv_old, qc_old, qv_out, qc_out, dt, lin);
+        else hipLaunchKernelGGL((k_moist_canon<false>), gr, bl, 0, h->stream, h->g, p, qv_old, qc_old, qv_out, qc_out, dt, lin);
     } else {
         if (h->g.i_turb) hipLaunchKernelGGL((k_moist<true, false>), gr, bl, 0, h->stream, h->g, p, qv_old, qc_old, qv_out, qc_out, dt, lin);
         else hipLaunchKernelGGL((k_moist<false, false>), gr, bl, 0, h->stream, h->g, p, qv_old, qc_old, qv_out, qc_out, dt, lin);

@@ -1735,6 +1735,93 @@ __global__ __launch_bounds__(TI *TJ) void k_pott_fused(Geo g, Ptrs p, const real
 
 
 // ------------------------------------------------------------------------------------
+// k_moist_canon: QV / QC of the fused step (dyn_moist.py:201-243 + the QV / QC part of dyn_timestep.py) -- k_moist<., EULER>'s
+// data flow and software pipeline with the arithmetic of a level written as the temperature sweep's is (TEMP_PARTIAL /
+// TEMP_CLOSE: horizontal advection and diffusion of level k, then the vertical advection between its two interfaces and the
+// pressure-weighted Euler step, every rounding spelt out).  Moisture IS that arithmetic with another interface value -- the
+// logarithmic interpolation of dyn_functions.py:70-95 instead of POTTVB -- and written with the same macros the kernel
+// produces the same bits wherever the level is evaluated: here (latitude bands, turbulence-coupled handles), or by the
+// temperature wavefronts of the whole-substep kernel (k_momentum_dma<..., WITH_TEMP, MOIST>), which walk the column the other
+// way round.  Against k_moist<., EULER> the sums are associated differently (the "/ 2" of the face means applied once, the
+// diffusion joined to the advection before the vertical term): a few ulp per level.
+// FROM_WINDS / TURB_PRE as in k_moist.
+template <bool FROM_WINDS, bool TURB_PRE = false>
+__global__ __launch_bounds__(TI *TJ) void k_moist_canon(Geo g, Ptrs p, const real *qv_old, const real *qc_old,
+                                                        real *qv_out, real *qc_out, real dt, int lin)
+{
+    int i, j;
+    if (!owned_cell(g, lin, i, j)) return;
+    const int P = g.P, nz = g.nz;
+    const size_t c = at2(g, i, j);
+    const real colp = p.COLP[c], cnew = p.COLP_NEW[c], cold = p.COLP_OLD[c];
+    const real c_im1 = p.COLP[c - 1], c_ip1 = p.COLP[c + 1], c_jm1 = p.COLP[c - P], c_jp1 = p.COLP[c + P];
+    const real hr_area = (real)(0.5 * (1.0 / p.A[c])), r_cnew = (real)(1.0 / cnew);
+    __shared__ real s_met[FROM_WINDS ? 4 : 1][TI * TJ];
+    const int st = threadIdx.y * TI + threadIdx.x;
+    if (FROM_WINDS) {
+        s_met[0][st] = p.dyis[c]; s_met[1][st] = p.dyis[c + 1]; s_met[2][st] = p.dxjs[c]; s_met[3][st] = p.dxjs[c + P];
+    }
+    const real *fu = FROM_WINDS ? p.UWIND : p.UFLX, *fv = FROM_WINDS ? p.VWIND : p.VFLX;
+    struct In { real uf, uf1, vf, vf1, w1, qv1, qc1, v_im1, v_ip1, v_jm1, v_jp1, c_im1, c_ip1, c_jm1, c_jp1, vo, co; };
+    auto load = [&](int k) {
+        In r;
+        const size_t q = c + (size_t)k * g.plane;
+        r.uf = fu[q]; r.uf1 = fu[q + 1]; r.vf = fv[q]; r.vf1 = fv[q + P];
+        const bool last = (k == nz - 1);
+        r.w1 = last ? 0.0 : p.WWIND[q + g.plane];
+        r.qv1 = last ? 0.0 : p.QV[q + g.plane];
+        r.qc1 = last ? 0.0 : p.QC[q + g.plane];
+        r.v_im1 = p.QV[q - 1]; r.v_ip1 = p.QV[q + 1]; r.v_jm1 = p.QV[q - P]; r.v_jp1 = p.QV[q + P];
+        r.c_im1 = p.QC[q - 1]; r.c_ip1 = p.QC[q + 1]; r.c_jm1 = p.QC[q - P]; r.c_jp1 = p.QC[q + P];
+        r.vo = qv_old[q]; r.co = qc_old[q];
+        return r;
+    };
+    real qv_k = p.QV[c], qc_k = p.QC[c];
+    LogCache lv_k = log_cache(qv_k), lc_k = log_cache(qc_k);
+    real w_k = 0.0, vbv_k = 0.0, vbc_k = 0.0;       // sigma-dot and the interface values at interface k (0 at the model top)
+    In nxt = load(0);
+#pragma unroll 1
+    for (int k = 0; k < nz; k++) {
+        const size_t q = c + (size_t)k * g.plane;
+        const In cur = nxt;
+        if (k + 1 < nz) nxt = load(k + 1);
+        const real dif = p.moist_dif_coef[k], rds = p.rdsigma[k];
+        real uflx = cur.uf, uflx_ip1 = cur.uf1, vflx = cur.vf, vflx_jp1 = cur.vf1;
+        if (FROM_WINDS) {           // dyn_continuity.py:40-45, operand order of k_continuity_reg (= the flux tiles of k_momentum_dma)
+            uflx = (c_im1 + colp) / 2.0 * uflx * s_met[0][st];
+            uflx_ip1 = (colp + c_ip1) / 2.0 * uflx_ip1 * s_met[1][st];
+            vflx = (c_jm1 + colp) / 2.0 * vflx * s_met[2][st];
+            vflx_jp1 = (colp + c_jp1) / 2.0 * vflx_jp1 * s_met[3][st];
+        }
+        const bool last = (k == nz - 1);
+        // the lower interface k+1: sigma-dot times the interface values (0 at the surface: sigma-dot vanishes there)
+        real w_kp1 = 0.0, vbv_kp1 = 0.0, vbc_kp1 = 0.0;
+        LogCache lv_kp1 = log_cache(cur.qv1), lc_kp1 = log_cache(cur.qc1);
+        if (!last) {
+            w_kp1 = cur.w1;
+            vbv_kp1 = varvb_log_cached(lv_kp1, lv_k);
+            vbc_kp1 = varvb_log_cached(lc_kp1, lc_k);
+        }
+        const real lpv = mul_rn(w_kp1, vbv_kp1), lpc = mul_rn(w_kp1, vbc_kp1);
+        TEMP_PARTIAL(tpv, colp, c_im1, c_ip1, c_jm1, c_jp1, hr_area, uflx, uflx_ip1, vflx, vflx_jp1, qv_k, cur.v_im1, cur.v_ip1, cur.v_jm1, cur.v_jp1, dif, false, 0.0)
+        TEMP_PARTIAL(tpc, colp, c_im1, c_ip1, c_jm1, c_jp1, hr_area, uflx, uflx_ip1, vflx, vflx_jp1, qc_k, cur.c_im1, cur.c_ip1, cur.c_jm1, cur.c_jp1, dif, false, 0.0)
+        if (TURB_PRE) { tpv = tpv + p.TURB_QV[q]; tpc = tpc + p.TURB_QC[q]; }
+        TEMP_CLOSE(nv_, tpv, cnew, cold, r_cnew, w_k, vbv_k, lpv, rds, cur.vo, dt)
+        TEMP_CLOSE(nc_, tpc, cnew, cold, r_cnew, w_k, vbc_k, lpc, rds, cur.co, dt)
+        real nv = nv_, nc = nc_;
+        if (g.i_moist_clip) {       // dyn_timestep.py:145-154: `if QV < 0: QV = 0` (a NaN stays a NaN)
+            if (nv < 0.0) nv = 0.0;
+            if (nc < 0.0) nc = 0.0;
+        }
+        qv_out[q] = nv;
+        qc_out[q] = nc;
+        qv_k = cur.qv1; qc_k = cur.qc1;
+        lv_k = lv_kp1; lc_k = lc_kp1;
+        w_k = w_kp1; vbv_k = vbv_kp1; vbc_k = vbc_kp1;
+    }
+}
+
+// ------------------------------------------------------------------------------------
 // k_temp_canon: the temperature kernel of the production dry / moist step (latitude bands; one GPU with
 // DYCORE_STEP_FUSED=0): dPOTTdt (dyn_POTT.py:180-216) + Euler step of POTT (dyn_timestep.py:70-79) + the Exner function
 // of the new column (dyn_diagnostics.py:139-156) in one bottom-up sweep.  Against k_pott_fused it moves two fields less:

@@ -147,6 +147,7 @@ struct dycore {
     // the same canonical forms (kernels_stage.h), so that results do not depend on the work list or the band decomposition
     bool lazy_phi = true;
     int step_fused_bands = -1;      // a latitude band on the whole-substep kernel: -1 when it is large enough (substep_fused), DYCORE_BANDS_STEP_FUSED=1 / 0 always / never
+    bool moist_fused = true;        // QV / QC advanced by the whole-substep kernel's temperature wavefronts (DYCORE_MOIST_FUSED=0: k_moist_canon behind it)
     bool row_c_valid = false;       // Ptrs::row_c holds the per-row constants of the current lat_rad / lat_is_rad / corf / corf_is
     bool colp_old_ready = false;    // COLP_OLD already holds COLP (second destination of the copy rider that closed the previous step)
     bool rows_ready = false;        // the PHIVB planes of the rows the next whole-substep launch cuts into chunks are current (rider of the halo launch behind the continuity kernel)
@@ -736,8 +737,11 @@ void finish_substep_fused(dycore *h)
     h->stale_pvtf = true; h->stale_phi = true; h->stale_phivb = true; h->stale_pottvb = true;
     h->planes_valid = false;        // this launch neither reads nor writes the planes as a whole
 }
+// the whole-substep launch advances QV / QC as well
+bool moist_in_substep(const dycore *h) { return h->g.i_moist && h->moist_fused && substep_fused(h); }
 int do_substep_fused(dycore *h, const Ptrs &p, const real *u_old, const real *v_old, const real *pott_old,
-                     real *u_out, real *v_out, real *pott_out, real dt, int mode = ROWS_ALL)
+                     real *u_out, real *v_out, real *pott_out, real dt, int mode = ROWS_ALL,
+                     const real *qv_old = nullptr, const real *qc_old = nullptr, real *qv_out = nullptr, real *qc_out = nullptr)
 {
     constexpr int tj = 4;
     const int gbx = (h->g.nx + FTI - 1) / FTI;
@@ -774,14 +778,20 @@ int do_substep_fused(dycore *h, const Ptrs &p, const real *u_old, const real *v_
 #ifdef DYC_TRACE
     static long long *trace_buf = nullptr;
     if (!trace_buf && hipMalloc((void **)&trace_buf, 8 * 256 * 8 * sizeof(long long)) == hipSuccess) (void)hipMemset(trace_buf, 0, 8 * 256 * 8 * sizeof(long long));
-    const TempArgs ta = {pott_old, pott_out, h->pvb_alt, trace_buf};
+    const TempArgs ta = {pott_old, pott_out, h->pvb_alt, trace_buf, qv_old, qc_old, qv_out, qc_out};
     h->trace_buf = trace_buf;
 #else
-    const TempArgs ta = {pott_old, pott_out, h->pvb_alt, nullptr};
+    const TempArgs ta = {pott_old, pott_out, h->pvb_alt, nullptr, qv_old, qc_old, qv_out, qc_out};
 #endif
     const int jv_lo = h->g.pole_s ? 2 : 1;
     // (whole columns: PHI starts from the surface geopotential in every thread, no stored PHIVB plane is read or written)
-    if (cur) hipLaunchKernelGGL((k_momentum_dma<true, tj, true, false, 2, true, true>), gr, blk, dma_lds_bytes(tj, true, true, 2, true, true), h->stream,
+    if (moist_in_substep(h)) {
+        if (!qv_out || !qc_out || !qv_old || !qc_old) return fail(DYCORE_ESTATE, "whole-substep launch of a moist handle without its QV / QC buffers");
+        if (cur) hipLaunchKernelGGL((k_momentum_dma<true, tj, true, false, 2, true, true, true>), gr, blk, dma_lds_bytes(tj, true, true, 2, true, true, false, true), h->stream,
+                                    h->g, p, gbx, plan, jv_lo, u_old, v_old, u_out, v_out, dt, ta);
+        else hipLaunchKernelGGL((k_momentum_dma<false, tj, true, false, 2, true, true, true>), gr, blk, dma_lds_bytes(tj, true, false, 2, true, true, false, true), h->stream,
+                                h->g, p, gbx, plan, jv_lo, u_old, v_old, u_out, v_out, dt, ta);
+    } else if (cur) hipLaunchKernelGGL((k_momentum_dma<true, tj, true, false, 2, true, true>), gr, blk, dma_lds_bytes(tj, true, true, 2, true, true), h->stream,
                                 h->g, p, gbx, plan, jv_lo, u_old, v_old, u_out, v_out, dt, ta);
     else hipLaunchKernelGGL((k_momentum_dma<false, tj, true, false, 2, true, true>), gr, blk, dma_lds_bytes(tj, true, false, 2, true, true), h->stream,
                             h->g, p, gbx, plan, jv_lo, u_old, v_old, u_out, v_out, dt, ta);
@@ -931,6 +941,7 @@ int substep_part(dycore *h, real dt, int sub, int part)
         real *u_out = sub == 0 ? p.UWIND_EST : p.UWIND;
         real *v_out = sub == 0 ? p.VWIND_EST : p.VWIND;
         real *t_out = sub == 0 ? p.POTT_EST : p.POTT;
+        real *qv_out = sub == 0 ? p.QV_EST : p.QV, *qc_out = sub == 0 ? p.QC_EST : p.QC;
         switch (part) {
         case 0: {                   // -> UFLX, VFLX, WWIND, COLP_NEW halo rows
             PlaneRows pr;           // (+ the PHIVB planes the whole-substep launch of part 1 starts its level chunks from)
@@ -945,12 +956,13 @@ int substep_part(dycore *h, real dt, int sub, int part)
             // the alternate buffer, swapped in by part TEMP -- PVTFVB of its rows
             if (substep_fused(h))
                 return do_substep_fused(h, q, p.UWIND, p.VWIND, p.POTT, u_out, v_out, t_out, dt,
-                                        part == DYCORE_PART_MOM_INNER ? ROWS_INNER : part == DYCORE_PART_MOM_INNER_A ? ROWS_INNER_A : ROWS_INNER_B);
+                                        part == DYCORE_PART_MOM_INNER ? ROWS_INNER : part == DYCORE_PART_MOM_INNER_A ? ROWS_INNER_A : ROWS_INNER_B,
+                                        p.QV, p.QC, qv_out, qc_out);
             if (part == DYCORE_PART_MOM_INNER_B) return 0;      // (two kernels: INNER_A is the whole inner piece, part TEMP hides the wind rows)
             if (h->g.i_turb && (rc = do_turb_tendencies(h, q, ROWS_INNER))) return rc;
             return do_momentum_fused(h, q, p.UWIND, p.VWIND, u_out, v_out, dt, ROWS_INNER);
         case DYCORE_PART_MOM_EDGE:  // -> new winds complete: their rows can travel while part TEMP runs
-            if (substep_fused(h)) return do_substep_fused(h, q, p.UWIND, p.VWIND, p.POTT, u_out, v_out, t_out, dt, ROWS_EDGE);
+            if (substep_fused(h)) return do_substep_fused(h, q, p.UWIND, p.VWIND, p.POTT, u_out, v_out, t_out, dt, ROWS_EDGE, p.QV, p.QC, qv_out, qc_out);
             if (h->g.i_turb && (rc = do_turb_tendencies(h, q, ROWS_EDGE))) return rc;
             // the rows that leave now are packed with their periodic images (k_rows); the lateral halo of
             // the new winds is refreshed with everything else at the end of part TEMP
@@ -958,7 +970,7 @@ int substep_part(dycore *h, real dt, int sub, int part)
         case 1:
         case DYCORE_PART_TEMP: {    // momentum reads the old diagnostics, so it runs first
             if (substep_fused(h)) {
-                if (part == 1 && (rc = do_substep_fused(h, q, p.UWIND, p.VWIND, p.POTT, u_out, v_out, t_out, dt))) return rc;
+                if (part == 1 && (rc = do_substep_fused(h, q, p.UWIND, p.VWIND, p.POTT, u_out, v_out, t_out, dt, ROWS_ALL, p.QV, p.QC, qv_out, qc_out))) return rc;
                 finish_substep_fused(h);        // (the pieces of a split part 1 have all been issued by now)
             } else {
                 if (part == 1) {
@@ -967,8 +979,8 @@ int substep_part(dycore *h, real dt, int sub, int part)
                 }
                 if ((rc = do_pott_fused(h, q, p.POTT, t_out, dt))) return rc;
             }
-            real *qv_out = sub == 0 ? p.QV_EST : p.QV, *qc_out = sub == 0 ? p.QC_EST : p.QC;
-            if (h->g.i_moist && (rc = do_moist(h, q, p.QV, p.QC, qv_out, qc_out, dt))) return rc;
+            // (QV, QC: by the whole-substep launch itself, or by the moisture kernel behind it)
+            if (h->g.i_moist && !moist_in_substep(h) && (rc = do_moist(h, q, p.QV, p.QC, qv_out, qc_out, dt))) return rc;
             const int nz = h->g.nz;
             if (h->g.i_moist && (rc = do_halo(h, {{qv_out, 0, 0, nz}, {qc_out, 0, 0, nz}}))) return rc;
             std::vector<HaloSpec> hl = {{t_out, 0, 0, nz}, {p.PVTFVB, 0, 0, nz + 1}};
@@ -1067,6 +1079,7 @@ int dycore_create(const DycoreConfig *cfg, dycore_t **out)
     if (g.term_off) h->fused = false;       // a tendency term switched off (namelist.py:62-88): the stage kernels carry the switches
     if (const char *e = getenv("DYCORE_FUSED_TURB")) h->fused_turb = atoi(e) != 0;          // 0: stage kernels for turbulence-coupled handles
     if (const char *e = getenv("DYCORE_BANDS_STEP_FUSED")) h->step_fused_bands = atoi(e) != 0;  // 1 / 0: latitude bands always / never on the whole-substep kernel (default: large bands, see substep_fused)
+    if (const char *e = getenv("DYCORE_MOIST_FUSED")) h->moist_fused = atoi(e) != 0;        // 0: the moisture kernel as a launch of its own behind the whole-substep kernel
     if (const char *e = getenv("DYCORE_STEP_FUSED")) h->step_fused = atoi(e) != 0;          // 0: momentum and temperature as two kernels on one GPU too (what a band runs)
     if (const char *e = getenv("DYCORE_LAZY_PHI")) h->lazy_phi = atoi(e) != 0;              // 0: PHI and POTTVB stored and staged (round 2's data flow)
     if (const char *e = getenv("DYCORE_MOM_KS")) h->mom_ks = atoi(e);                       // level chunks per tile forced (work-list tests)
@@ -1107,6 +1120,12 @@ int dycore_create(const DycoreConfig *cfg, dycore_t **out)
         if (hipFuncSetAttribute((const void *)k_momentum_dma<false, 4, true, false, 2, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)dma_lds_bytes(4, true, false, 2, true, true)) != hipSuccess) { (void)hipGetLastError(); ok_wt = false; }
         if (!ok_wt) h->step_fused = false;
+        bool ok_mo = true;      // ... and with the moisture sweep in its temperature wavefronts
+        if (hipFuncSetAttribute((const void *)k_momentum_dma<true, 4, true, false, 2, true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)dma_lds_bytes(4, true, true, 2, true, true, false, true)) != hipSuccess) { (void)hipGetLastError(); ok_mo = false; }
+        if (hipFuncSetAttribute((const void *)k_momentum_dma<false, 4, true, false, 2, true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)dma_lds_bytes(4, true, false, 2, true, true, false, true)) != hipSuccess) { (void)hipGetLastError(); ok_mo = false; }
+        if (!ok_mo) h->moist_fused = false;
 #define MOM_ATTR(CUR_, FW_, TB_, DP_, FLAG_) MOM_ATTR_T(CUR_, FTJ, FW_, TB_, DP_, FLAG_)
 #ifdef DYCORE_AB_SWITCHES
         MOM_ATTR_T(true, 4, true, false, 1, ok_half)

@@ -348,9 +348,13 @@ constexpr int DMAXZ = 160;                        // levels up to which the LDS-
 // holds anyway, with a per-column reciprocal 1 / ((1 + kappa) COLP) and 1 / dsigma[k]: 58 instead of 67 tile rows
 // through the DMA per level.  The kernel's time is its data movement (profiles/r02_notes.md), the arithmetic
 // rides along.  The quotient differs from the stored PVTF by the rounding of p[k+1] - p[k] (~4e-15 relative).
-enum { S_UF = 0, S_VF, S_UW, S_VW, S_W, S_PHI, S_POTT, S_PVTF, S_PVB };
-constexpr int mom_rows(int f, int tj, bool fw, bool pl = false, bool wt = false)
+enum { S_UF = 0, S_VF, S_UW, S_VW, S_W, S_PHI, S_POTT, S_PVTF, S_PVB, S_QV, S_QC };
+constexpr int DNF = 11;                 // staged field slots of k_momentum_dma: the nine of k_momentum_fused + QV, QC (`mo`, below)
+constexpr int mom_rows(int f, int tj, bool fw, bool pl = false, bool wt = false, bool mo = false)
 {
+    // `mo` (MOIST, with WITH_TEMP): the temperature wavefronts advect QV and QC as well (k_moist_canon's arithmetic): their
+    // tiles with one halo row and column on each side, like POTT's
+    if (f == S_QV || f == S_QC) return mo ? tj + 2 : 0;
 #ifdef DYC_MOM_NOHALO       // experiment builds only (wrong results): no halo rows staged
     return tj;
 #endif
@@ -367,37 +371,39 @@ constexpr int mom_rows(int f, int tj, bool fw, bool pl = false, bool wt = false)
 // LDS layout (doubles).  A DMA slot holds the staged fields of one level back to back (each rows x FTW), then the
 // two step-start tiles of the corrector (tj rows each); with `fw` (fluxes re-formed from the winds) UFLX / VFLX
 // are not staged: they live in their own two-slot ring, written by the DMA wavefronts (flux_own).
-constexpr int mom_off(int f, int tj, bool fw, bool pl = false, bool wt = false)     // offset of field f inside its slot; f = FNF: the step-start tiles
+constexpr int mom_off(int f, int tj, bool fw, bool pl = false, bool wt = false, bool mo = false)     // offset of field f inside its slot; f = DNF: the step-start tiles
 {
     if (fw && f < 2) return f == S_UF ? 0 : (tj + 2) * FTW;
     int o = 0;
-    for (int g = (fw ? 2 : 0); g < f; g++) o += mom_rows(g, tj, fw, pl, wt) * FTW;
+    for (int g = (fw ? 2 : 0); g < f; g++) o += mom_rows(g, tj, fw, pl, wt, mo) * FTW;
     return o;
 }
 // own-cell tiles behind the staged ones (FTI wide): the step-start winds of the corrector; WITH_TEMP: + the step-start POTT of the corrector, + dPOTTdt_RAD
 // number of staged fields the momentum wavefronts move when each of them reaches into the last wavefront's 64-chunk slice (then
 // every momentum wavefront issues exactly that many DMA instructions per level), else 0; WITH_TEMP only -- elsewhere some
 // momentum wavefronts move the step-start tiles as well
-constexpr int mom_ni_const(int tj, bool fw, bool pl, bool wt, unsigned mv_t)
+constexpr int mom_ni_const(int tj, bool fw, bool pl, bool wt, unsigned mv_t, bool mo = false)
 {
     if (!wt) return 0;
     int n = 0;
-    for (int f = (fw ? 2 : 0); f < FNF; f++) {
+    for (int f = (fw ? 2 : 0); f < DNF; f++) {
         if ((mv_t >> f) & 1u) continue;
-        const int chunks = mom_rows(f, tj, fw, pl, wt) * (FTW / VW);
+        const int chunks = mom_rows(f, tj, fw, pl, wt, mo) * (FTW / VW);
         if (chunks == 0) continue;
         if (chunks <= (tj - 1) * 64) return 0;
         n++;
     }
     return n;
 }
-constexpr int mom_own_tiles(bool cur, bool wt, bool tb = false) { return (cur ? 0 : 2) + (wt ? (cur ? 0 : 1) + 1 : 0) + (tb ? 2 : 0); }       // `tb`: + TURB_U, TURB_V (turbulence-coupled instances)       // (+ 1: the radiative heating rate, staged only on a handle with i_radiation)
-constexpr int mom_dma_slot(int tj, bool fw, bool cur, bool pl = false, bool wt = false, bool tb = false) { return mom_off(FNF, tj, fw, pl, wt) + mom_own_tiles(cur, wt, tb) * FTI * tj; }
+// own-cell tiles: [u_old, v_old (corrector)] [pott_old (corrector, WITH_TEMP)] [qv_old, qc_old (corrector, MOIST)] [dPOTTdt_RAD (WITH_TEMP; staged
+// only on a handle with i_radiation)] [TURB_U, TURB_V (`tb`: turbulence-coupled instances)]
+constexpr int mom_own_tiles(bool cur, bool wt, bool tb = false, bool mo = false) { return (cur ? 0 : 2) + (wt ? (cur ? 0 : 1) + 1 : 0) + ((mo && !cur) ? 2 : 0) + (tb ? 2 : 0); }
+constexpr int mom_dma_slot(int tj, bool fw, bool cur, bool pl = false, bool wt = false, bool tb = false, bool mo = false) { return mom_off(DNF, tj, fw, pl, wt, mo) + mom_own_tiles(cur, wt, tb, mo) * FTI * tj; }
 constexpr int mom_flux_slot(int tj, bool fw) { return fw ? (2 * tj + 5) * FTW : 0; }
 // ... then (fw) two factor tiles, dyis (tj+2 rows) and dxjs (tj+3 rows), shaped like the UFLX / VFLX tiles
-constexpr size_t dma_lds_bytes(int tj, bool fw, bool cur, int depth, bool pl = false, bool wt = false, bool tb = false)
+constexpr size_t dma_lds_bytes(int tj, bool fw, bool cur, int depth, bool pl = false, bool wt = false, bool tb = false, bool mo = false)
 {
-    return ((size_t)(depth + 1) * mom_dma_slot(tj, fw, cur, pl, wt, tb) + 3 * (size_t)mom_flux_slot(tj, fw)) * sizeof(real);
+    return ((size_t)(depth + 1) * mom_dma_slot(tj, fw, cur, pl, wt, tb, mo) + 3 * (size_t)mom_flux_slot(tj, fw)) * sizeof(real);
 }
 
 #ifndef DYC_DMA_AUX
@@ -577,7 +583,7 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 // after the launch.  Level chunks (MomPlan) as in the momentum-only instances: the temperature sweep carries nothing further
 // than one level since it stopped integrating PHI (round 3), the momentum wavefronts of a chunk that ends inside the column
 // start their hydrostatic integration from a stored PHIVB plane (k_phivb_rows, launched for the tile rows that are cut).
-struct TempArgs { const real *pott_old; real *pott_out, *pvb_out; long long *trace; };
+struct TempArgs { const real *pott_old; real *pott_out, *pvb_out; long long *trace; const real *qv_old, *qc_old; real *qv_out, *qc_out; };
 // -DDYC_TRACE (experiment builds only): the wavefronts of ONE workgroup of the whole-substep kernel write their cycle counter at
 // four points of every level: [wave][level][point], point 0 = top of the iteration, 1 = stores and DMA issued, 2 = arithmetic
 // done, 3 = own DMA landed / flux entries formed (the barrier follows)
@@ -586,7 +592,12 @@ struct TempArgs { const real *pott_old; real *pott_out, *pvb_out; long long *tra
 #else
 #define TRACE_PT(k_, pt_) do { } while (0)
 #endif
-template <bool OLD_IS_CUR, int TJ, bool FROM_WINDS, bool TURB = false, int DEPTH = 1, bool PHI_LOCAL = false, bool WITH_TEMP = false>
+// MOIST (with WITH_TEMP, a handle with i_moist): the temperature wavefronts advance QV and QC too -- dyn_moist.py:201-243 + the QV /
+// QC part of dyn_timestep.py, the arithmetic of k_moist_canon level for level (TEMP_PARTIAL / TEMP_CLOSE with the logarithmic
+// interface value of dyn_functions.py:70-95; the same bits) -- on two more staged tiles (one halo row / column each side) and, in
+// the corrector, two more own-cell tiles: k_moist's launch and its passes over UWIND, VWIND, WWIND disappear (8 -> 5 passes for
+// the moisture of a substep), at the price of a temperature wavefront about as long as the momentum wavefront of its SIMD.
+template <bool OLD_IS_CUR, int TJ, bool FROM_WINDS, bool TURB = false, int DEPTH = 1, bool PHI_LOCAL = false, bool WITH_TEMP = false, bool MOIST = false>
 __global__ __launch_bounds__(FTI *TJ *(WITH_TEMP ? 2 : 1), ((TJ <= 4 && !WITH_TEMP) ? 2 : 1)) void k_momentum_dma(Geo g, Ptrs p, int gbx, MomPlan plan, int jv_lo,
                                                       const real *u_old, const real *v_old,
                                                       real *u_out, real *v_out, real dt, TempArgs ta)
@@ -595,8 +606,9 @@ __global__ __launch_bounds__(FTI *TJ *(WITH_TEMP ? 2 : 1), ((TJ <= 4 && !WITH_TE
     static_assert(DEPTH == 1 || DEPTH == 2, "ring of 2 or 3 slots");
     static_assert(!TURB || (TJ == 8 && !WITH_TEMP), "the turbulent tendencies travel as own-cell tiles of the two step-start wavefronts (64 x 8 tiles)");
     static_assert(!PHI_LOCAL || FROM_WINDS, "PHI in the thread needs PVTF in the thread");
-#define MROWS(f) mom_rows(f, TJ, FROM_WINDS, PHI_LOCAL, WITH_TEMP)
-#define MOFF(f) mom_off(f, TJ, FROM_WINDS, PHI_LOCAL, WITH_TEMP)
+    static_assert(!MOIST || WITH_TEMP, "the moisture sweep is the temperature wavefronts'");
+#define MROWS(f) mom_rows(f, TJ, FROM_WINDS, PHI_LOCAL, WITH_TEMP, MOIST)
+#define MOFF(f) mom_off(f, TJ, FROM_WINDS, PHI_LOCAL, WITH_TEMP, MOIST)
     // segment of the work list this workgroup belongs to (MomPlan)
     const bool seg_b = (int)blockIdx.x >= plan.nblk_a;
     const RowSet trows = seg_b ? plan.b : plan.a;
@@ -611,8 +623,8 @@ __global__ __launch_bounds__(FTI *TJ *(WITH_TEMP ? 2 : 1), ((TJ <= 4 && !WITH_TE
     // temperature wavefront is the slower of the two on a SIMD, profiles/r02_notes.md)
     constexpr int AHEAD = DEPTH;
     constexpr int NS = AHEAD + 1;
-    constexpr int DSLOT = mom_dma_slot(TJ, FROM_WINDS, OLD_IS_CUR, PHI_LOCAL, WITH_TEMP, TURB), FSLOT = mom_flux_slot(TJ, FROM_WINDS);
-    constexpr int OFF_OLD = MOFF(FNF);
+    constexpr int DSLOT = mom_dma_slot(TJ, FROM_WINDS, OLD_IS_CUR, PHI_LOCAL, WITH_TEMP, TURB, MOIST), FSLOT = mom_flux_slot(TJ, FROM_WINDS);
+    constexpr int OFF_OLD = MOFF(DNF);
     // the step-start tiles: two wavefronts of their own (8 rows), or one slice more for the first 2 ONSL wavefronts (4 rows)
     constexpr bool OLD_SHARED = NSL + 2 > TJ;
     static_assert(!(TURB && OLD_SHARED), "TURB_U / TURB_V ride with the two wavefronts that move the step-start tiles");
@@ -659,12 +671,12 @@ __global__ __launch_bounds__(FTI *TJ *(WITH_TEMP ? 2 : 1), ((TJ <= 4 && !WITH_TE
         const int e = VW * (dma_on ? ch : 0), r = e / FTW, c2 = e - r * FTW;
         goff = min(j0 - 1 + r, g.NJ - 1) * P + min(i0 - FXO + c2, P - VW);
 #pragma unroll
-        for (int f = (FROM_WINDS ? 2 : 0); f < FNF; f++)
+        for (int f = (FROM_WINDS ? 2 : 0); f < DNF; f++)
             if ((((MV_T >> f) & 1u) != 0) == role_t && sl * 64 < MROWS(f) * CPR) n_issue++;
     }
     // a slice of a step-start tile = VW rows of OCPR chunks (16 B each, i0 is 16-B aligned): lane -> (row, column)
     const int orow = lane / OCPR, ocol = i0 + VW * (lane % OCPR);
-    constexpr int NOWN = mom_own_tiles(OLD_IS_CUR, WITH_TEMP);         // own-cell tiles: [u_old, v_old, pott_old,] [dPOTTdt_RAD]
+    constexpr int NOWN = mom_own_tiles(OLD_IS_CUR, WITH_TEMP, false, MOIST);         // own-cell tiles: [u_old, v_old, pott_old, [qv_old, qc_old,]] [dPOTTdt_RAD]
     const int nown = (WITH_TEMP && !g.i_rad) ? NOWN - 1 : NOWN;        // ... the last one only with radiative heating
     if (WITH_TEMP) {            // the temperature wavefronts move them: slice s (of nown * ONSL) by wavefront TJ + s % TJ
         if (role_t)
@@ -673,10 +685,10 @@ __global__ __launch_bounds__(FTI *TJ *(WITH_TEMP ? 2 : 1), ((TJ <= 4 && !WITH_TE
         if (!OLD_SHARED && wave >= TJ - 2) n_issue = ONSL * ((OLD_IS_CUR ? 0 : 1) + (TURB ? 1 : 0));
         if (!OLD_IS_CUR && OLD_SHARED && wave < 2 * ONSL) n_issue++;
     }
-    const real *src[FNF] = {p.UFLX, p.VFLX, p.UWIND, p.VWIND, p.WWIND, p.PHI, p.POTT, p.PVTF, p.PVTFVB};
+    const real *src[DNF] = {p.UFLX, p.VFLX, p.UWIND, p.VWIND, p.WWIND, p.PHI, p.POTT, p.PVTF, p.PVTFVB, p.QV, p.QC};
     // the momentum wavefronts' DMA instructions per level where that is the same number for all of them (WITH_TEMP: they move
     // staged fields only, and every staged field reaches into the last wavefront's slice); 0: counted per wavefront (n_issue)
-    constexpr int NI_CONST = mom_ni_const(TJ, FROM_WINDS, PHI_LOCAL, WITH_TEMP, MV_T);
+    constexpr int NI_CONST = mom_ni_const(TJ, FROM_WINDS, PHI_LOCAL, WITH_TEMP, MV_T, MOIST);
     const real *osrc = OLD_SHARED ? (wave < ONSL ? u_old : v_old) : ((wave == TJ - 2) ? u_old : v_old);
 
     // the lane's chunk as a byte offset from (field base + k plane - one row): tile column 0 of the first tile is longitude -1 of
@@ -693,14 +705,15 @@ __global__ __launch_bounds__(FTI *TJ *(WITH_TEMP ? 2 : 1), ((TJ <= 4 && !WITH_TE
 #define DMA_FIELD(F_)                                                                                                        \
                 if ((F_) >= (FROM_WINDS ? 2 : 0) && ((((MV_T >> (F_)) & 1u) != 0) == role_t) && ch < MROWS(F_) * CPR)             \
                     lds_dma16s<(unsigned)(MOFF(F_) * sizeof(real))>(src[F_] + kp, voff, lds_sl);
-                DMA_FIELD(0) DMA_FIELD(1) DMA_FIELD(2) DMA_FIELD(3) DMA_FIELD(4) DMA_FIELD(5) DMA_FIELD(6) DMA_FIELD(7) DMA_FIELD(8)
+                DMA_FIELD(0) DMA_FIELD(1) DMA_FIELD(2) DMA_FIELD(3) DMA_FIELD(4) DMA_FIELD(5) DMA_FIELD(6) DMA_FIELD(7) DMA_FIELD(8) DMA_FIELD(9) DMA_FIELD(10)
 #undef DMA_FIELD
-                static_assert(FNF == 9, "DMA_FIELD list");
+                static_assert(DNF == 11, "DMA_FIELD list");
             }
         }
         if (WITH_TEMP) {
             if (role_t) {
-                const real *own[4] = {OLD_IS_CUR ? p.dPOTTdt_RAD : u_old, v_old, ta.pott_old, p.dPOTTdt_RAD};
+                // (in the order of mom_own_tiles: [u_old, v_old, pott_old, [qv_old, qc_old,]] dPOTTdt_RAD)
+                const real *own[6] = {OLD_IS_CUR ? p.dPOTTdt_RAD : u_old, v_old, ta.pott_old, MOIST ? ta.qv_old : p.dPOTTdt_RAD, ta.qc_old, p.dPOTTdt_RAD};
 #pragma unroll
                 for (int s5 = 0; s5 < NOWN * ONSL; s5++) {
                     if (s5 % TJ == wave - TJ && s5 < nown * ONSL) {
@@ -859,11 +872,24 @@ __global__ __launch_bounds__(FTI *TJ *(WITH_TEMP ? 2 : 1), ((TJ <= 4 && !WITH_TE
             pt_kp1 = p.POTT[c + (size_t)k1 * pl];
             w_kp1 = p.WWIND[c + (size_t)k1 * pl];
         }
+        // MOIST: QV, QC carried like POTT -- the level below (its value with the logarithm / reciprocal cache of the interface
+        // interpolation), sigma-dot times the interface value at interface k+2, the partial tendency and the step-start value
+        // of level k+1
+        cdouble_t *c_mdif = (cdouble_t *)p.moist_dif_coef;
+        LogCache lqv_kp1 = log_cache((real)0.0), lqc_kp1 = log_cache((real)0.0);
+        real lpv_kp2 = 0.0, lpc_kp2 = 0.0, tqv_kp1 = 0.0, tqc_kp1 = 0.0, qvo_kp1 = 0.0, qco_kp1 = 0.0;
+        real o_qv = 0.0, o_qc = 0.0;
+        if (MOIST && k1 < nz) {
+            real qv1 = p.QV[c + (size_t)k1 * pl], qc1 = p.QC[c + (size_t)k1 * pl];
+            asm volatile("" : "+v"(qv1), "+v"(qc1));
+            lqv_kp1 = log_cache(qv1); lqc_kp1 = log_cache(qc1);
+        }
         real o_pott = 0.0, o_pvb = 0.0;       // outputs stored at the end of a level: POTT of level k+1, PVTFVB at interface k
         {   // every value loaded above is complete before the level loop starts (see the momentum wavefronts)
             asm volatile("" : "+v"(colp), "+v"(cold), "+v"(c_im1), "+v"(c_ip1), "+v"(c_jm1), "+v"(c_jp1), "+v"(hr_area), "+v"(r_cnew), "+v"(rcolO), "+v"(pvbO_kp1), "+v"(pvtfO_kp1), "+v"(pt_kp1), "+v"(w_kp1));
         }
-        constexpr int OWN_PO = OFF_OLD + 2 * ON, OWN_RAD = OFF_OLD + (NOWN - 1) * ON;
+        constexpr int OWN_PO = OFF_OLD + 2 * ON, OWN_QV = OFF_OLD + 3 * ON, OWN_QC = OFF_OLD + 4 * ON, OWN_RAD = OFF_OLD + (NOWN - 1) * ON;
+        (void)OWN_QV; (void)OWN_QC;
         const bool has_rad = g.i_rad;
 #if !DYC_EARLY_DMA
         issue(k1 - 1, 0);
@@ -904,6 +930,32 @@ __global__ __launch_bounds__(FTI *TJ *(WITH_TEMP ? 2 : 1), ((TJ <= 4 && !WITH_TE
                 TEMP_PARTIAL(tpart, colp, c_im1, c_ip1, c_jm1, c_jp1, hr_area, SM(S_UF, 0, 0), SM(S_UF, 1, 0), SM(S_VF, 0, 0), SM(S_VF, 0, 1),
                              pt, SM(S_POTT, -1, 0), SM(S_POTT, 1, 0), SM(S_POTT, 0, -1), SM(S_POTT, 0, 1), c_tdif[k], has_rad, db[OWN_RAD + ty * FTI + tx])
                 o_pvb = canon_exner(canon_pk(g.pair_top, c_sig[k], cnew));
+                if (MOIST) {        // k_moist_canon's level, bottom-up: interface k+1 closes level k+1, then level k's partial tendency
+                    const real qv = SM(S_QV, 0, 0), qc = SM(S_QC, 0, 0);
+                    const real qvo = OLD_IS_CUR ? qv : db[OWN_QV + ty * FTI + tx], qco = OLD_IS_CUR ? qc : db[OWN_QC + ty * FTI + tx];
+                    LogCache lqv = log_cache(qv), lqc = log_cache(qc);
+                    real lpv_kp1 = 0.0, lpc_kp1 = 0.0;
+                    if (k < nz - 1) {
+                        const real vbv = varvb_log_cached(lqv_kp1, lqv), vbc = varvb_log_cached(lqc_kp1, lqc);
+                        if (k < k1 - 1) {
+                            TEMP_CLOSE(qvn, tqv_kp1, cnew, cold, r_cnew, w_kp1, vbv, lpv_kp2, c_rdst[k + 1], qvo_kp1, dt)
+                            TEMP_CLOSE(qcn, tqc_kp1, cnew, cold, r_cnew, w_kp1, vbc, lpc_kp2, c_rdst[k + 1], qco_kp1, dt)
+                            o_qv = qvn; o_qc = qcn;
+                            if (g.i_moist_clip) {       // dyn_timestep.py:145-154
+                                if (o_qv < 0.0) o_qv = 0.0;
+                                if (o_qc < 0.0) o_qc = 0.0;
+                            }
+                        }
+                        lpv_kp1 = mul_rn(w_kp1, vbv); lpc_kp1 = mul_rn(w_kp1, vbc);
+                    }
+                    const real mdif = c_mdif[k];
+                    TEMP_PARTIAL(tqv, colp, c_im1, c_ip1, c_jm1, c_jp1, hr_area, SM(S_UF, 0, 0), SM(S_UF, 1, 0), SM(S_VF, 0, 0), SM(S_VF, 0, 1),
+                                 qv, SM(S_QV, -1, 0), SM(S_QV, 1, 0), SM(S_QV, 0, -1), SM(S_QV, 0, 1), mdif, false, 0.0)
+                    TEMP_PARTIAL(tqc, colp, c_im1, c_ip1, c_jm1, c_jp1, hr_area, SM(S_UF, 0, 0), SM(S_UF, 1, 0), SM(S_VF, 0, 0), SM(S_VF, 0, 1),
+                                 qc, SM(S_QC, -1, 0), SM(S_QC, 1, 0), SM(S_QC, 0, -1), SM(S_QC, 0, 1), mdif, false, 0.0)
+                    lqv_kp1 = lqv; lqc_kp1 = lqc;
+                    lpv_kp2 = lpv_kp1; lpc_kp2 = lpc_kp1; tqv_kp1 = tqv; tqc_kp1 = tqc; qvo_kp1 = qvo; qco_kp1 = qco;
+                }
                 pvbO_kp1 = pvbO_k; pkO_kp1 = pkO_k; pvtfO_kp1 = pvtfO_k; pt_kp1 = pt; w_kp1 = w_k;
                 lp_kp2 = lp_kp1; tpart_kp1 = tpart; po_kp1 = po;
             }
@@ -921,7 +973,10 @@ __global__ __launch_bounds__(FTI *TJ *(WITH_TEMP ? 2 : 1), ((TJ <= 4 && !WITH_TE
             asm volatile("" ::: "memory");
             if (active) {
                 const size_t q0 = c + (size_t)k * pl;
-                if (k < k1 - 1) __builtin_nontemporal_store(o_pott, ta.pott_out + q0 + pl);
+                if (k < k1 - 1) {
+                    __builtin_nontemporal_store(o_pott, ta.pott_out + q0 + pl);
+                    if (MOIST) { __builtin_nontemporal_store(o_qv, ta.qv_out + q0 + pl); __builtin_nontemporal_store(o_qc, ta.qc_out + q0 + pl); }
+                }
                 __builtin_nontemporal_store(o_pvb, ta.pvb_out + q0);
             }
             asm volatile("" ::: "memory");
@@ -940,6 +995,22 @@ __global__ __launch_bounds__(FTI *TJ *(WITH_TEMP ? 2 : 1), ((TJ <= 4 && !WITH_TE
             }
             TEMP_CLOSE(pott0, tpart_kp1, cnew, cold, r_cnew, w_top, vb_top, lp_kp2, c_rdst[k0], po_kp1, dt)
             __builtin_nontemporal_store(pott0, ta.pott_out + c + (size_t)k0 * pl);
+            if (MOIST) {
+                real vbv_top = 0.0, vbc_top = 0.0;
+                if (k0 > 0) {
+                    LogCache lqv_m = log_cache(p.QV[c + (size_t)(k0 - 1) * pl]), lqc_m = log_cache(p.QC[c + (size_t)(k0 - 1) * pl]);
+                    vbv_top = varvb_log_cached(lqv_kp1, lqv_m); vbc_top = varvb_log_cached(lqc_kp1, lqc_m);
+                }
+                TEMP_CLOSE(qv0, tqv_kp1, cnew, cold, r_cnew, w_top, vbv_top, lpv_kp2, c_rdst[k0], qvo_kp1, dt)
+                TEMP_CLOSE(qc0, tqc_kp1, cnew, cold, r_cnew, w_top, vbc_top, lpc_kp2, c_rdst[k0], qco_kp1, dt)
+                real qv0c = qv0, qc0c = qc0;
+                if (g.i_moist_clip) {
+                    if (qv0c < 0.0) qv0c = 0.0;
+                    if (qc0c < 0.0) qc0c = 0.0;
+                }
+                __builtin_nontemporal_store(qv0c, ta.qv_out + c + (size_t)k0 * pl);
+                __builtin_nontemporal_store(qc0c, ta.qc_out + c + (size_t)k0 * pl);
+            }
         }
         return;
     }

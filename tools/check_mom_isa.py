@@ -28,8 +28,8 @@ def main():
         name = L[st].split(':')[0]
         en = next(i for i in range(st, len(L)) if L[i].strip().startswith('.Lfunc_end'))
         body = L[st:en]
-        m = re.search(r'k_momentum_dmaILb([01])ELi(\d+)ELb([01])ELb([01])ELi(\d)ELb([01])ELb([01])E', name)
-        cur, tj, fw, turb, depth, pl, wt = m.groups()
+        m = re.search(r'k_momentum_dmaILb([01])ELi(\d+)ELb([01])ELb([01])ELi(\d)ELb([01])ELb([01])ELb([01])E', name)
+        cur, tj, fw, turb, depth, pl, wt, mo = m.groups()
         # the level loop: the loop (lines grouped by their header label) that contains the DMA instructions
         groups = {}
         for i, l in enumerate(body):
@@ -38,7 +38,10 @@ def main():
         spans = []
         for hdr, idx in groups.items():
             a = min(idx)
-            b = next((i for i in range(max(idx) + 1, len(body)) if re.match(r'^\.LBB\d+_\d+:', body[i])), len(body))
+            # the loop's last block ends with its back edge (the code behind that branch, up to the next label, is the
+            # epilogue of the sweep -- its loads of the level above a chunk are not in the loop)
+            last = max(idx)
+            b = next((i + 1 for i in range(last + 1, len(body)) if re.match(r'\s*s_c?branch', body[i]) or re.match(r'^\.LBB\d+_\d+:', body[i])), len(body))
             if any('global_load_lds' in l for l in body[a:b]): spans.append((a, b))
         # innermost DMA loops only (a WITH_TEMP instance has two: the momentum and the temperature wavefronts')
         spans = [sp for sp in spans if not any(o != sp and sp[0] <= o[0] and o[1] <= sp[1] for o in spans)]
@@ -56,8 +59,8 @@ def main():
         lo, hi = (min(a for a, b in spans), max(b for a, b in spans)) if spans else (0, 0)
         tag = 'predictor' if cur == '1' else 'corrector'
         prod = True
-        print('%-9s TJ=%s fw=%s turb=%s depth=%s phi_local=%s with_temp=%s: %d level loop(s), %d DMA instructions, findings: %s' % (
-            tag, tj, fw, turb, depth, pl, wt, len(spans), ndma, found or 'none'))
+        print('%-9s TJ=%s fw=%s turb=%s depth=%s phi_local=%s with_temp=%s moist=%s: %d level loop(s), %d DMA instructions, findings: %s' % (
+            tag, tj, fw, turb, depth, pl, wt, mo, len(spans), ndma, found or 'none'))
         if found and prod: bad = 1
     return bad
 

@@ -252,6 +252,11 @@ def main():
     run(nbreak)
     fence()
     bstats = core.kernel_stats()
+    # a moist handle's whole-substep launch advances QV / QC as well (round 3; no k_moist launch then): + R QV,QC (+2 old in
+    # the corrector) W QV,QC
+    passes = dict(KERNEL_PASSES)
+    if args.moist and not bstats.get('k_moist', (0, 0))[0]:
+        passes['k_substep_fused'] = KERNEL_PASSES['k_substep_fused'] + 5.0
     breakdown = {k: tot / nbreak for k, (n, tot) in bstats.items() if n}
     launches_per_step = {k: n / nbreak for k, (n, tot) in bstats.items() if n}
     core.profile(0)
@@ -290,11 +295,11 @@ def main():
     # dominant kernel on this rank
     dom, dom_n, dom_ms = None, 0, 0.0
     for k, (n, tot) in stats.items():
-        if n and tot > dom_ms and k in KERNEL_PASSES:
+        if n and tot > dom_ms and k in passes:
             dom, dom_n, dom_ms = k, n, tot
     roof = None
     if dom:
-        per_launch_bytes = KERNEL_PASSES[dom] * band_cells * esize
+        per_launch_bytes = passes[dom] * band_cells * esize
         # a band runs the kernel as two or three launches per substep (inner rows behind the exchanges, edge
         # rows between them): price them as the one pass over the band they are
         if world > 1:
@@ -305,10 +310,10 @@ def main():
         # per-launch breakdown pass above
         kern, step_bytes = {}, 0.0
         for k, ms in breakdown.items():
-            if k not in KERNEL_PASSES:
+            if k not in passes:
                 continue
             nl_ = launches_per_step[k]
-            gb = KERNEL_PASSES[k] * band_cells * esize / 1e9
+            gb = passes[k] * band_cells * esize / 1e9
             if world > 1 and k in ('k_momentum_dma', 'k_substep_fused'):
                 nl_ = 2.0               # the pieces of a substep (inner tile rows in one or two launches, edge rows) = one pass over the band
             step_bytes += gb * nl_

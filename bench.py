@@ -52,8 +52,8 @@ KERNEL_PASSES = {
     # momentum + temperature of a substep in one launch (single GPU): R UWIND,VWIND,WWIND,POTT,PVTFVB (+3 old in the
     # corrector) W UWIND,VWIND,POTT,PVTFVB: 9 / 12 -- the temperature wavefronts read the tiles the momentum wavefronts stage
     'k_substep_fused': 10.5,
-    'k_pott_fused': 9.5,         # (turbulence-coupled handles) R POTT,UWIND,VWIND,WWIND,POTTVB (+1 old) W POTT,PVTFVB,PHI,POTTVB
-    'k_temp_canon': 7.75,        # R POTT,UWIND,VWIND,WWIND,PVTFVB (+1 old) W POTT,PVTFVB (+ PHIVB at every 4th interface): 7.25 / 8.25
+    'k_pott_fused': 9.5,         # (DYCORE_LAZY_PHI=0 / experiment builds) R POTT,UWIND,VWIND,WWIND,POTTVB (+1 old) W POTT,PVTFVB,PHI,POTTVB
+    'k_temp_canon': 7.75,        # R POTT,UWIND,VWIND,WWIND,PVTFVB (+1 old) W POTT,PVTFVB (+ PHIVB at every 4th interface): 7.25 / 8.25 (turbulence-coupled: + R TURB_T W PHI,PHIVB)
     'k_moist': 8.0,              # R QV,QC,UWIND,VWIND,WWIND (+2 old) W QV,QC
     'k_turb_tendencies': 16.0,   # R UWIND,VWIND,PHI,PHIVB,RHO,RHOVB,KMOM,KHEAT,POTT(,QV,QC) W TURB_U,V,T(,QV,QC)
 }

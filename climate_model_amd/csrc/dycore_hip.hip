@@ -488,7 +488,7 @@ int refresh_lazy(dycore *h, int need)
         h->stale_flxdiv = false;
     }
     // (a handle whose step keeps PHI in the momentum kernel's threads derives with the canonical forms that step uses)
-    const int canon = phi_on_demand(h) ? 1 : 0;
+    const int canon = (phi_on_demand(h) || (h->g.i_turb && fused_path(h))) ? 1 : 0;      // (... and the turbulence-coupled fused step: k_temp_canon<true>)
     if (d_pvtf) {
         hipLaunchKernelGGL(k_derive_pvtf, grid_for(h->g, h->g.nx + 2, h->g.ny + 2), dim3(TI, TJ), 0, h->stream, h->g, h->p, canon);
         if ((rc = launch_check("k_derive_pvtf"))) return rc;
@@ -799,16 +799,17 @@ int do_substep_fused(dycore *h, const Ptrs &p, const real *u_old, const real *v_
 }
 int do_pott_fused(dycore *h, const Ptrs &p, const real *pott_old, real *pott_out, real dt)
 {
-    Scope s(h, (!h->g.i_turb && h->lazy && phi_on_demand(h)) ? K_TEMP_CANON : K_POTT_FUSED);
+    Scope s(h, (h->g.i_turb || (h->lazy && phi_on_demand(h))) ? K_TEMP_CANON : K_POTT_FUSED);
     const dim3 gr = grid_cells(h), bl(TI, TJ);
     const int lin = cells_linear(h);
 #define POTT_LAUNCH_P(W_, F_, T_, V_, P_) hipLaunchKernelGGL((k_pott_fused<W_, F_, T_, V_, P_>), gr, bl, 0, h->stream, h->g, p, pott_old, pott_out, dt, lin)
 #define POTT_LAUNCH(W_, F_, T_, V_) POTT_LAUNCH_P(W_, F_, T_, V_, true)
-    if (h->g.i_turb) {                  // fused turbulence-coupled step: PHIVB is an input of k_turb_tendencies, so it is stored
-        POTT_LAUNCH(true, true, true, true);
+    if (h->g.i_turb) {                  // fused turbulence-coupled step: PHI and PHIVB are inputs of k_turb_tendencies, so they are stored;
+        hipLaunchKernelGGL(k_temp_canon<true>, gr, bl, 0, h->stream, h->g, p, pott_old, pott_out, dt, lin);      // PVTF and POTTVB are derived when asked for
+        h->stale_pvtf = true; h->stale_pottvb = true;
     } else if (h->lazy) {
         if (phi_on_demand(h)) {         // production: neither PHI nor POTTVB is stored (k_temp_canon)
-            hipLaunchKernelGGL(k_temp_canon, gr, bl, 0, h->stream, h->g, p, pott_old, pott_out, dt, lin);
+            hipLaunchKernelGGL(k_temp_canon<false>, gr, bl, 0, h->stream, h->g, p, pott_old, pott_out, dt, lin);
             h->stale_pvtf = true; h->stale_phi = true; h->stale_pottvb = true;
             h->planes_valid = true;     // ... and of the halo rows once their owner's rows have arrived (a band's exchange)
         }
@@ -898,7 +899,13 @@ int step_begin(dycore *h, int with_rho)
 {
     int rc;
     Ptrs &p = h->p;
-    if (with_rho && ((rc = refresh_lazy(h, LAZY_PVTF | LAZY_POTTVB)) || (rc = do_rho(h, p)))) return rc;
+    if (with_rho) {
+        if (h->g.i_turb && fused_path(h)) {     // PVTF / POTTVB are not stored on this path (k_temp_canon<true>): formed in the thread
+            Scope s(h, K_RHO);
+            hipLaunchKernelGGL(k_diag_rho_canon, grid_for(h->g, h->g.nx + 2, h->g.ny + 2), dim3(TI, TJ), 0, h->stream, h->g, p);
+            if ((rc = launch_check("k_diag_rho_canon"))) return rc;
+        } else if ((rc = refresh_lazy(h, LAZY_PVTF | LAZY_POTTVB)) || (rc = do_rho(h, p))) return rc;
+    }
     if (fused_path(h)) {
         if (!h->g.i_turb && !substep_fused(h) && (rc = ensure_planes(h))) return rc;
         if (h->g.i_turb) {
@@ -984,8 +991,9 @@ int substep_part(dycore *h, real dt, int sub, int part)
             const int nz = h->g.nz;
             if (h->g.i_moist && (rc = do_halo(h, {{qv_out, 0, 0, nz}, {qc_out, 0, 0, nz}}))) return rc;
             std::vector<HaloSpec> hl = {{t_out, 0, 0, nz}, {p.PVTFVB, 0, 0, nz + 1}};
-            if (!phi_on_demand(h)) { hl.push_back({p.POTTVB, 0, 0, nz + 1}); hl.push_back({p.PHI, 0, 0, nz}); }
-            if (!pvtf_on_demand(h)) hl.push_back({p.PVTF, 0, 0, nz});
+            // (a turbulence-coupled handle stores PHI and PHIVB, not POTTVB and PVTF: k_temp_canon<true>)
+            if (!phi_on_demand(h)) { if (!h->g.i_turb) hl.push_back({p.POTTVB, 0, 0, nz + 1}); hl.push_back({p.PHI, 0, 0, nz}); }
+            if (!pvtf_on_demand(h) && !h->g.i_turb) hl.push_back({p.PVTF, 0, 0, nz});
             if (!h->lazy || h->g.i_turb) hl.push_back({p.PHIVB, 0, 0, nz + 1});
             hl.push_back({u_out, 1, 0, nz});   // owned rows and pole rows only: rows in flight from a neighbour are not touched
             hl.push_back({v_out, 0, 1, nz});
@@ -1256,9 +1264,11 @@ static void band_row_fields(const dycore *h, std::vector<const char *> &out)
     out.push_back("PVTFVB");
     if (substep_fused(h)) return;               // the whole-substep kernel keeps nothing else: PHI is carried in its threads
     if (!h->g.i_turb && phi_on_demand(h)) { out.push_back("PHIVB"); return; }       // (the planes the level chunks start from)
-    out.push_back("PHI"); out.push_back("POTTVB");
+    out.push_back("PHI");
+    if (h->g.i_turb) { out.push_back("PHIVB"); return; }        // (k_temp_canon<true>: PVTF and POTTVB are derived, halo rows included, when asked for)
+    out.push_back("POTTVB");
     if (!pvtf_on_demand(h)) out.push_back("PVTF");
-    if (!h->lazy || h->g.i_turb) out.push_back("PHIVB");
+    if (!h->lazy) out.push_back("PHIVB");
 }
 int dycore_band_row_fields(dycore_t *h, char *buf, int32_t nbytes)
 {

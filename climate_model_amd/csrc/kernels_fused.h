@@ -1806,6 +1806,40 @@ __global__ __launch_bounds__(TI *TJ) void k_pott_fused(Geo g, Ptrs p, const real
 
 
 // ------------------------------------------------------------------------------------
+// k_diag_rho_canon: RHO / RHOVB (dyn_diagnostics.py:199-222) of a turbulence-coupled handle on the fused step, whose temperature
+// kernel (k_temp_canon<true>) stores neither PVTF nor POTTVB: both are formed in the thread from POTT, PVTFVB and COLP with the
+// canonical forms (the expressions of k_derive_pvtf / k_derive_pottvb: the values a caller would get on demand), one bottom-up sweep,
+// whole array including halos like k_diag_rho.  2 reads instead of 4, and no derive launches in front of it.
+__global__ __launch_bounds__(TI *TJ) void k_diag_rho_canon(Geo g, Ptrs p)
+{
+    DYC_IJ(0, 0)
+    if (i > g.nx + 1 || j > g.ny + 1) return;
+    const size_t c = at2(g, i, j);
+    const int nz = g.nz;
+    const real colp = p.COLP[c], rcol = canon_rcol(colp);
+    double pk1 = canon_pk(g.pair_top, p.sigma_vb[nz], colp);
+    real pvb_kp1 = p.PVTFVB[c + (size_t)nz * g.plane];
+    const real pvb_surf = pvb_kp1;
+    real pott_kp1 = 0.0, pvtf_kp1 = 0.0, first = 0.0;
+    auto rho_of = [](real pv, real pt) { return (real)(100000.0 * pow(pv, 1.0 / CON_KAPPA) / (CON_RD * (pt * pv))); };
+    for (int k = nz - 1; k >= 0; k--) {
+        const size_t q = c + (size_t)k * g.plane;
+        const double pk = canon_pk(g.pair_top, p.sigma_vb[k], colp);
+        const real pvb_k = p.PVTFVB[q], pott = p.POTT[q];
+        const real pvtf = canon_pvtf(pvb_kp1, pk1, pvb_k, pk, rcol, p.rdsigma[k]);
+        p.RHO[q] = rho_of(pvtf, pott);
+        if (k < nz - 1) {
+            const real vb = pottvb_between(pvb_kp1, pvtf, pott, pvtf_kp1, pott_kp1);       // interface k+1
+            p.RHOVB[q + g.plane] = rho_of(pvb_kp1, vb);
+            if (k == nz - 2 && nz > 2) p.RHOVB[c + (size_t)nz * g.plane] = rho_of(pvb_surf, pott_kp1 - (vb - pott_kp1));     // surface, dyn_diagnostics.py:191-194
+            if (k == 0) first = vb;
+        }
+        pk1 = pk; pvb_kp1 = pvb_k; pott_kp1 = pott; pvtf_kp1 = pvtf;
+    }
+    if (nz >= 2) p.RHOVB[c] = rho_of(pvb_kp1, pott_kp1 - (first - pott_kp1));       // model top, :187-190
+}
+
+// ------------------------------------------------------------------------------------
 // k_moist_canon: QV / QC of the fused step (dyn_moist.py:201-243 + the QV / QC part of dyn_timestep.py) -- k_moist<., EULER>'s
 // data flow and software pipeline with the arithmetic of a level written as the temperature sweep's is (TEMP_PARTIAL /
 // TEMP_CLOSE: horizontal advection and diffusion of level k, then the vertical advection between its two interfaces and the
@@ -1904,6 +1938,11 @@ __global__ __launch_bounds__(TI *TJ) void k_moist_canon(Geo g, Ptrs p, const rea
 //     the same canonical forms, so that a chunk continues the chunk below it bit for bit.
 // 5 reads (+1 in the corrector) + 2 1/4 writes.  POTTVB, PHI, PHIVB, PVTF of the new state are derived on demand
 // (k_derive_*).  A level is closed one iteration late (TEMP_PARTIAL / TEMP_CLOSE above).
+// TURB (turbulence-coupled handles, late in round 3; k_pott_fused<true, ...> before): + the turbulent tendency of
+// k_turb_tendencies at the own cell, and PHI / PHIVB of the new column stored at every level / interface -- the inputs of the next
+// substep's k_turb_tendencies and of the momentum kernel's staged PHI -- from the hydrostatic integration this sweep carries
+// anyway.  PVTF and POTTVB are not stored (derived once per step for the RHO / RHOVB diagnosis): 10 / 11 passes instead of 12 / 13.
+template <bool TURB>
 __global__ __launch_bounds__(TI *TJ) void k_temp_canon(Geo g, Ptrs p, const real *pott_old, real *pott_out, real dt, int lin)
 {
     int i, j;
@@ -1924,13 +1963,15 @@ __global__ __launch_bounds__(TI *TJ) void k_temp_canon(Geo g, Ptrs p, const real
     double pkN_kp1 = canon_pk(g.pair_top, c_sig[nz], cnew), pkN_kp2 = 0.0;
     real pvbN_kp1 = canon_exner(pkN_kp1), pvbN_kp2 = 0.0;
     real phivbN_kp1 = p.HSURF[c] * CON_G, phivbN_kp2 = 0.0;
+    if (TURB) stb(p.PHIVB, bc + (unsigned)nz * bpl, phivbN_kp1);
     real pvbO_kp1 = ldn(p.PVTFVB, bc + (unsigned)nz * bpl);
     double pkO_kp1 = canon_pk(g.pair_top, c_sig[nz], colp);
     stb(p.PVTFVB, bc + (unsigned)nz * bpl, pvbN_kp1);
     real pvtfO_kp1 = 0.0, pt_kp1 = 0.0, w_kp1 = 0.0, lp_kp2 = 0.0, tpart_kp1 = 0.0, po_kp1 = 0.0;
-    struct In { real pt, im1, ip1, jm1, jp1, uf, uf1, vf, vf1, w, pvb, po; };
+    struct In { real pt, im1, ip1, jm1, jp1, uf, uf1, vf, vf1, w, pvb, po, tb; };
     auto load = [&](int k, In &r) {
         const unsigned q = bc + (unsigned)k * bpl;
+        r.tb = TURB ? ldn(p.TURB_T, q) : (real)0.0;
         r.pt = ldb(p.POTT, q); r.im1 = ldb(p.POTT, q - (unsigned)sizeof(real)); r.ip1 = ldb(p.POTT, q + (unsigned)sizeof(real));
         r.jm1 = ldb(p.POTT, q - bP); r.jp1 = ldb(p.POTT, q + bP);
         r.uf = ldb(p.UWIND, q); r.uf1 = ldb(p.UWIND, q + (unsigned)sizeof(real)); r.vf = ldb(p.VWIND, q); r.vf1 = ldb(p.VWIND, q + bP);
@@ -1959,12 +2000,15 @@ __global__ __launch_bounds__(TI *TJ) void k_temp_canon(Geo g, Ptrs p, const real
             // hydrostatic integration of the new column through level k+1; PHIVB at interface k+1
 #if DYC_EXP_TEMP != 1
             const real pvtfN = canon_pvtf(pvbN_kp2, pkN_kp2, pvbN_kp1, pkN_kp1, rcolN, c_rds[k + 1]);
-            phivbN_kp1 = canon_phivb(canon_phi(phivbN_kp2, pottn, pvtfN, pvbN_kp2), pottn, pvbN_kp1, pvtfN);
-            if ((k + 1) % PHIVB_STRIDE == 0) stb(p.PHIVB, q + bpl, phivbN_kp1);
+            const real phiN = canon_phi(phivbN_kp2, pottn, pvtfN, pvbN_kp2);
+            phivbN_kp1 = canon_phivb(phiN, pottn, pvbN_kp1, pvtfN);
+            if (TURB) stb(p.PHI, q + bpl, phiN);
+            if (TURB || (k + 1) % PHIVB_STRIDE == 0) stb(p.PHIVB, q + bpl, phivbN_kp1);
 #endif
         }
         TEMP_PARTIAL(tpart, colp, c_im1, c_ip1, c_jm1, c_jp1, hr_area, cur.uf, cur.uf1, cur.vf, cur.vf1, cur.pt, cur.im1, cur.ip1, cur.jm1, cur.jp1,
                      c_dif[k], g.i_rad, ldb(p.dPOTTdt_RAD, q))
+        if (TURB) tpart = tpart + cur.tb;
         // Exner function of the new column at interface k
         const double pkN_k = canon_pk(g.pair_top, c_sig[k], cnew);
 #if DYC_EXP_TEMP == 3
@@ -1992,6 +2036,12 @@ __global__ __launch_bounds__(TI *TJ) void k_temp_canon(Geo g, Ptrs p, const real
     // the top level: its upper interface is the model top (sigma-dot = 0)
     TEMP_CLOSE(pott0, tpart_kp1, cnew, cold, r_cnew, (real)0.0, (real)0.0, lp_kp2, c_rds[0], po_kp1, dt)
     stb(pott_out, bc, pott0);
+    if (TURB) {     // PHI of the top level and PHIVB at the model top (after the last level: _kp1 = interface 0, _kp2 = interface 1)
+        const real pvtfN = canon_pvtf(pvbN_kp2, pkN_kp2, pvbN_kp1, pkN_kp1, rcolN, c_rds[0]);
+        const real phiN = canon_phi(phivbN_kp2, pott0, pvtfN, pvbN_kp2);
+        stb(p.PHI, bc, phiN);
+        stb(p.PHIVB, bc, canon_phivb(phiN, pott0, pvbN_kp1, pvtfN));
+    }
 }
 
 }  // namespace dyc

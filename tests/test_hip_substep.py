@@ -82,5 +82,6 @@ def test_fused_substep_is_what_a_single_gpu_step_runs():
         core.step_matsuno(GR.dt, 1); core.sync()
         st = {k: n for k, (n, t) in core.kernel_stats().items() if n}
         assert ('k_substep_fused' in st) == want, (kw, st)
-        assert ('k_pott_fused' in st) == (not want), (kw, st)
+        # (a turbulence-coupled handle: momentum kernel + the temperature kernel in the canonical forms, k_temp_canon<true>)
+        assert ('k_temp_canon' in st) == (not want) and 'k_pott_fused' not in st, (kw, st)
         core.close()

@@ -57,6 +57,7 @@ def _run(tmp_path, tag, nx, ny, nz, steps, moist, f32, fused, rad=0):
     (200, 50, 32, 2, 1, 0, 1),       # BASELINE config 5's ingredients: moisture + a radiative heating rate (staged as one more own-cell tile)
     (360, 180, 64, 2, 0, 0, 0),      # BASELINE config 1's resolution at 64 levels
     (130, 33, 16, 2, 0, 1, 0),       # the float build (DYCORE_STEP_FUSED=1 asks for it; off by default there)
+    (200, 50, 32, 2, 1, 1, 0),       # ... with the moisture sweep in its temperature wavefronts
 ])
 def test_fused_substep_equals_separate_kernels(tmp_path, nx, ny, nz, steps, moist, f32, rad):
     ref, _ = _run(tmp_path, 'separate', nx, ny, nz, steps, moist, f32, 0, rad)

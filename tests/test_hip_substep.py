@@ -53,7 +53,7 @@ def _run(tmp_path, tag, nx, ny, nz, steps, moist, f32, fused, rad=0):
     (90, 45, 8, 3, 0, 0, 0),         # BASELINE config 0's grid
     (130, 33, 16, 2, 0, 0, 0),       # ragged: three tile columns, the last one 2 wide; 33 rows = 8 tile rows + 1
     (64, 6, 8, 2, 0, 0, 0),          # one tile column, two tile rows
-    (200, 50, 32, 2, 1, 0, 0),       # with moisture (k_moist follows the fused launch)
+    (200, 50, 32, 2, 1, 0, 0),       # with moisture (round 3: advanced inside the fused launch; the separate run launches k_moist_canon)
     (200, 50, 32, 2, 1, 0, 1),       # BASELINE config 5's ingredients: moisture + a radiative heating rate (staged as one more own-cell tile)
     (360, 180, 64, 2, 0, 0, 0),      # BASELINE config 1's resolution at 64 levels
     (130, 33, 16, 2, 0, 1, 0),       # the float build (DYCORE_STEP_FUSED=1 asks for it; off by default there)

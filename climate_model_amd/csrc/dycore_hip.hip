@@ -989,8 +989,8 @@ int substep_part(dycore *h, real dt, int sub, int part)
             // (QV, QC: by the whole-substep launch itself, or by the moisture kernel behind it)
             if (h->g.i_moist && !moist_in_substep(h) && (rc = do_moist(h, q, p.QV, p.QC, qv_out, qc_out, dt))) return rc;
             const int nz = h->g.nz;
-            if (h->g.i_moist && (rc = do_halo(h, {{qv_out, 0, 0, nz}, {qc_out, 0, 0, nz}}))) return rc;
             std::vector<HaloSpec> hl = {{t_out, 0, 0, nz}, {p.PVTFVB, 0, 0, nz + 1}};
+            if (h->g.i_moist) { hl.push_back({qv_out, 0, 0, nz}); hl.push_back({qc_out, 0, 0, nz}); }     // (one launch for everything: at most 10 of its 12 slots)
             // (a turbulence-coupled handle stores PHI and PHIVB, not POTTVB and PVTF: k_temp_canon<true>)
             if (!phi_on_demand(h)) { if (!h->g.i_turb) hl.push_back({p.POTTVB, 0, 0, nz + 1}); hl.push_back({p.PHI, 0, 0, nz}); }
             if (!pvtf_on_demand(h) && !h->g.i_turb) hl.push_back({p.PVTF, 0, 0, nz});
